@@ -1,0 +1,98 @@
+// ek_common.h -- shared declarations for libek_hip.so (gfx950 / MI355X only).
+//
+// Internal C++ interface between the translation units of the library; the public C-ABI
+// is include/ek_hip.h.  All matrices are column-major fp64 in device memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#define EK_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      fprintf(stderr, "[ek_hip] %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__,   \
+              hipGetErrorString(_e));                                                   \
+      return -1000 - (int)_e;                                                           \
+    }                                                                                   \
+  } while (0)
+
+namespace ek {
+
+constexpr int kWave = 64;
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ---------------------------------------------------------------- GEMM (ek_gemm.hip)
+// C = alpha * op(A) * op(B) + beta * C, op(X) = X or X^T, batched over `batch` problems
+// with element strides.  lower_only: skip 128x128 tiles strictly above the diagonal
+// (SYRK / SYR2K style updates where only the lower triangle is referenced).
+struct GemmDesc {
+  int M, N, K;
+  bool transA, transB;
+  double alpha, beta;
+  const double *A; int lda; long long strideA;
+  const double *B; int ldb; long long strideB;
+  double *C; int ldc; long long strideC;
+  int batch;
+  bool lower_only;
+};
+void gemm(hipStream_t s, const GemmDesc &g);
+
+inline void gemm(hipStream_t s, bool ta, bool tb, int M, int N, int K, double alpha,
+                 const double *A, int lda, const double *B, int ldb, double beta, double *C,
+                 int ldc, bool lower_only = false) {
+  GemmDesc g{M, N, K, ta, tb, alpha, beta, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, lower_only};
+  gemm(s, g);
+}
+
+// ---------------------------------------------------------------- small utilities (ek_util.hip)
+void copy_matrix(hipStream_t s, int m, int n, const double *src, int lds, double *dst, int ldd);
+void set_matrix(hipStream_t s, int m, int n, double offdiag, double diag, double *A, int lda);
+void symmetrize_lower(hipStream_t s, int n, double *A, int lda);   // upper <- lower^T
+void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, const int *perm,
+                    double *dst, int ldd);                         // dst(:,j) = src(:,perm[j])
+
+// ---------------------------------------------------------------- Cholesky & triangular (ek_chol.hip)
+constexpr int kDiagNB = 128;   // order of the diagonal blocks factored/inverted by one workgroup
+// B = L L^T (lower). invdiag (optional, ld = kDiagNB, ceil(n/128) blocks of 128x128) receives the
+// explicit inverses of the diagonal blocks of L.  *d_info (device int, must be 0 on entry)
+// receives the LAPACK info (first non-positive pivot, 1-based).
+void potrf_lower(hipStream_t s, int n, double *B, int ldb, double *invdiag, int *d_info,
+                 double *work /* >= 128 * n doubles */);
+// inverses of the 128x128 diagonal blocks of a given lower-triangular L
+void trtri_diag_blocks(hipStream_t s, int n, const double *L, int ldl, double *invdiag);
+void trsm_rlt(hipStream_t s, int m, int n, const double *L, int ldl, const double *invdiag,
+              double *X, int ldx, double *work);   // X <- X L^-T   (X m x n, L n x n)
+void trsm_lln(hipStream_t s, int n, int m, const double *L, int ldl, const double *invdiag,
+              double *X, int ldx, double *work);   // X <- L^-1 X   (X n x m)
+void trsm_llt(hipStream_t s, int n, int m, const double *L, int ldl, const double *invdiag,
+              double *X, int ldx, double *work);   // X <- L^-T X   (X n x m)
+void sygst_lower(hipStream_t s, int n, double *A, int lda, const double *L, int ldl,
+                 const double *invdiag, double *work);
+
+// ---------------------------------------------------------------- tridiagonalisation (ek_sytrd.hip)
+struct SytrdWork;   // opaque, sized by sytrd_work_bytes
+size_t sytrd_work_bytes(int n);
+// A (lower, ld even, base 16-B aligned, padded to a multiple of 128 rows/cols with
+// finite values) -> d(n), e(n-1), tau(n-1); V (n x n, ldv) receives the explicit unit
+// lower-trapezoidal reflector matrix (column j = v_j, zeros above row j+1); the scaled
+// reflectors are also written below the sub-diagonal of A as PDSYTRD does.
+void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e, double *tau,
+                 double *V, int ldv, void *work);
+
+// ---------------------------------------------------------------- tridiagonal D&C (ek_stedc.hip)
+size_t stedc_work_bytes(int n);
+// d(n), e(n-1) -> eigenvalues ascending in w(n), eigenvectors in Z (n x n, ldz).
+void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z,
+           int ldz, void *work, int *d_info);
+
+// ---------------------------------------------------------------- back-transformation (ek_ormtr.hip)
+size_t ormtr_work_bytes(int n, int ncols);
+// Z(:, 0:ncols) <- Q Z with Q = H(0)...H(n-2) given by explicit V (see sytrd_lower) and tau.
+void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, const double *tau,
+                 double *Z, int ldz, void *work);
+
+}  // namespace ek

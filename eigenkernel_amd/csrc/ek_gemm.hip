@@ -1,0 +1,174 @@
+// ek_gemm.hip -- fp64 GEMM on the CDNA4 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Used by every MFMA-bound stage of the path: the trailing SYRK of the Cholesky
+// factorisation (reference: generalized_to_standard.f90:24, PDPOTRF), the triangular
+// solves of the reduction/recovery (:37 PDSYGST, :103 PDTRTRS), the SYR2K trailing update
+// of the tridiagonalisation (solver_scalapack_all.f90:59, PDSYTRD), the merge products of
+// the divide & conquer (:96 PDSTEDC) and the block-reflector products of the
+// back-transformation (:115 PDORMTR).
+//
+// Tiling: one 256-thread workgroup (4 waves, 2x2) owns a 128x128 tile of C; each wave a
+// 64x64 sub-tile = 4x4 MFMA 16x16 accumulators (64 fp64 = 128 VGPRs per lane).  K is
+// walked in steps of 16 through LDS.  The MFMA "A" operand is taken from op(B) and the "B"
+// operand from op(A), i.e. the instruction computes the transposed tile: its lane&15 index
+// then runs along M, which is the contiguous direction of column-major C, so every store
+// instruction writes four 128-byte row segments instead of 64 scattered doubles.
+//
+// LDS images depend on which direction is contiguous in global memory:
+//   MC (M- or N-contiguous operand): s[k][128 + 16]  -- global reads and LDS writes are
+//       contiguous along the 128-direction; fragment reads (16 consecutive m per k) are
+//       conflict-free because the 1152-byte row stride shifts each k-row by 32 banks.
+//   KC (K-contiguous operand):       s[128][16 + 1]  -- global reads run along k, and the
+//       17-double row stride keeps both the writes and the fragment reads conflict-free.
+#include "ek_common.h"
+
+namespace ek {
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int MC_LD = BM + 16;   // doubles per k-row of an MC image
+constexpr int KC_LD = BK + 1;    // doubles per m-row of a KC image
+constexpr int TILE_DOUBLES = (BK * MC_LD > BM * KC_LD) ? BK * MC_LD : BM * KC_LD;
+
+struct GemmArgs {
+  int M, N, K;
+  double alpha, beta;
+  const double *A; int lda; long long sA;
+  const double *B; int ldb; long long sB;
+  double *C; int ldc; long long sC;
+  int lower_only;
+  int tiles_m, tiles_n;
+};
+
+// Loads the 128 x 16 slab of an operand into registers (8 doubles per thread).
+// KCONTIG = false: element (x, k) at P[x + k*ld]; true: at P[k + x*ld].
+template <bool KCONTIG>
+__device__ __forceinline__ void load_slab(double (&r)[8], const double *__restrict__ P, int ld,
+                                          int x0, int X, int k0, int K, int t) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = t + 256 * i;
+    int x, k;
+    if (KCONTIG) { k = idx & 15; x = idx >> 4; }
+    else         { x = idx & 127; k = idx >> 7; }
+    const int gx = x0 + x, gk = k0 + k;
+    double v = 0.0;
+    if (gx < X && gk < K)
+      v = KCONTIG ? P[(size_t)gk + (size_t)gx * ld] : P[(size_t)gx + (size_t)gk * ld];
+    r[i] = v;
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_slab(const double (&r)[8], double *s, int t) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = t + 256 * i;
+    if (KCONTIG) { const int k = idx & 15, x = idx >> 4; s[x * KC_LD + k] = r[i]; }
+    else         { const int x = idx & 127, k = idx >> 7; s[k * MC_LD + x] = r[i]; }
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ double frag(const double *s, int x, int k) {
+  return KCONTIG ? s[x * KC_LD + k] : s[k * MC_LD + x];
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+  __shared__ double smem[2 * TILE_DOUBLES];
+  double *sA = smem, *sB = smem + TILE_DOUBLES;
+
+  // tile index: consecutive workgroups walk down M first (they share the B slab in L2)
+  const int tile = blockIdx.x;
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (p.lower_only && n0 > m0 + BM - 1) return;
+
+  const double *__restrict__ A = p.A + (size_t)blockIdx.y * p.sA;
+  const double *__restrict__ B = p.B + (size_t)blockIdx.y * p.sB;
+  double *__restrict__ C = p.C + (size_t)blockIdx.y * p.sC;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  double4_t acc[4][4];   // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  double ra[8], rb[8];
+  // op(A) is M x K: not transposed -> M-contiguous (MC); transposed -> K-contiguous (KC)
+  // op(B) is K x N: not transposed -> K-contiguous (KC); transposed -> N-contiguous (MC)
+  load_slab<TA>(ra, A, p.lda, m0, p.M, 0, p.K, t);
+  load_slab<!TB>(rb, B, p.ldb, n0, p.N, 0, p.K, t);
+
+  for (int k0 = 0; k0 < p.K; k0 += BK) {
+    __syncthreads();
+    store_slab<TA>(ra, sA, t);
+    store_slab<!TB>(rb, sB, t);
+    __syncthreads();
+    if (k0 + BK < p.K) {
+      load_slab<TA>(ra, A, p.lda, m0, p.M, k0 + BK, p.K, t);
+      load_slab<!TB>(rb, B, p.ldb, n0, p.N, k0 + BK, p.K, t);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = frag<TA>(sA, wm + i * 16 + l15, kk + l4);
+        fb[i] = frag<!TB>(sB, wn + i * 16 + l15, kk + l4);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+  }
+
+  // D[i][j]: i = n index = (lane>>4) + 4*reg, j = m index = lane&15
+  const double alpha = p.alpha, beta = p.beta;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = m0 + wm + mi * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + ni * 16 + l4 + 4 * r;
+        if (m < p.M && n < p.N) {
+          double *c = C + (size_t)m + (size_t)n * p.ldc;
+          double v = alpha * acc[ni][mi][r];
+          if (beta != 0.0) v += beta * *c;
+          *c = v;
+        }
+      }
+    }
+}
+
+}  // namespace
+
+void gemm(hipStream_t s, const GemmDesc &g) {
+  if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return;
+  GemmArgs p;
+  p.M = g.M; p.N = g.N; p.K = g.K > 0 ? g.K : 0;
+  p.alpha = g.alpha; p.beta = g.beta;
+  p.A = g.A; p.lda = g.lda; p.sA = g.strideA;
+  p.B = g.B; p.ldb = g.ldb; p.sB = g.strideB;
+  p.C = g.C; p.ldc = g.ldc; p.sC = g.strideC;
+  p.lower_only = g.lower_only ? 1 : 0;
+  p.tiles_m = ceil_div(g.M, BM); p.tiles_n = ceil_div(g.N, BN);
+  dim3 grid(p.tiles_m * p.tiles_n, g.batch), block(256);
+  if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, p);
+  else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, p);
+  else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, s, p);
+}
+
+}  // namespace ek

@@ -1,0 +1,77 @@
+// ek_util.hip -- small data-movement kernels (copies, fills, symmetrisation, column gather).
+// All are plain HBM streaming kernels: one thread per element, consecutive lanes on
+// consecutive rows of the column-major arrays so every wave access is a 512-byte run.
+#include "ek_common.h"
+
+namespace ek {
+namespace {
+
+__global__ void copy_matrix_kernel(int m, int n, const double *__restrict__ src, int lds,
+                                   double *__restrict__ dst, int ldd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  for (int j = blockIdx.y; j < n; j += gridDim.y)
+    dst[(size_t)i + (size_t)j * ldd] = src[(size_t)i + (size_t)j * lds];
+}
+
+__global__ void set_matrix_kernel(int m, int n, double offdiag, double diag, double *A, int lda) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  for (int j = blockIdx.y; j < n; j += gridDim.y)
+    A[(size_t)i + (size_t)j * lda] = (i == j) ? diag : offdiag;
+}
+
+// upper <- lower^T through a 32x33 LDS tile so both the read and the write are coalesced
+__global__ void symmetrize_kernel(int n, double *A, int lda) {
+  __shared__ double tile[32][33];
+  const int bi = blockIdx.x, bj = blockIdx.y;   // tile row / col, only bi >= bj do work
+  if (bi < bj) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int c = ty; c < 32; c += 8) {
+    const int i = bi * 32 + tx, j = bj * 32 + c;
+    tile[c][tx] = (i < n && j < n) ? A[(size_t)i + (size_t)j * lda] : 0.0;
+  }
+  __syncthreads();
+  for (int c = ty; c < 32; c += 8) {
+    // A(bj*32 + tx, bi*32 + c) <- A(bi*32 + c, bj*32 + tx) = tile[tx][c]
+    const int i = bj * 32 + tx, j = bi * 32 + c;
+    if (i < n && j < n && i < j) A[(size_t)i + (size_t)j * lda] = tile[tx][c];
+  }
+}
+
+__global__ void gather_columns_kernel(int m, int n, const double *__restrict__ src, int lds,
+                                      const int *__restrict__ perm, double *__restrict__ dst,
+                                      int ldd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  for (int j = blockIdx.y; j < n; j += gridDim.y)
+    dst[(size_t)i + (size_t)j * ldd] = src[(size_t)i + (size_t)perm[j] * lds];
+}
+
+inline dim3 grid2d(int m, int n) {
+  return dim3(ceil_div(m, 256), n < 4096 ? (n > 0 ? n : 1) : 4096);
+}
+
+}  // namespace
+
+void copy_matrix(hipStream_t s, int m, int n, const double *src, int lds, double *dst, int ldd) {
+  if (m <= 0 || n <= 0) return;
+  hipLaunchKernelGGL(copy_matrix_kernel, grid2d(m, n), dim3(256), 0, s, m, n, src, lds, dst, ldd);
+}
+void set_matrix(hipStream_t s, int m, int n, double offdiag, double diag, double *A, int lda) {
+  if (m <= 0 || n <= 0) return;
+  hipLaunchKernelGGL(set_matrix_kernel, grid2d(m, n), dim3(256), 0, s, m, n, offdiag, diag, A, lda);
+}
+void symmetrize_lower(hipStream_t s, int n, double *A, int lda) {
+  if (n <= 0) return;
+  const int t = ceil_div(n, 32);
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(t, t), dim3(256), 0, s, n, A, lda);
+}
+void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, const int *perm,
+                    double *dst, int ldd) {
+  if (m <= 0 || n <= 0) return;
+  hipLaunchKernelGGL(gather_columns_kernel, grid2d(m, n), dim3(256), 0, s, m, n, src, lds, perm,
+                     dst, ldd);
+}
+
+}  // namespace ek

@@ -1,0 +1,270 @@
+"""Host-side mirror of the reference's solver dispatch, bound to libek_hip.so via ctypes.
+
+Mirrors src/solver_main.f90:22-100 (`eigen_solver(arg, matrix_A, eigenpairs, proc,
+matrix_B)`): the `-s <name>` string selects a back-end; the new arms `hip`, `hip_select`,
+`general_hip`, `general_hip_select` forward to the C-ABI (include/ek_hip.h) exactly where
+the reference forwards `scalapack`, `scalapack_select`, `general_scalapack`,
+`general_scalapack_select` to ScaLAPACK (:55-75).
+
+There is NO CPU fallback here: if libek_hip.so is missing or no GPU is visible the call
+raises (LibraryMissing / RuntimeError), as the reference `terminate`s when built without a
+back-end (solver_elpa_dummy.f90:21).
+"""
+import ctypes
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import descriptor as _d
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libek_hip.so")
+
+N_STAGES = 8
+SOLVERS = ("hip", "hip_select", "general_hip", "general_hip_select")
+# reference solver name each arm replaces (solver_main.f90:55,59,64,66)
+REPLACES = {"hip": "scalapack", "hip_select": "scalapack_select",
+            "general_hip": "general_scalapack", "general_hip_select": "general_scalapack_select"}
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def load_library(path=None):
+    """Loads libek_hip.so and declares every symbol of include/ek_hip.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise LibraryMissing(
+            "libek_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C eigenkernel_amd/csrc` (there is no CPU fallback)" % p)
+    lib = ctypes.CDLL(p)
+    c_int, c_dbl, c_ull = ctypes.c_int, ctypes.c_double, ctypes.c_ulonglong
+    vp = ctypes.c_void_p
+    sigs = {
+        "ek_hip_version": (c_int, []),
+        "ek_hip_init": (c_int, [c_int]),
+        "ek_hip_finalize": (c_int, []),
+        "ek_hip_stage_name": (ctypes.c_char_p, [c_int]),
+        "ek_hip_solve": (c_int, [c_int, c_int, c_int, _dp, _ip, _dp, _ip, _dp, _dp, _ip,
+                                 c_int, c_int, c_int, c_int, _dp, c_int]),
+        "ek_hip_solve_device": (c_int, [c_int, c_int, c_int, vp, c_int, vp, c_int, vp, vp, c_int,
+                                        _dp, c_int]),
+        "ek_hip_potrf": (c_int, [c_int, _dp, _ip]),
+        "ek_hip_sygst": (c_int, [c_int, _dp, _ip, _dp, _ip, _dp]),
+        "ek_hip_sytrd": (c_int, [c_int, _dp, _ip, _dp, _dp, _dp]),
+        "ek_hip_stedc": (c_int, [c_int, _dp, _dp, _dp, _ip]),
+        "ek_hip_ormtr": (c_int, [c_int, c_int, _dp, _ip, _dp, _dp, _ip]),
+        "ek_hip_trtrs": (c_int, [c_int, c_int, _dp, _ip, _dp, _ip]),
+        "ek_hip_dgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_dbl, _dp, c_int, _dp, c_int,
+                                 c_dbl, _dp, c_int, c_int]),
+        "ek_hip_malloc": (c_int, [ctypes.POINTER(vp), c_ull]),
+        "ek_hip_free": (c_int, [vp]),
+        "ek_hip_memcpy_h2d": (c_int, [vp, vp, c_ull]),
+        "ek_hip_memcpy_d2h": (c_int, [vp, vp, c_ull]),
+        "ek_hip_synchronize": (c_int, []),
+        "ek_hip_synth_matrix_device": (c_int, [c_int, c_ull, vp, c_int]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "ek_hip_version", "ek_hip_init", "ek_hip_finalize", "ek_hip_stage_name", "ek_hip_solve",
+    "ek_hip_solve_device", "ek_hip_potrf", "ek_hip_sygst", "ek_hip_sytrd", "ek_hip_stedc",
+    "ek_hip_ormtr", "ek_hip_trtrs", "ek_hip_dgemm", "ek_hip_malloc", "ek_hip_free",
+    "ek_hip_memcpy_h2d", "ek_hip_memcpy_d2h", "ek_hip_synchronize", "ek_hip_synth_matrix_device",
+)
+
+
+def _P(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _I(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _farr(a):
+    a = np.asarray(a, dtype=np.float64)
+    return a if a.flags.f_contiguous else np.asfortranarray(a)
+
+
+def _desc_for(a, nb=None):
+    m, n = a.shape
+    nb = min(_d.g_block_size if nb is None else nb, max(min(m, n), 1))
+    return _d.descinit(m, n, nb, nb, 0, 0, 0, max(1, a.strides[1] // 8 if n > 1 else m))
+
+
+# ----------------------------------------------------------------------------- types
+@dataclass
+class Process:
+    """ek_process_t (processes.f90:6-9)."""
+    my_rank: int = 0
+    n_procs: int = 1
+    context: int = 0
+    n_procs_row: int = 1
+    n_procs_col: int = 1
+    my_proc_row: int = 0
+    my_proc_col: int = 0
+
+
+@dataclass
+class EigenpairsBlacs:
+    """ek_eigenpairs_blacs_t (eigenpairs_types.f90:7-11); type_number = 2."""
+    values: np.ndarray = None
+    desc: np.ndarray = None
+    Vectors: np.ndarray = None
+    type_number: int = 2
+    stage_seconds: dict = field(default_factory=dict)
+    info: int = 0
+
+
+class SolverError(RuntimeError):
+    """Raised where the reference calls terminate(msg, info) (processes.f90:122-139)."""
+
+    def __init__(self, msg, info):
+        super().__init__("%s (info=%d)" % (msg, info))
+        self.info = info
+
+
+# ----------------------------------------------------------------------------- stage-level wrappers
+def potrf(B):
+    """PDPOTRF('L') (generalized_to_standard.f90:24). Returns (B_with_L_in_lower, info)."""
+    lib = load_library()
+    B = np.array(_farr(B), order="F", copy=True)
+    desc = _desc_for(B)
+    info = lib.ek_hip_potrf(B.shape[0], _P(B), _I(desc))
+    return B, info
+
+
+def sygst(A, L):
+    """PDSYGST(1,'L') (generalized_to_standard.f90:37)."""
+    lib = load_library()
+    A = np.array(_farr(A), order="F", copy=True)
+    L = _farr(L)
+    scale = ctypes.c_double(0.0)
+    info = lib.ek_hip_sygst(A.shape[0], _P(A), _I(_desc_for(A)), _P(L), _I(_desc_for(L)),
+                            ctypes.byref(scale))
+    return A, info
+
+
+def sytrd(A):
+    """PDSYTRD('L') (solver_scalapack_all.f90:59). Returns (A_reflectors, d, e, tau, info)."""
+    lib = load_library()
+    A = np.array(_farr(A), order="F", copy=True)
+    n = A.shape[0]
+    d = np.zeros(max(n, 1)); e = np.zeros(max(n, 1)); tau = np.zeros(max(n, 1))
+    info = lib.ek_hip_sytrd(n, _P(A), _I(_desc_for(A)), _P(d), _P(e), _P(tau))
+    return A, d[:n], e[:max(n - 1, 0)], tau[:max(n - 1, 0)], info
+
+
+def stedc(d, e):
+    """PDSTEDC('I') (solver_scalapack_all.f90:96). Returns (w, Z, info)."""
+    lib = load_library()
+    d = np.array(d, dtype=np.float64, copy=True)
+    n = d.shape[0]
+    ee = np.zeros(max(n, 1)); ee[:max(n - 1, 0)] = np.asarray(e, dtype=np.float64)[:max(n - 1, 0)]
+    Z = np.zeros((n, n), order="F")
+    info = lib.ek_hip_stedc(n, _P(d), _P(ee), _P(Z), _I(_desc_for(Z)))
+    return d, Z, info
+
+
+def ormtr(Ar, tau, Z):
+    """PDORMTR('L','L','N') (solver_scalapack_all.f90:115). Returns (QZ, info)."""
+    lib = load_library()
+    Ar = _farr(Ar)
+    Z = np.array(_farr(Z), order="F", copy=True)
+    n = Ar.shape[0]
+    t = np.zeros(max(n, 1)); t[:max(n - 1, 0)] = np.asarray(tau, dtype=np.float64)[:max(n - 1, 0)]
+    info = lib.ek_hip_ormtr(n, Z.shape[1], _P(Ar), _I(_desc_for(Ar)), _P(t), _P(Z), _I(_desc_for(Z)))
+    return Z, info
+
+
+def trtrs(L, Z):
+    """PDTRTRS('L','T','N') (generalized_to_standard.f90:103). Returns (X, info)."""
+    lib = load_library()
+    L = _farr(L)
+    Z = np.array(_farr(Z), order="F", copy=True)
+    info = lib.ek_hip_trtrs(L.shape[0], Z.shape[1], _P(L), _I(_desc_for(L)), _P(Z), _I(_desc_for(Z)))
+    return Z, info
+
+
+def dgemm(transa, transb, alpha, A, B, beta, C, lower_only=False):
+    lib = load_library()
+    A = _farr(A); B = _farr(B)
+    C = np.array(_farr(C), order="F", copy=True)
+    m, n = C.shape
+    k = A.shape[0] if transa else A.shape[1]
+    info = lib.ek_hip_dgemm(int(transa), int(transb), m, n, k, alpha, _P(A), max(1, A.shape[0]),
+                            _P(B), max(1, B.shape[0]), beta, _P(C), max(1, m), int(lower_only))
+    if info:
+        raise RuntimeError("ek_hip_dgemm info=%d" % info)
+    return C
+
+
+# ----------------------------------------------------------------------------- the dispatch
+def eigen_solver(solver_type, matrix_A, matrix_B=None, n_vec=None, block_size=None, proc=None):
+    """eigen_solver (solver_main.f90:22-100) for the hip arms.
+
+    matrix_A / matrix_B: SparseMat (replicated triplets, as the reference passes) or dense
+    symmetric ndarrays.  Returns (eigenpairs: EigenpairsBlacs, proc: Process).
+    Raises SolverError where the reference terminates (info != 0 from the Cholesky,
+    reduction or recovery stage), ValueError for an unknown solver
+    ('eigen_solver: Unknown solver', solver_main.f90:98).
+    """
+    if solver_type not in SOLVERS:
+        raise ValueError("eigen_solver: Unknown solver %r" % (solver_type,))
+    generalized = solver_type.startswith("general_")
+    select = solver_type.endswith("_select")
+    if generalized and matrix_B is None:
+        raise ValueError("eigen_solver: matrix_B is required for %s" % solver_type)
+    lib = load_library()
+    proc = proc or Process()
+    if proc.n_procs_row * proc.n_procs_col != 1:
+        raise NotImplementedError("this round implements the 1x1 process grid")
+
+    def dense(m):
+        return m.to_dense() if hasattr(m, "to_dense") else np.array(_farr(m), order="F", copy=True)
+
+    A = dense(matrix_A)
+    n = A.shape[0]
+    if n_vec is None or not select:
+        if n_vec is not None and n_vec != n and not select:
+            raise ValueError("-n is only legal for *_select solvers (command_argument.f90:186-200)")
+        n_vec = n if not select or n_vec is None else n_vec
+    # setup_distributed_matrix (distribute_matrix.f90:92-148) on the 1x1 grid
+    desc_A, A_loc = _d.setup_distributed_matrix(n, n, block_size=block_size)
+    A_loc[:, :] = A
+    if generalized:
+        desc_B, B_loc = _d.setup_distributed_matrix(n, n, block_size=block_size)
+        B_loc[:, :] = dense(matrix_B)
+    else:
+        desc_B, B_loc = None, None
+    desc_Z, Z_loc = _d.setup_distributed_matrix(n, n, block_size=int(desc_A[_d.BLOCK_ROW_]))
+    w = np.zeros(n)
+    stage = np.zeros(N_STAGES)
+    info = lib.ek_hip_solve(1 if generalized else 0, n, n_vec, _P(A_loc), _I(desc_A),
+                            _P(B_loc) if generalized else None,
+                            _I(desc_B) if generalized else None, _P(w), _P(Z_loc), _I(desc_Z),
+                            1, 1, 0, 0, _P(stage), N_STAGES)
+    if info != 0:
+        raise SolverError("eigen_solver(%s): libek_hip failed" % solver_type, info)
+    ep = EigenpairsBlacs(values=w, desc=desc_Z, Vectors=Z_loc, info=info)
+    ep.stage_seconds = {lib.ek_hip_stage_name(i).decode(): float(stage[i]) for i in range(N_STAGES)}
+    ep.n_vec = n_vec
+    return ep, proc

@@ -1,0 +1,122 @@
+/*
+ * ek_hip.h -- C-ABI of libek_hip.so: the MI355X (gfx950) implementation of EigenKernel's
+ * `scalapack` / `general_scalapack` / `*_select` solver path.
+ *
+ * Drop-in boundary.  The reference selects a back-end by the `-s <name>` string in
+ * eigen_solver (src/solver_main.f90:52-99); each arm has the shape
+ *     solve_with_<x>(n, proc, matrix_A, eigenpairs, matrix_B)         (:65)
+ *     <solver>(proc, desc_A, A_local, [n_vec,] eigenpairs)            (:58, :62)
+ * A Fortran maintainer adds arms `hip`, `hip_select`, `general_hip`, `general_hip_select`
+ * that forward to ek_hip_solve through ISO_C_BINDING (stub in INTEGRATION.md).
+ *
+ * Conventions shared by every entry point:
+ *   - plain C types only; all arrays fp64 column-major ("Fortran order");
+ *   - `desc` is the 9-int ScaLAPACK descriptor with the reference's field order
+ *     (src/descriptor_parameters.f90:2-4): [dtype=1, ctxt, M, N, MB, NB, rsrc, csrc, lld];
+ *   - local arrays are `lld x numroc(N, NB, mycol, 0, npcol)` (distribute_matrix.f90:128-138);
+ *   - the caller owns every array; the library borrows pointers for the duration of the
+ *     call only (solver_scalapack_all.f90 allocates/deallocates around each call);
+ *   - return value is LAPACK `info`: 0 = success, -k = argument k invalid,
+ *     >0 = numerical failure of the stage (the reference aborts on info != 0 after
+ *     pdpotrf/pdsygst/pdtrtrs: generalized_to_standard.f90:25-30,38-41,105-108),
+ *     <= -1000 = HIP runtime error (-1000 - hipError_t);
+ *   - SPMD: called once, collectively, by the single main thread of every rank
+ *     (main.f90:100-104).  This round implements the 1x1 grid (one GPU); a call with
+ *     nprow*npcol != 1 returns the negative index of the offending argument.
+ *   - there is no CPU fallback anywhere behind this interface.
+ */
+#ifndef EK_HIP_H
+#define EK_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EK_HIP_N_STAGES 8
+/* indices into stage_seconds[]; names are the reference's add_event names
+ * (generalized_to_standard.f90:33,44,111; solver_scalapack_all.f90:66,93,104,122) */
+#define EK_STAGE_POTRF   0  /* reduce_generalized:pdpotrf              */
+#define EK_STAGE_SYGST   1  /* reduce_generalized:pdsygst              */
+#define EK_STAGE_SYTRD   2  /* eigen_solver_scalapack_all:pdsytrd      */
+#define EK_STAGE_GATHER  3  /* eigen_solver_scalapack_all:gather1      */
+#define EK_STAGE_STEDC   4  /* eigen_solver_scalapack_all:pdstedc      */
+#define EK_STAGE_ORMTR   5  /* eigen_solver_scalapack_all:pdormtr      */
+#define EK_STAGE_TRTRS   6  /* recovery_generalized                    */
+#define EK_STAGE_COPY    7  /* host<->device staging (not in the reference) */
+
+/* Library / device management ---------------------------------------------------------- */
+int ek_hip_version(void);                       /* 100*major + minor                        */
+int ek_hip_init(int device);                    /* bind this process (rank) to a GPU        */
+int ek_hip_finalize(void);                      /* release cached workspaces                */
+const char *ek_hip_stage_name(int stage);       /* reference event name of a stage index    */
+
+/* Whole path -- replaces solve_with_general_scalapack (solver_scalapack_all.f90:127-168),
+ * eigen_solver_scalapack_all (:19-124) and, with n_vec < n, the *_select arms
+ * (solver_main.f90:59-75, solver_scalapack_select.f90:14-69).
+ *   problem : 0 standard (A x = l x), 1 generalized (A x = l B x, B SPD)
+ *   n_vec   : n for the full spectrum; < n only for the *_select arms
+ *   A_loc   : in: symmetric, lower triangle referenced; out: Householder reflectors
+ *             below the sub-diagonal (as PDSYTRD leaves it)
+ *   B_loc   : in: SPD, lower; out: Cholesky factor L (needed by recovery); NULL if problem==0
+ *   w       : out: n doubles, ascending, first n_vec valid (eigenpairs%blacs%values)
+ *   Z_loc   : out: eigenvectors (eigenpairs%blacs%Vectors), N x N descriptor, same NB as A;
+ *             B-orthonormal (generalized) / orthonormal (standard)
+ *   stage_seconds : NULL or EK_HIP_N_STAGES doubles (device time of each stage)
+ */
+int ek_hip_solve(int problem, int n, int n_vec,
+                 double *A_loc, const int desc_A[9],
+                 double *B_loc, const int desc_B[9],
+                 double *w,
+                 double *Z_loc, const int desc_Z[9],
+                 int nprow, int npcol, int myrow, int mycol,
+                 double *stage_seconds, int n_stages);
+
+/* Same computation on arrays that already live in device memory (HBM) of the bound GPU:
+ * dA (lda), dB (ldb), dZ (ldz) column-major n x n, dw n doubles.  This is what bench.py
+ * times.  Asynchronous errors are reported by the return value (the call synchronises). */
+int ek_hip_solve_device(int problem, int n, int n_vec,
+                        double *dA, int lda, double *dB, int ldb,
+                        double *dw, double *dZ, int ldz,
+                        double *stage_seconds, int n_stages);
+
+/* Stage-level entry points: one per ScaLAPACK call of the reference, host arrays,
+ * 1x1 grid descriptors.  They exist so the path can be replaced (and tested) call by call. */
+/* PDPOTRF('L', n, B, 1, 1, desc_B, info)        generalized_to_standard.f90:24 */
+int ek_hip_potrf(int n, double *B_loc, const int desc_B[9]);
+/* PDSYGST(1, 'L', n, A, 1,1, desc_A, B, 1,1, desc_B, scale, info)   :37 (B holds L) */
+int ek_hip_sygst(int n, double *A_loc, const int desc_A[9],
+                 const double *L_loc, const int desc_B[9], double *scale);
+/* PDSYTRD('L', n, A, 1,1, desc_A, d, e, tau, work, lwork, info)     solver_scalapack_all.f90:59
+ * d(n), e(n-1), tau(n-1) are returned replicated (the reference gathers them, :75-78). */
+int ek_hip_sytrd(int n, double *A_loc, const int desc_A[9], double *d, double *e, double *tau);
+/* PDSTEDC('I', n, d, e, Z, 1,1, desc_Z, ...)                         :96
+ * d in: diagonal, out: eigenvalues ascending; e in: sub-diagonal (destroyed). */
+int ek_hip_stedc(int n, double *d, double *e, double *Z_loc, const int desc_Z[9]);
+/* PDORMTR('L','L','N', n, ncols, A, 1,1, desc_A, tau, Z, 1,1, desc_Z, ...)   :115 */
+int ek_hip_ormtr(int n, int ncols, const double *A_loc, const int desc_A[9], const double *tau,
+                 double *Z_loc, const int desc_Z[9]);
+/* PDTRTRS('L','T','N', n, nrhs, B, 1,1, desc_B, Z, 1,1, desc_Z, info)  generalized_to_standard.f90:103 */
+int ek_hip_trtrs(int n, int nrhs, const double *L_loc, const int desc_B[9],
+                 double *Z_loc, const int desc_Z[9]);
+
+/* Building block exposed for the parity tests: C = alpha op(A) op(B) + beta C on the
+ * fp64 matrix cores (host arrays; transa/transb: 0 = 'N', 1 = 'T'; lower_only: only
+ * tiles touching the lower triangle are updated, as in a SYRK/SYR2K). */
+int ek_hip_dgemm(int transa, int transb, int m, int n, int k, double alpha,
+                 const double *A, int lda, const double *B, int ldb,
+                 double beta, double *C, int ldc, int lower_only);
+
+/* Device-memory helpers for hosts without a HIP runtime binding of their own. */
+int ek_hip_malloc(void **dptr, unsigned long long bytes);
+int ek_hip_free(void *dptr);
+int ek_hip_memcpy_h2d(void *dst, const void *src, unsigned long long bytes);
+int ek_hip_memcpy_d2h(void *dst, const void *src, unsigned long long bytes);
+int ek_hip_synchronize(void);
+/* Fills a device n x n matrix with the synthetic SPD generator of SURVEY.md 8(d)
+ * (seed 1 = A, seed 2 = B), so the large bench configurations need no file or PCIe traffic. */
+int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int ldm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EK_HIP_H */

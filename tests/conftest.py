@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import ek_oracle
+    ek_oracle.lib()
+    return ek_oracle
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library; GPU tests fail loudly (no skip) if it is missing."""
+    from eigenkernel_amd import solver
+    lib = solver.load_library()
+    rc = lib.ek_hip_init(0)
+    assert rc == 0, "ek_hip_init failed: %d" % rc
+    return solver
