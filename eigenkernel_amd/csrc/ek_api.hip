@@ -281,4 +281,301 @@ int ek_hip_trtrs(int n, int nrhs, const double *L_loc, const int desc_B[9], doub
   return 0;
 }
 
+
+int ek_hip_sytrd(int n, double *A_loc, const int desc_A[9], double *d, double *e, double *tau) {
+  if (n < 0) return -1;
+  if (!A_loc && n > 0) return -2;
+  int rc = check_desc(desc_A, 3, n, n); if (rc) return rc;
+  if (n > 0 && !d) return -4;
+  if (n > 1 && !e) return -5;
+  if (n > 1 && !tau) return -6;
+  rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const size_t wb = sytrd_work_bytes(n);
+  void *ws;
+  rc = workspace(al((size_t)ld * ld * 8) + al(wb) + 3 * al((size_t)ld * 8), &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *dA = a.get<double>((size_t)ld * ld);
+  char *work = a.get<char>(wb);
+  double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld);
+  EK_HIP_CHECK(hipMemsetAsync(dA, 0, (size_t)ld * ld * 8, s));
+  EK_HIP_CHECK(hipMemsetAsync(dd, 0, 3 * al((size_t)ld * 8), s));
+  rc = h2d_matrix(n, n, A_loc, desc_A[8], dA, ld, s); if (rc) return rc;
+  sytrd_lower(s, n, dA, ld, dd, de, dt, nullptr, 0, work);
+  EK_HIP_CHECK(hipGetLastError());
+  rc = d2h_matrix(n, n, dA, ld, A_loc, desc_A[8], s); if (rc) return rc;
+  EK_HIP_CHECK(hipMemcpyAsync(d, dd, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  if (n > 1) {
+    EK_HIP_CHECK(hipMemcpyAsync(e, de, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, s));
+    EK_HIP_CHECK(hipMemcpyAsync(tau, dt, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, s));
+  }
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+
+
+int ek_hip_stedc(int n, double *d, double *e, double *Z_loc, const int desc_Z[9]) {
+  if (n < 0) return -1;
+  if (n > 0 && !d) return -2;
+  if (n > 1 && !e) return -3;
+  if (n > 0 && !Z_loc) return -4;
+  int rc = check_desc(desc_Z, 5, n, n); if (rc) return rc;
+  rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const size_t wb = stedc_work_bytes(n);
+  void *ws;
+  rc = workspace(al((size_t)ld * n * 8) + al(wb) + 3 * al((size_t)ld * 8), &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *dZ = a.get<double>((size_t)ld * n);
+  char *work = a.get<char>(wb);
+  double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dw = a.get<double>(ld);
+  EK_HIP_CHECK(hipMemcpyAsync(dd, d, (size_t)n * 8, hipMemcpyHostToDevice, s));
+  EK_HIP_CHECK(hipMemsetAsync(de, 0, (size_t)ld * 8, s));
+  if (n > 1) EK_HIP_CHECK(hipMemcpyAsync(de, e, (size_t)(n - 1) * 8, hipMemcpyHostToDevice, s));
+  EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, 4 * sizeof(int), s));
+  stedc(s, n, dd, de, dw, dZ, ld, work, g_ctx.d_info);
+  EK_HIP_CHECK(hipGetLastError());
+  rc = d2h_matrix(n, n, dZ, ld, Z_loc, desc_Z[8], s); if (rc) return rc;
+  EK_HIP_CHECK(hipMemcpyAsync(d, dw, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  int info = 0;
+  rc = fetch_info(&info); if (rc) return rc;
+  return info;
+}
+
+int ek_hip_ormtr(int n, int ncols, const double *A_loc, const int desc_A[9], const double *tau,
+                 double *Z_loc, const int desc_Z[9]) {
+  if (n < 0) return -1;
+  if (ncols < 0) return -2;
+  if (n > 0 && !A_loc) return -3;
+  int rc = check_desc(desc_A, 4, n, n); if (rc) return rc;
+  if (n > 1 && !tau) return -5;
+  if (n > 0 && ncols > 0 && !Z_loc) return -6;
+  if (!desc_Z) return -7;
+  rc = check_desc(desc_Z, 7, n, desc_Z[3]); if (rc) return rc;
+  if (desc_Z[3] < ncols) return -704;
+  rc = ensure_init(); if (rc) return rc;
+  if (n <= 1 || ncols == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const size_t wb = ormtr_work_bytes(n, ncols);
+  void *ws;
+  rc = workspace(2 * al((size_t)ld * ld * 8) + al((size_t)ld * ncols * 8) + al(wb) + al((size_t)ld * 8), &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *dA = a.get<double>((size_t)ld * ld);
+  double *dV = a.get<double>((size_t)ld * ld);
+  double *dZ = a.get<double>((size_t)ld * ncols);
+  char *work = a.get<char>(wb);
+  double *dt = a.get<double>(ld);
+  rc = h2d_matrix(n, n, A_loc, desc_A[8], dA, ld, s); if (rc) return rc;
+  rc = h2d_matrix(n, ncols, Z_loc, desc_Z[8], dZ, ld, s); if (rc) return rc;
+  EK_HIP_CHECK(hipMemsetAsync(dt, 0, (size_t)ld * 8, s));
+  EK_HIP_CHECK(hipMemcpyAsync(dt, tau, (size_t)(n - 1) * 8, hipMemcpyHostToDevice, s));
+  EK_HIP_CHECK(hipMemsetAsync(dV, 0, (size_t)ld * ld * 8, s));
+  build_explicit_v(s, n, dA, ld, dV, ld);
+  ormtr_lower(s, n, ncols, dV, ld, dt, dZ, ld, work);
+  EK_HIP_CHECK(hipGetLastError());
+  rc = d2h_matrix(n, ncols, dZ, ld, Z_loc, desc_Z[8], s); if (rc) return rc;
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int ldm) {
+  if (n < 0) return -1;
+  if (ldm < (n > 1 ? n : 1)) return -4;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  synth_matrix(g_ctx.stream, n, seed, dM, ldm);
+  EK_HIP_CHECK(hipGetLastError());
+  EK_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// Whole path on device-resident data.
+namespace {
+
+struct StageTimer {
+  hipEvent_t ev[EK_HIP_N_STAGES + 1];
+  bool on = false;
+  int init() {
+    for (auto &e : ev) EK_HIP_CHECK(hipEventCreate(&e));
+    on = true; return 0;
+  }
+  void destroy() { if (on) for (auto &e : ev) (void)hipEventDestroy(e); on = false; }
+};
+
+// Runs the path on user device arrays dA, dB, dZ (column-major, any ld >= n) by way of padded
+// internal work arrays (ld multiple of 128, zero padding), so the kernels see aligned tiles.
+int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
+                        double *dw, double *dZ, int ldz, double *stage_seconds, int n_stages) {
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
+  const size_t wb_sytrd = sytrd_work_bytes(n), wb_stedc = stedc_work_bytes(n),
+               wb_ormtr = ormtr_work_bytes(n, n_vec);
+  const size_t mat = al((size_t)ld * ld * 8);
+  size_t scratch = wb_sytrd;
+  if (wb_stedc > scratch) scratch = wb_stedc;
+  if (wb_ormtr > scratch) scratch = wb_ormtr;
+  const size_t trsm_work = al((size_t)128 * ld * 8);
+  void *ws;
+  int rc = workspace(4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
+                     4 * al((size_t)ld * 8), &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *wA = a.get<double>((size_t)ld * ld);
+  double *wB = a.get<double>((size_t)ld * ld);
+  double *wZ = a.get<double>((size_t)ld * ld);
+  double *wV = a.get<double>((size_t)ld * ld);
+  double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
+  double *twork = a.get<double>((size_t)128 * ld);
+  char *work = a.get<char>(scratch);
+  double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
+
+  StageTimer tm;
+  const bool timing = stage_seconds && n_stages > 0;
+  if (timing) { rc = tm.init(); if (rc) return rc; }
+  int evi = 0;
+  auto mark = [&]() { if (timing) (void)hipEventRecord(tm.ev[evi++], s); };
+
+  EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, 4 * sizeof(int), s));
+  mark();                                                              // 0
+  // stage-in: padded, zero-filled work copies
+  EK_HIP_CHECK(hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s));
+  copy_matrix(s, n, n, dA, lda, wA, ld);
+  if (problem == 1) {
+    EK_HIP_CHECK(hipMemsetAsync(wB, 0, (size_t)ld * ld * 8, s));
+    copy_matrix(s, n, n, dB, ldb, wB, ld);
+  }
+  EK_HIP_CHECK(hipMemsetAsync(wV, 0, (size_t)ld * ld * 8, s));
+  EK_HIP_CHECK(hipMemsetAsync(dd, 0, 4 * al((size_t)ld * 8), s));
+  mark();                                                              // 1
+  if (problem == 1) potrf_lower(s, n, wB, ld, dInv, g_ctx.d_info, twork);
+  mark();                                                              // 2
+  if (problem == 1) sygst_lower(s, n, wA, ld, wB, ld, dInv, twork);
+  mark();                                                              // 3
+  sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, work);
+  mark();                                                              // 4
+  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1);
+  mark();                                                              // 5
+  ormtr_lower(s, n, n_vec, wV, ld, dt, wZ, ld, work);
+  mark();                                                              // 6
+  if (problem == 1) trsm_llt(s, n, n_vec, wB, ld, dInv, wZ, ld, twork);
+  mark();                                                              // 7
+  // stage-out: eigenvalues, eigenvectors, and the in-place results the reference leaves
+  // behind (L in B, reflectors in A)
+  EK_HIP_CHECK(hipMemcpyAsync(dw, dwv, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+  copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
+  copy_matrix(s, n, n, wA, ld, dA, lda);
+  if (problem == 1) copy_matrix(s, n, n, wB, ld, dB, ldb);
+  mark();                                                              // 8
+  EK_HIP_CHECK(hipGetLastError());
+  int info[4] = {0, 0, 0, 0};
+  EK_HIP_CHECK(hipMemcpyAsync(info, g_ctx.d_info, sizeof(info), hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  if (timing) {
+    float ms[8];
+    for (int i = 0; i < 8; ++i) (void)hipEventElapsedTime(&ms[i], tm.ev[i], tm.ev[i + 1]);
+    double st[EK_HIP_N_STAGES] = {0};
+    st[EK_STAGE_COPY] = (ms[0] + ms[7]) * 1e-3;
+    st[EK_STAGE_POTRF] = ms[1] * 1e-3; st[EK_STAGE_SYGST] = ms[2] * 1e-3;
+    st[EK_STAGE_SYTRD] = ms[3] * 1e-3; st[EK_STAGE_GATHER] = 0.0;
+    st[EK_STAGE_STEDC] = ms[4] * 1e-3; st[EK_STAGE_ORMTR] = ms[5] * 1e-3;
+    st[EK_STAGE_TRTRS] = ms[6] * 1e-3;
+    for (int i = 0; i < n_stages && i < EK_HIP_N_STAGES; ++i) stage_seconds[i] = st[i];
+    tm.destroy();
+  }
+  if (info[0] != 0) return info[0];          // Cholesky: leading minor not positive definite
+  if (info[1] != 0) return 100000 + info[1];  // tridiagonal eigensolver did not converge
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ek_hip_solve_device(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
+                        double *dw, double *dZ, int ldz, double *stage_seconds, int n_stages) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_vec < 0 || n_vec > n) return -3;
+  if (n > 0 && !dA) return -4;
+  if (lda < (n > 1 ? n : 1)) return -5;
+  if (problem == 1 && n > 0 && !dB) return -6;
+  if (problem == 1 && ldb < (n > 1 ? n : 1)) return -7;
+  if (n > 0 && !dw) return -8;
+  if (n > 0 && !dZ) return -9;
+  if (ldz < (n > 1 ? n : 1)) return -10;
+  int rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return solve_device_locked(problem, n, n_vec, dA, lda, dB, ldb, dw, dZ, ldz, stage_seconds, n_stages);
+}
+
+int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[9], double *B_loc,
+                 const int desc_B[9], double *w, double *Z_loc, const int desc_Z[9], int nprow,
+                 int npcol, int myrow, int mycol, double *stage_seconds, int n_stages) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_vec < 0 || n_vec > n) return -3;
+  if (n > 0 && !A_loc) return -4;
+  int rc = check_desc(desc_A, 5, n, n); if (rc) return rc;
+  if (problem == 1) {
+    if (n > 0 && !B_loc) return -6;
+    rc = check_desc(desc_B, 7, n, n); if (rc) return rc;
+  }
+  if (n > 0 && !w) return -8;
+  if (n > 0 && !Z_loc) return -9;
+  rc = check_desc(desc_Z, 10, n, n); if (rc) return rc;
+  if (nprow != 1) return -11;     // 1x1 grid this round
+  if (npcol != 1) return -12;
+  if (myrow != 0) return -13;
+  if (mycol != 0) return -14;
+  rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  // user-side device images (exact n x n); freed before returning: the library keeps nothing
+  double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
+  const size_t nn = (size_t)n * n * 8;
+  auto t0 = std::chrono::steady_clock::now();
+  EK_HIP_CHECK(hipMalloc((void **)&uA, nn));
+  EK_HIP_CHECK(hipMalloc((void **)&uZ, nn));
+  EK_HIP_CHECK(hipMalloc((void **)&uw, (size_t)n * 8));
+  if (problem == 1) EK_HIP_CHECK(hipMalloc((void **)&uB, nn));
+  rc = h2d_matrix(n, n, A_loc, desc_A[8], uA, n, s);
+  if (!rc && problem == 1) rc = h2d_matrix(n, n, B_loc, desc_B[8], uB, n, s);
+  if (!rc) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc = -1000 - (int)e; }
+  auto t1 = std::chrono::steady_clock::now();
+  int info = rc;
+  if (!rc) info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, n, stage_seconds, n_stages);
+  auto t2 = std::chrono::steady_clock::now();
+  if (info >= 0 || info > -1000) {
+    // results travel back even when info > 0 so the host can inspect them, as with ScaLAPACK
+    int rc2 = d2h_matrix(n, n_vec, uZ, n, Z_loc, desc_Z[8], s);
+    if (!rc2) rc2 = d2h_matrix(n, n, uA, n, A_loc, desc_A[8], s);
+    if (!rc2 && problem == 1) rc2 = d2h_matrix(n, n, uB, n, B_loc, desc_B[8], s);
+    if (!rc2) { hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (rc2 && info == 0) info = rc2;
+  }
+  auto t3 = std::chrono::steady_clock::now();
+  (void)hipFree(uA); (void)hipFree(uZ); (void)hipFree(uw); if (uB) (void)hipFree(uB);
+  if (stage_seconds && n_stages > EK_STAGE_COPY)
+    stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() +
+                                    std::chrono::duration<double>(t3 - t2).count();
+  return info;
+}
+
 }  // extern "C"

@@ -38,6 +38,8 @@ struct GemmDesc {
   double *C; int ldc; long long strideC;
   int batch;
   bool lower_only;
+  const long long *d_offs = nullptr;   // device: per-batch element offsets {A, B, C} (added to strides)
+  const int *d_dims = nullptr;         // device: per-batch {M, N, K}; host M, N, K are then upper bounds
 };
 void gemm(hipStream_t s, const GemmDesc &g);
 
@@ -94,5 +96,9 @@ size_t ormtr_work_bytes(int n, int ncols);
 // Z(:, 0:ncols) <- Q Z with Q = H(0)...H(n-2) given by explicit V (see sytrd_lower) and tau.
 void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, const double *tau,
                  double *Z, int ldz, void *work);
+// explicit V from the PDSYTRD storage (reflectors below the sub-diagonal of A)
+void build_explicit_v(hipStream_t s, int n, const double *A, int lda, double *V, int ldv);
+// synthetic SPD generator of SURVEY.md 8(d) on the device
+void synth_matrix(hipStream_t s, int n, unsigned long long seed, double *M, int ldm);
 
 }  // namespace ek

@@ -40,6 +40,8 @@ struct GemmArgs {
   double *C; int ldc; long long sC;
   int lower_only;
   int tiles_m, tiles_n;
+  const long long *offs;   // optional per-batch element offsets {A, B, C}
+  const int *dims;         // optional per-batch {M, N, K} (device memory), <= the host M, N, K
 };
 
 // Loads the 128 x 16 slab of an operand into registers (8 doubles per thread).
@@ -86,10 +88,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   if (p.lower_only && n0 > m0 + BM - 1) return;
+  if (p.dims) {
+    p.M = p.dims[3 * blockIdx.y]; p.N = p.dims[3 * blockIdx.y + 1]; p.K = p.dims[3 * blockIdx.y + 2];
+    if (m0 >= p.M || n0 >= p.N) return;
+  }
 
   const double *__restrict__ A = p.A + (size_t)blockIdx.y * p.sA;
   const double *__restrict__ B = p.B + (size_t)blockIdx.y * p.sB;
   double *__restrict__ C = p.C + (size_t)blockIdx.y * p.sC;
+  if (p.offs) {
+    A += p.offs[3 * blockIdx.y]; B += p.offs[3 * blockIdx.y + 1]; C += p.offs[3 * blockIdx.y + 2];
+  }
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
@@ -164,6 +173,7 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   p.C = g.C; p.ldc = g.ldc; p.sC = g.strideC;
   p.lower_only = g.lower_only ? 1 : 0;
   p.tiles_m = ceil_div(g.M, BM); p.tiles_n = ceil_div(g.N, BN);
+  p.offs = g.d_offs; p.dims = g.d_dims;
   dim3 grid(p.tiles_m * p.tiles_n, g.batch), block(256);
   if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, p);
   else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, p);

@@ -1,0 +1,522 @@
+// ek_stedc.hip -- divide & conquer eigensolver for the symmetric tridiagonal matrix,
+// T = Z diag(w) Z^T.  Replaces PDSTEDC('I') at solver_scalapack_all.f90:96 (1x1 grid).
+//
+// Cuppen's method with Gu/Eisenstat stabilisation, organised for the GPU:
+//   * the recursion tree is built on the host once; all sub-problems of one tree height
+//     are processed by the same batched launches, so the whole solve is a fixed,
+//     input-independent launch sequence with NO device->host synchronisation
+//     (deflation counts stay on the device);
+//   * leaves (order <= 32): implicit QL, one wavefront per leaf, Z block in LDS;
+//   * a merge is: rank-sort of the poles -> deflation scan -> column permutation +
+//     Givens rotations -> secular equation (one root per lane, origin shifted to the
+//     nearer pole) -> Loewner weights -> eigenvector matrix of the rank-one update ->
+//     ONE batched MFMA GEMM  Q <- W * S  per tree height.  Deflated columns ride through
+//     the same GEMM as unit columns of S.
+// The O(n^3) part (4/3 N^3 nominal) is therefore entirely in ek::gemm.
+#include "ek_common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace ek {
+namespace {
+
+constexpr int LEAF = 32;
+
+struct Merge { int off, n1, n, pad; };
+
+struct DcBufs {
+  double *d, *e;                 // n: current eigenvalues (column order), scaled off-diagonals
+  double *dsort, *zsort;         // n: poles / weights in ascending pole order
+  double *dl, *zl;               // n: surviving poles / weights
+  double *zhat, *tauv;           // n: Loewner weights, secular shifts
+  int *korig;                    // n: origin pole of each root
+  int *perm, *wcol;              // n: sorted position -> local column / W column
+  int *rotp, *rotn;              // n: rotation list (sorted positions)
+  double *rotc, *rots;           // n
+  double *rho;                   // per merge
+  int *k, *nrot;                 // per merge
+  Merge *merges;
+  double *orgnrm;                // 1
+};
+
+// ------------------------------------------------------------------ scaling / splits
+__global__ void dc_scale_kernel(int n, const double *__restrict__ din, const double *__restrict__ ein,
+                                DcBufs b) {
+  __shared__ double red[256];
+  const int t = threadIdx.x;
+  double m = 0.0;
+  for (int i = t; i < n; i += 256) m = fmax(m, fabs(din[i]));
+  for (int i = t; i < n - 1; i += 256) m = fmax(m, fabs(ein[i]));
+  red[t] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmax(red[t], red[t + o]); __syncthreads(); }
+  const double nrm = red[0] > 0.0 ? red[0] : 1.0;
+  if (t == 0) b.orgnrm[0] = nrm;
+  const double r = 1.0 / nrm;
+  for (int i = t; i < n; i += 256) { b.d[i] = din[i] * r; b.e[i] = (i < n - 1) ? ein[i] * r : 0.0; }
+}
+
+__global__ void dc_split_kernel(int nmerges, DcBufs b) {
+  // each split position belongs to exactly one merge: no conflicts
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nmerges) return;
+  const Merge mg = b.merges[m];
+  const double rho = fabs(b.e[mg.off + mg.n1 - 1]);
+  b.d[mg.off + mg.n1 - 1] -= rho;
+  b.d[mg.off + mg.n1] -= rho;
+}
+
+// ------------------------------------------------------------------ leaves: implicit QL
+struct Leaf { int off, n; };
+
+__global__ __launch_bounds__(64) void dc_leaf_kernel(const Leaf *__restrict__ leaves, DcBufs b,
+                                                     double *__restrict__ Q, int ldq, int *info) {
+  __shared__ double sd[LEAF], se[LEAF + 1];
+  __shared__ double sZ[LEAF][LEAF + 1];   // sZ[col][row]
+  const Leaf lf = leaves[blockIdx.x];
+  const int n = lf.n, lane = threadIdx.x;
+  if (lane < n) { sd[lane] = b.d[lf.off + lane]; se[lane] = (lane < n - 1) ? b.e[lf.off + lane] : 0.0; }
+  for (int idx = lane; idx < LEAF * (LEAF + 1); idx += 64) (&sZ[0][0])[idx] = 0.0;
+  __syncthreads();
+  if (lane < n) sZ[lane][lane] = 1.0;
+  __syncthreads();
+  const double eps = 1.1102230246251565e-16;
+  // every lane runs the same scalar recurrence (uniform control flow); lane r owns row r of Z
+  for (int l = 0; l < n; ++l) {
+    int iter = 0;
+    while (true) {
+      int m;
+      for (m = l; m < n - 1; ++m) {
+        const double dd = fabs(sd[m]) + fabs(sd[m + 1]);
+        if (fabs(se[m]) <= eps * dd) break;
+      }
+      if (m == l) break;
+      if (iter++ == 60) { if (lane == 0) atomicMax(info, lf.off + l + 1); break; }
+      double g = (sd[l + 1] - sd[l]) / (2.0 * se[l]);
+      double r = hypot(g, 1.0);
+      g = sd[m] - sd[l] + se[l] / (g + copysign(r, g));
+      double s = 1.0, c = 1.0, p = 0.0;
+      int i;
+      bool under = false;
+      for (i = m - 1; i >= l; --i) {
+        const double f = s * se[i], bb = c * se[i];
+        r = hypot(f, g);
+        __syncthreads();
+        if (lane == 0) se[i + 1] = r;
+        if (r == 0.0) {
+          __syncthreads();
+          if (lane == 0) { sd[i + 1] -= p; se[m] = 0.0; }
+          under = true;
+          break;
+        }
+        s = f / r; c = g / r;
+        g = sd[i + 1] - p;
+        r = (sd[i] - g) * s + 2.0 * c * bb;
+        p = s * r;
+        __syncthreads();
+        if (lane == 0) sd[i + 1] = g + p;
+        g = c * r - bb;
+        if (lane < n) {
+          const double f2 = sZ[i + 1][lane], z0 = sZ[i][lane];
+          sZ[i + 1][lane] = s * z0 + c * f2;
+          sZ[i][lane] = c * z0 - s * f2;
+        }
+      }
+      __syncthreads();
+      if (under) continue;
+      if (lane == 0) { sd[l] -= p; se[l] = g; se[m] = 0.0; }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (lane < n) {
+    b.d[lf.off + lane] = sd[lane];
+    for (int c = 0; c < n; ++c) Q[(size_t)(lf.off + lane) + (size_t)(lf.off + c) * ldq] = sZ[c][lane];
+  }
+}
+
+// ------------------------------------------------------------------ merge step 1: z and rank sort
+__global__ void dc_sort_kernel(int mbeg, DcBufs b, const double *__restrict__ Q, int ldq) {
+  const Merge mg = b.merges[mbeg + blockIdx.y];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= mg.n) return;
+  const double *d = b.d + mg.off;
+  const double dt = d[t];
+  int rank = 0;
+  for (int i = 0; i < mg.n; ++i) {
+    const double di = d[i];
+    rank += (di < dt || (di == dt && i < t)) ? 1 : 0;
+  }
+  const double rho_in = b.e[mg.off + mg.n1 - 1];
+  const double is2 = 0.70710678118654752440;
+  double z;
+  if (t < mg.n1) z = Q[(size_t)(mg.off + mg.n1 - 1) + (size_t)(mg.off + t) * ldq] * is2;
+  else z = (rho_in < 0.0 ? -1.0 : 1.0) * Q[(size_t)(mg.off + mg.n1) + (size_t)(mg.off + t) * ldq] * is2;
+  b.perm[mg.off + rank] = t;
+  b.dsort[mg.off + rank] = dt;
+  b.zsort[mg.off + rank] = z;
+}
+
+// ------------------------------------------------------------------ merge step 2: deflation (DLAED2)
+__global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
+  __shared__ double red[256];
+  const int mi = mbeg + blockIdx.x;
+  const Merge mg = b.merges[mi];
+  const int n = mg.n, off = mg.off, t = threadIdx.x;
+  double *ds = b.dsort + off, *zs = b.zsort + off;
+  double dm = 0.0, zm = 0.0;
+  for (int i = t; i < n; i += 256) { dm = fmax(dm, fabs(ds[i])); zm = fmax(zm, fabs(zs[i])); }
+  red[t] = dm; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmax(red[t], red[t + o]); __syncthreads(); }
+  dm = red[0]; __syncthreads();
+  red[t] = zm; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmax(red[t], red[t + o]); __syncthreads(); }
+  zm = red[0];
+  if (t != 0) return;
+  const double eps = 1.1102230246251565e-16;
+  const double rho = fabs(2.0 * b.e[off + mg.n1 - 1]);
+  const double tol = 8.0 * eps * fmax(dm, zm);
+  int *wcol = b.wcol + off, *rotp = b.rotp + off, *rotn = b.rotn + off;
+  double *rotc = b.rotc + off, *rots = b.rots + off, *dl = b.dl + off, *zl = b.zl + off;
+  double *dout = b.d + off;
+  int k = 0, ndf = 0, nrot = 0;
+  if (rho * zm <= tol) {
+    for (int i = 0; i < n; ++i) { wcol[i] = n - 1 - ndf; dout[n - 1 - ndf] = ds[i]; ++ndf; }
+  } else {
+    int pj = -1;
+    double dpj = 0.0, zpj = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double zi = zs[i], di = ds[i];
+      if (rho * fabs(zi) <= tol) { wcol[i] = n - 1 - ndf; dout[n - 1 - ndf] = di; ++ndf; continue; }
+      if (pj < 0) { pj = i; dpj = di; zpj = zi; continue; }
+      double s = zpj, c = zi;
+      const double tau = hypot(c, s), tt = di - dpj;
+      c /= tau; s = -s / tau;
+      if (fabs(tt * c * s) <= tol) {
+        // deflate pj: rotate columns (pj, i); the combined weight moves to i
+        rotp[nrot] = pj; rotn[nrot] = i; rotc[nrot] = c; rots[nrot] = s; ++nrot;
+        const double dnew_p = dpj * c * c + di * s * s;
+        const double dnew_i = dpj * s * s + di * c * c;
+        wcol[pj] = n - 1 - ndf; dout[n - 1 - ndf] = dnew_p; ++ndf;
+        pj = i; dpj = dnew_i; zpj = tau;
+      } else {
+        wcol[pj] = k; dl[k] = dpj; zl[k] = zpj; ++k;
+        pj = i; dpj = di; zpj = zi;
+      }
+    }
+    if (pj >= 0) { wcol[pj] = k; dl[k] = dpj; zl[k] = zpj; ++k; }
+  }
+  b.k[mi] = k; b.nrot[mi] = nrot; b.rho[mi] = rho;
+}
+
+// ------------------------------------------------------------------ merge step 3: W = permuted (and rotated) basis
+__global__ void dc_permute_kernel(int mbeg, DcBufs b, const double *__restrict__ Q, int ldq,
+                                  double *__restrict__ W, int ldw) {
+  const Merge mg = b.merges[mbeg + blockIdx.z];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= mg.n) return;
+  const int off = mg.off;
+  for (int t = blockIdx.y; t < mg.n; t += gridDim.y) {
+    const int src = b.perm[off + t], dst = b.wcol[off + t];
+    W[(size_t)(off + r) + (size_t)(off + dst) * ldw] = Q[(size_t)(off + r) + (size_t)(off + src) * ldq];
+  }
+}
+
+__global__ void dc_rotate_kernel(int mbeg, DcBufs b, double *__restrict__ W, int ldw) {
+  const int mi = mbeg + blockIdx.y;
+  const Merge mg = b.merges[mi];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= mg.n) return;
+  const int off = mg.off, nrot = b.nrot[mi];
+  double *Wr = W + (size_t)(off + r) + (size_t)off * ldw;
+  for (int q = 0; q < nrot; ++q) {
+    const int cp = b.wcol[off + b.rotp[off + q]], cn = b.wcol[off + b.rotn[off + q]];
+    const double c = b.rotc[off + q], s = b.rots[off + q];
+    const double a = Wr[(size_t)cp * ldw], bb = Wr[(size_t)cn * ldw];
+    Wr[(size_t)cp * ldw] = c * a + s * bb;
+    Wr[(size_t)cn * ldw] = c * bb - s * a;
+  }
+}
+
+// ------------------------------------------------------------------ merge step 4: secular equation (DLAED4)
+// root i of 1 + rho * sum_j z_j^2 / (d_j - lambda) = 0 in shifted form lambda = d_K + tau,
+// K the nearer pole, so that d_j - lambda_i = (d_j - d_K) - tau keeps full relative accuracy.
+__device__ void secular_root(int k, int i, const double *__restrict__ d, const double *__restrict__ z,
+                             double rho, int *Kout, double *tauout) {
+  if (k == 1) { *Kout = 0; *tauout = rho * z[0] * z[0]; return; }
+  const double eps = 1.1102230246251565e-16;
+  int K;
+  double lo, hi;
+  if (i < k - 1) {
+    const double di = d[i];
+    const double mid = 0.5 * (d[i + 1] - di);
+    double f = 1.0;
+    for (int j = 0; j < k; ++j) f += rho * z[j] * z[j] / ((d[j] - di) - mid);
+    if (f > 0.0) { K = i; lo = 0.0; hi = mid; }
+    else { K = i + 1; lo = -mid; hi = 0.0; }
+  } else {
+    double zn = 0.0;
+    for (int j = 0; j < k; ++j) zn += z[j] * z[j];
+    K = k - 1; lo = 0.0; hi = rho * zn;
+  }
+  const double dK = d[K];
+  double tau = 0.5 * (lo + hi);
+  if (i == k - 1) {
+    double f = 1.0;
+    for (int j = 0; j < k; ++j) f += rho * z[j] * z[j] / ((d[j] - dK) - tau);
+    if (f > 0.0) hi = tau; else lo = tau;
+    tau = 0.5 * (lo + hi);
+  }
+  for (int it = 0; it < 100; ++it) {
+    double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, err = 0.0;
+    for (int j = 0; j <= i; ++j) {
+      const double t = z[j] / ((d[j] - dK) - tau);
+      psi += z[j] * t; dpsi += t * t; err += psi;
+    }
+    err = fabs(err);
+    for (int j = k - 1; j > i; --j) {
+      const double t = z[j] / ((d[j] - dK) - tau);
+      phi += z[j] * t; dphi += t * t; err += phi;
+    }
+    psi *= rho; dpsi *= rho; phi *= rho; dphi *= rho; err *= rho;
+    const double f = 1.0 + psi + phi;
+    err = 8.0 * (phi - psi) + err + 2.0 + fabs(tau) * (dpsi + dphi);
+    if (fabs(f) <= eps * err) break;
+    if (f > 0.0) hi = tau; else lo = tau;
+    if (!(hi - lo > 2.0 * eps * fmax(fabs(lo), fabs(hi)))) break;
+    double next;
+    const double dl_ = (d[i] - dK) - tau;            // < 0
+    const double S = dpsi * dl_ * dl_, s = psi - dpsi * dl_;
+    if (i < k - 1) {
+      const double dr = (d[i + 1] - dK) - tau;        // > 0
+      const double R = dphi * dr * dr, r = phi - dphi * dr;
+      const double a = 1.0 + s + r;
+      const double bq = -(a * (dl_ + dr) + S + R);
+      const double cq = a * dl_ * dr + S * dr + R * dl_;
+      double eta;
+      if (a == 0.0) eta = (bq != 0.0) ? -cq / bq : 0.0;
+      else {
+        double disc = bq * bq - 4.0 * a * cq;
+        if (disc < 0.0) disc = 0.0;
+        const double q = -0.5 * (bq + copysign(sqrt(disc), bq));
+        const double e1 = q / a, e2 = (q != 0.0) ? cq / q : e1;
+        const bool in1 = (e1 > dl_ && e1 < dr), in2 = (e2 > dl_ && e2 < dr);
+        eta = in1 ? e1 : e2;
+        if (in1 && in2) eta = (fabs(e1) < fabs(e2)) ? e1 : e2;
+      }
+      next = tau + eta;
+    } else {
+      const double a = 1.0 + s;
+      next = (a > 0.0) ? tau + (dl_ + S / a) : hi;
+    }
+    if (!(next > lo && next < hi)) next = 0.5 * (lo + hi);
+    tau = next;
+  }
+  *Kout = K; *tauout = tau;
+}
+
+__global__ void dc_secular_kernel(int mbeg, DcBufs b) {
+  const int mi = mbeg + blockIdx.y;
+  const Merge mg = b.merges[mi];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = b.k[mi];
+  if (i >= k) return;
+  int K; double tau;
+  secular_root(k, i, b.dl + mg.off, b.zl + mg.off, b.rho[mi], &K, &tau);
+  b.korig[mg.off + i] = K;
+  b.tauv[mg.off + i] = tau;
+  b.d[mg.off + i] = b.dl[mg.off + K] + tau;    // new eigenvalue, W column i
+}
+
+// Loewner / Gu-Eisenstat weights: zhat_j = sign(z_j) sqrt(| prod_i (d_j - lam_i) / prod_{i!=j} (d_j - d_i) |)
+__global__ void dc_zhat_kernel(int mbeg, DcBufs b) {
+  const int mi = mbeg + blockIdx.y;
+  const Merge mg = b.merges[mi];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = b.k[mi];
+  if (j >= k) return;
+  const double *dl = b.dl + mg.off, *tauv = b.tauv + mg.off;
+  const int *korig = b.korig + mg.off;
+  const double dj = dl[j];
+  double p = 1.0;
+  for (int i = 0; i < k; ++i) {
+    const double del = (dj - dl[korig[i]]) - tauv[i];   // d_j - lambda_i
+    p *= (i == j) ? del : del / (dj - dl[i]);
+  }
+  b.zhat[mg.off + j] = copysign(sqrt(fabs(p)), b.zl[mg.off + j]);
+}
+
+// Column c of S (n x n): c < k: normalised eigenvector of the rank-one update in rows 0..k-1;
+// c >= k: unit vector (deflated column passes through the GEMM unchanged).
+__global__ __launch_bounds__(256) void dc_vectors_kernel(int mbeg, DcBufs b, double *__restrict__ S,
+                                                         int lds) {
+  __shared__ double red[4];
+  const int mi = mbeg + blockIdx.y;
+  const Merge mg = b.merges[mi];
+  const int c = blockIdx.x, t = threadIdx.x;
+  if (c >= mg.n) return;
+  const int k = b.k[mi], n = mg.n;
+  double *col = S + (size_t)mg.off + (size_t)(mg.off + c) * lds;
+  if (c >= k) {
+    for (int r = t; r < n; r += 256) col[r] = (r == c) ? 1.0 : 0.0;
+    return;
+  }
+  const double *dl = b.dl + mg.off, *zh = b.zhat + mg.off;
+  const double dK = dl[b.korig[mg.off + c]], tau = b.tauv[mg.off + c];
+  double ss = 0.0;
+  for (int j = t; j < k; j += 256) {
+    const double u = zh[j] / ((dl[j] - dK) - tau);
+    ss += u * u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+  if ((t & 63) == 0) red[t >> 6] = ss;
+  __syncthreads();
+  const double inv = 1.0 / sqrt((red[0] + red[1]) + (red[2] + red[3]));
+  for (int j = t; j < n; j += 256)
+    col[j] = (j < k) ? zh[j] / ((dl[j] - dK) - tau) * inv : 0.0;
+}
+
+// ------------------------------------------------------------------ final ordering
+__global__ void dc_final_rank_kernel(int n, DcBufs b, double *__restrict__ w, int *__restrict__ perm) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double dt = b.d[t];
+  int rank = 0;
+  for (int i = 0; i < n; ++i) {
+    const double di = b.d[i];
+    rank += (di < dt || (di == dt && i < t)) ? 1 : 0;
+  }
+  w[rank] = dt * b.orgnrm[0];
+  perm[rank] = t;
+}
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Plan {
+  std::vector<Leaf> leaves;
+  std::vector<std::vector<Merge>> levels;   // by height
+  int height(int off, int n) {
+    if (n <= LEAF) { leaves.push_back({off, n}); return 0; }
+    const int n1 = n / 2;
+    const int h1 = height(off, n1), h2 = height(off + n1, n - n1);
+    const int h = std::max(h1, h2) + 1;
+    if ((int)levels.size() < h) levels.resize(h);
+    levels[h - 1].push_back({off, n1, n, 0});
+    return h;
+  }
+};
+
+struct WorkLayout {
+  size_t off_Q, off_S, off_vec, off_int, off_merge, off_leaf, off_offs, off_dims, total;
+  int nmerge_cap, nleaf_cap;
+  explicit WorkLayout(int n) {
+    nleaf_cap = n / (LEAF / 2) + 2; nmerge_cap = nleaf_cap;
+    size_t o = 0;
+    off_Q = o; o += al256((size_t)n * n * 8);
+    off_S = o; o += al256((size_t)n * n * 8);
+    off_vec = o; o += 12 * al256((size_t)(n + 8) * 8) + al256((size_t)nmerge_cap * 8) + 256;
+    off_int = o; o += 6 * al256((size_t)(n + 8) * 4) + 2 * al256((size_t)nmerge_cap * 4);
+    off_merge = o; o += al256((size_t)nmerge_cap * sizeof(Merge));
+    off_leaf = o; o += al256((size_t)nleaf_cap * sizeof(Leaf));
+    off_offs = o; o += al256((size_t)nmerge_cap * 3 * 8);
+    off_dims = o; o += al256((size_t)nmerge_cap * 3 * 4);
+    total = o;
+  }
+};
+
+}  // namespace
+
+size_t stedc_work_bytes(int n) { return WorkLayout(n > 0 ? n : 1).total; }
+
+void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z, int ldz,
+           void *work, int *d_info) {
+  if (n <= 0) return;
+  const WorkLayout L(n);
+  char *base = (char *)work;
+  double *Q = (double *)(base + L.off_Q);      // current eigenvector basis (ld = n)
+  double *S = (double *)(base + L.off_S);      // rank-one eigenvector matrices (ld = n)
+  const int ldq = n, lds = n;
+  DcBufs b;
+  {
+    char *p = base + L.off_vec;
+    auto dv = [&](size_t cnt) { double *r = (double *)p; p += al256(cnt * 8); return r; };
+    b.d = dv(n + 8); b.e = dv(n + 8); b.dsort = dv(n + 8); b.zsort = dv(n + 8); b.dl = dv(n + 8);
+    b.zl = dv(n + 8); b.zhat = dv(n + 8); b.tauv = dv(n + 8); b.rotc = dv(n + 8); b.rots = dv(n + 8);
+    double *spare1 = dv(n + 8), *spare2 = dv(n + 8); (void)spare1; (void)spare2;
+    b.rho = dv(L.nmerge_cap); b.orgnrm = (double *)p;
+    char *q = base + L.off_int;
+    auto iv = [&](size_t cnt) { int *r = (int *)q; q += al256(cnt * 4); return r; };
+    b.korig = iv(n + 8); b.perm = iv(n + 8); b.wcol = iv(n + 8); b.rotp = iv(n + 8); b.rotn = iv(n + 8);
+    int *fperm = iv(n + 8); (void)fperm;
+    b.k = iv(L.nmerge_cap); b.nrot = iv(L.nmerge_cap);
+    b.merges = (Merge *)(base + L.off_merge);
+  }
+  int *fperm = (int *)(base + L.off_int + 5 * al256((size_t)(n + 8) * 4));
+  Leaf *d_leaves = (Leaf *)(base + L.off_leaf);
+  long long *d_offs = (long long *)(base + L.off_offs);
+  int *d_dims = (int *)(base + L.off_dims);
+
+  Plan plan;
+  plan.height(0, n);
+  std::vector<Merge> all;
+  std::vector<long long> offs;
+  std::vector<int> dims;
+  std::vector<int> lvl_beg;
+  for (auto &lv : plan.levels) {
+    lvl_beg.push_back((int)all.size());
+    for (auto &m : lv) {
+      all.push_back(m);
+      const long long o = (long long)m.off + (long long)m.off * n;
+      offs.push_back((long long)m.off + (long long)m.off * ldz);   // A = W (in Z buffer)
+      offs.push_back(o);                                           // B = S
+      offs.push_back(o);                                           // C = Q
+      dims.push_back(m.n); dims.push_back(m.n); dims.push_back(m.n);
+    }
+  }
+  lvl_beg.push_back((int)all.size());
+  (void)hipMemcpyAsync(d_leaves, plan.leaves.data(), plan.leaves.size() * sizeof(Leaf),
+                       hipMemcpyHostToDevice, s);
+  if (!all.empty()) {
+    (void)hipMemcpyAsync(b.merges, all.data(), all.size() * sizeof(Merge), hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(d_dims, dims.data(), dims.size() * 4, hipMemcpyHostToDevice, s);
+  }
+  (void)hipStreamSynchronize(s);   // host vectors go out of scope; pageable copies are staged anyway
+
+  hipLaunchKernelGGL(dc_scale_kernel, dim3(1), dim3(256), 0, s, n, d, e, b);
+  if (!all.empty())
+    hipLaunchKernelGGL(dc_split_kernel, dim3(ceil_div((int)all.size(), 256)), dim3(256), 0, s,
+                       (int)all.size(), b);
+  (void)hipMemsetAsync(Q, 0, (size_t)n * n * 8, s);
+  hipLaunchKernelGGL(dc_leaf_kernel, dim3((int)plan.leaves.size()), dim3(64), 0, s, d_leaves, b, Q, ldq,
+                     d_info);
+
+  double *W = Z;   // the output array doubles as the permuted-basis scratch until the end
+  for (size_t lv = 0; lv < plan.levels.size(); ++lv) {
+    const int mbeg = lvl_beg[lv], cnt = lvl_beg[lv + 1] - mbeg;
+    int maxn = 0;
+    for (auto &m : plan.levels[lv]) maxn = std::max(maxn, m.n);
+    const int gx = ceil_div(maxn, 256);
+    hipLaunchKernelGGL(dc_sort_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, Q, ldq);
+    hipLaunchKernelGGL(dc_deflate_kernel, dim3(cnt), dim3(256), 0, s, mbeg, b);
+    const int gy = std::min(maxn, std::max(1, 4096 / std::max(1, gx * cnt)));
+    hipLaunchKernelGGL(dc_permute_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, Q, ldq, W, ldz);
+    hipLaunchKernelGGL(dc_rotate_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, W, ldz);
+    hipLaunchKernelGGL(dc_secular_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b);
+    hipLaunchKernelGGL(dc_zhat_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b);
+    hipLaunchKernelGGL(dc_vectors_kernel, dim3(maxn, cnt), dim3(256), 0, s, mbeg, b, S, lds);
+    GemmDesc g{};
+    g.M = maxn; g.N = maxn; g.K = maxn; g.transA = false; g.transB = false; g.alpha = 1.0; g.beta = 0.0;
+    g.A = W; g.lda = ldz; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
+    g.C = Q; g.ldc = ldq; g.strideC = 0; g.batch = cnt; g.lower_only = false;
+    g.d_offs = d_offs + 3 * (size_t)mbeg; g.d_dims = d_dims + 3 * (size_t)mbeg;
+    gemm(s, g);
+  }
+  hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, b, w, fperm);
+  gather_columns(s, n, n, Q, ldq, fperm, Z, ldz);
+}
+
+}  // namespace ek

@@ -48,6 +48,26 @@ __global__ void gather_columns_kernel(int m, int n, const double *__restrict__ s
     dst[(size_t)i + (size_t)j * ldd] = src[(size_t)i + (size_t)perm[j] * lds];
 }
 
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  unsigned long long z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+// M(i,j) = M(j,i) = u(seed, max(i,j), min(i,j)) / sqrt(n) + 2 [i == j]   
+__global__ void synth_kernel(int n, unsigned long long seed, double inv, double *M, int ldm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int j = blockIdx.y; j < n; j += gridDim.y) {
+    const unsigned long long hi = i > j ? i : j, lo = i > j ? j : i;
+    const unsigned long long r = splitmix64((seed << 40) + hi * (unsigned long long)n + lo);
+    const double u = (double)(r >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    M[(size_t)i + (size_t)j * ldm] = __dadd_rn(__dmul_rn(u, inv), (i == j ? 2.0 : 0.0));  // no FMA: bit-equal to the CPU generator
+  }
+}
+
 inline dim3 grid2d(int m, int n) {
   return dim3(ceil_div(m, 256), n < 4096 ? (n > 0 ? n : 1) : 4096);
 }
@@ -72,6 +92,11 @@ void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, con
   if (m <= 0 || n <= 0) return;
   hipLaunchKernelGGL(gather_columns_kernel, grid2d(m, n), dim3(256), 0, s, m, n, src, lds, perm,
                      dst, ldd);
+}
+
+void synth_matrix(hipStream_t s, int n, unsigned long long seed, double *M, int ldm) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(synth_kernel, grid2d(n, n), dim3(256), 0, s, n, seed, 1.0 / sqrt((double)n), M, ldm);
 }
 
 }  // namespace ek

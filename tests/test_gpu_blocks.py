@@ -108,3 +108,30 @@ def test_trtrs_singular_diag(hip, oracle):
     _, info_or = oracle.trtrs_lt(L, np.ones((n, 2)))
     _, info = hip.trtrs(L, np.ones((n, 2)))
     assert info == info_or == 21
+
+
+def _tridiag_check(A, Ar, d, e, tau, oracle):
+    """Q T Q^T == A with Q rebuilt from the reflectors by the oracle's ormtr."""
+    n = A.shape[0]
+    T = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    Q = oracle.ormtr_lower(Ar, tau, np.eye(n))
+    return np.abs(Q @ T @ Q.T - A).max(), np.abs(Q.T @ Q - np.eye(n)).max()
+
+
+@pytest.mark.parametrize("n", [2, 3, 17, 64, 65, 128, 130, 257, 400, 700])
+def test_sytrd_matches_oracle(hip, oracle, n):
+    A = oracle.synth_matrix(n, 1)
+    Ar_or, d_or, e_or, tau_or = oracle.sytrd_lower(A)
+    Ar, d, e, tau, info = hip.sytrd(A)
+    assert info == 0
+    scale = np.abs(A).max()
+    # same Householder convention => d, e, tau agree element-wise up to rounding growth
+    assert np.abs(d - d_or).max() <= 64 * n * EPS * scale
+    assert np.abs(np.abs(e) - np.abs(e_or)).max() <= 64 * n * EPS * scale
+    assert np.abs(tau - tau_or).max() <= 256 * n * EPS
+    res, orth = _tridiag_check(A, Ar, d, e, tau, oracle)
+    assert res <= 64 * n * EPS * scale
+    assert orth <= 64 * n * EPS
+    il = np.tril_indices(n, -2)
+    if len(il[0]):
+        assert np.abs(Ar[il] - Ar_or[il]).max() <= 512 * n * EPS

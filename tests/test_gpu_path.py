@@ -1,0 +1,188 @@
+"""GPU parity of the tridiagonal eigensolver, the back-transformation and the whole path,
+through the C-ABI, against the CPU oracle, the reference's golden files and
+oracle-independent identities.  Tolerances follow SURVEY.md 8(c):
+    eigenvalues   max|l - l_oracle| <= N eps max|l|
+    residual      max_j ||A v_j - l_j B v_j||_2 / ||A||_F <= 1e-14 sqrt(N/1024) (floor 1e-14)
+    orthogonality ||V^T B V - I||_F (normalised as verifier.f90:310-325) <= 1e-11
+"""
+import os
+
+import numpy as np
+import pytest
+
+from eigenkernel_amd import read_matrix_file
+from eigenkernel_amd.verifier import eval_orthogonality, eval_residual_norm, get_ipratios
+
+pytestmark = pytest.mark.gpu
+EPS = 2.220446049250313e-16
+
+
+def _check_pairs(A, B, w, Z, n_vec=None):
+    n = A.shape[0]
+    n_vec = n if n_vec is None else n_vec
+    a_norm, ave, mx = eval_residual_norm(A, w[:n_vec], Z[:, :n_vec], B)
+    orth = eval_orthogonality(Z[:, :n_vec], B)
+    assert mx <= 1e-14 * max(1.0, np.sqrt(n / 1024.0)), mx
+    assert orth <= 1e-11, orth
+
+
+def _tridiag(n, seed, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "random":
+        return rng.uniform(-1, 1, n), rng.uniform(-1, 1, n - 1)
+    if kind == "wilkinson":          # W_n^+: pairs of nearly equal eigenvalues
+        m = (n - 1) / 2.0
+        return np.abs(np.arange(n) - m), np.ones(n - 1)
+    if kind == "toeplitz":           # 1-2-1: known spectrum 2 - 2 cos(k pi/(n+1))
+        return 2.0 * np.ones(n), -np.ones(n - 1)
+    if kind == "glued":              # weakly coupled identical blocks: heavy deflation
+        d = np.tile(np.arange(1.0, 11.0), n // 10 + 1)[:n]
+        e = np.ones(n - 1) * 0.5
+        e[9::10] = 1e-9
+        return d, e
+    if kind == "zero_offdiag":       # already diagonal, unsorted
+        return rng.uniform(-1, 1, n), np.zeros(n - 1)
+    if kind == "identity":
+        return np.ones(n), np.zeros(n - 1)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["random", "wilkinson", "toeplitz", "glued", "zero_offdiag", "identity"])
+@pytest.mark.parametrize("n", [1, 2, 21, 32, 33, 64, 100, 257, 600])
+def test_stedc_matches_oracle(hip, oracle, n, kind):
+    if n == 1:
+        d, e = np.array([0.7]), np.zeros(0)
+    else:
+        d, e = _tridiag(n, n, kind)
+    w_or, Z_or = oracle.stedc(d, e)
+    w, Z, info = hip.stedc(d, e)
+    assert info == 0
+    T = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    scale = max(np.abs(T).max(), 1e-300)
+    assert np.all(np.diff(w) >= 0)
+    assert np.abs(w - w_or).max() <= 4 * n * EPS * scale
+    assert np.abs(T @ Z - Z * w).max() <= 32 * n * EPS * scale
+    assert np.abs(Z.T @ Z - np.eye(n)).max() <= 32 * n * EPS
+    if kind == "toeplitz":
+        exact = 2.0 - 2.0 * np.cos(np.arange(1, n + 1) * np.pi / (n + 1))
+        assert np.abs(w - exact).max() <= 4 * n * EPS * 4
+
+
+@pytest.mark.parametrize("n,ncols", [(2, 2), (5, 3), (64, 64), (129, 129), (130, 7), (300, 300), (515, 100)])
+def test_ormtr_matches_oracle(hip, oracle, n, ncols):
+    A = oracle.synth_matrix(n, 1)
+    Ar, d, e, tau = oracle.sytrd_lower(A)
+    Z = np.asfortranarray(np.random.default_rng(n).uniform(-1, 1, (n, ncols)))
+    ref = oracle.ormtr_lower(Ar, tau, Z)
+    got, info = hip.ormtr(Ar, tau, Z)
+    assert info == 0
+    assert np.abs(got - ref).max() <= 32 * n * EPS * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n", [1, 2, 30, 100, 128, 257, 640, 1000])
+def test_solve_standard_matches_oracle(hip, oracle, n):
+    A = oracle.synth_matrix(n, 1)
+    w_or, _, info_or, _ = oracle.solve(A)
+    ep, _ = hip.eigen_solver("hip", A)
+    w = ep.values
+    assert np.abs(w - w_or).max() <= n * EPS * np.abs(w_or).max() * 4
+    _check_pairs(A, None, w, ep.Vectors)
+
+
+@pytest.mark.parametrize("n", [1, 2, 30, 100, 128, 257, 640, 1000])
+def test_solve_generalized_matches_oracle(hip, oracle, n):
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    w_or, _, info_or, _ = oracle.solve(A, B)
+    ep, _ = hip.eigen_solver("general_hip", A, B)
+    w = ep.values
+    assert np.abs(w - w_or).max() <= 4 * n * EPS * np.abs(w_or).max()
+    _check_pairs(A, B, w, ep.Vectors)
+    names = set(ep.stage_seconds)
+    assert "reduce_generalized:pdpotrf" in names and "eigen_solver_scalapack_all:pdsytrd" in names
+
+
+def test_golden_bnz30_generalized(hip, golden_dir):
+    """config C1: the reference's own shipped case, -s general_scalapack (README.md:22)."""
+    A = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_A.mtx"))
+    B = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_B.mtx"))
+    ev = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ev.txt"))[:, 1]
+    ipr = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ipr.txt"))[:, 1]
+    ep, _ = hip.eigen_solver("general_hip", A, B)
+    assert np.abs(ep.values - ev).max() <= 1e-14          # golden has 16 digits
+    _check_pairs(A.to_dense(), B.to_dense(), ep.values, ep.Vectors)
+    got_ipr = get_ipratios(ep.Vectors, B.to_dense())
+    # near-degenerate pairs (l2,l3 differ by 4e-9) make individual IPRs ill-conditioned: 1e-6
+    assert np.abs(got_ipr - ipr).max() <= 1e-6
+
+
+def test_golden_vcnt400_standard(hip, golden_dir):
+    A = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_VCNT400std_A.mtx"))
+    E = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_VCNT400std_E.txt"))[:, 1]
+    ep, _ = hip.eigen_solver("hip", A)
+    assert np.abs(ep.values - E).max() <= 1e-12           # golden has 12 digits
+    _check_pairs(A.to_dense(), None, ep.values, ep.Vectors)
+
+
+@pytest.mark.parametrize("n,n_vec", [(100, 10), (300, 300), (640, 64)])
+def test_select_arms(hip, oracle, n, n_vec):
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    w_or, _, _, _ = oracle.solve(A, B)
+    ep, _ = hip.eigen_solver("general_hip_select", A, B, n_vec=n_vec)
+    assert np.abs(ep.values[:n_vec] - w_or[:n_vec]).max() <= 4 * n * EPS * np.abs(w_or).max()
+    _check_pairs(A, B, ep.values, ep.Vectors, n_vec)
+    ep2, _ = hip.eigen_solver("hip_select", A, n_vec=n_vec)
+    w2, _, _, _ = oracle.solve(A)
+    assert np.abs(ep2.values[:n_vec] - w2[:n_vec]).max() <= 4 * n * EPS * np.abs(w2).max()
+
+
+def test_not_positive_definite_B_aborts_like_reference(hip, oracle):
+    """generalized_to_standard.f90:25-30: info(pdpotrf) != 0 -> terminate."""
+    n = 150
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    B[70, 70] = -3.0
+    _, info_or = oracle.potrf_lower(B)
+    with pytest.raises(hip.SolverError) as ei:
+        hip.eigen_solver("general_hip", A, B)
+    assert ei.value.info == info_or == 71
+
+
+def test_unknown_solver_and_missing_B(hip, oracle):
+    A = oracle.synth_matrix(10, 1)
+    with pytest.raises(ValueError):
+        hip.eigen_solver("general_elpa1", A, A)     # out of scope arms are not silently accepted
+    with pytest.raises(ValueError):
+        hip.eigen_solver("general_hip", A)
+
+
+def test_device_resident_solve_and_synth(hip, oracle):
+    """bench.py's entry: inputs generated and solved in HBM; generator is bit-equal to the oracle's."""
+    import ctypes
+    lib = hip.load_library()
+    n = 384
+    nn = n * n * 8
+    ptrs = [ctypes.c_void_p() for _ in range(4)]
+    for p, sz in zip(ptrs, (nn, nn, nn, n * 8)):
+        assert lib.ek_hip_malloc(ctypes.byref(p), sz) == 0
+    dA, dB, dZ, dw = ptrs
+    assert lib.ek_hip_synth_matrix_device(n, 1, dA, n) == 0
+    assert lib.ek_hip_synth_matrix_device(n, 2, dB, n) == 0
+    hA = np.zeros((n, n), order="F")
+    lib.ek_hip_memcpy_d2h(hA.ctypes.data, dA, nn)
+    assert np.array_equal(hA, oracle.synth_matrix(n, 1))
+    st = np.zeros(8)
+    info = lib.ek_hip_solve_device(1, n, n, dA, n, dB, n, dw, dZ, n,
+                                   st.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 8)
+    assert info == 0
+    w = np.zeros(n); Z = np.zeros((n, n), order="F")
+    lib.ek_hip_memcpy_d2h(w.ctypes.data, dw, n * 8)
+    lib.ek_hip_memcpy_d2h(Z.ctypes.data, dZ, nn)
+    A = oracle.synth_matrix(n, 1); B = oracle.synth_matrix(n, 2)
+    w_or, _, _, _ = oracle.solve(A, B)
+    assert np.abs(w - w_or).max() <= 4 * n * EPS * np.abs(w_or).max()
+    _check_pairs(A, B, w, Z)
+    assert st[:7].sum() > 0
+    for p in ptrs:
+        lib.ek_hip_free(p)
