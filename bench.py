@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the hot path on MI355X.
+
+A "step" is one full-spectrum generalized eigensolve (Cholesky + reduction +
+tridiagonalisation + divide & conquer + back-transformation + recovery) of the synthetic
+dense SPD pair of SURVEY.md 8(d) (A = seed 1, B = seed 2) at N = 16384 (BASELINE.json
+configs[2], the configuration the metric is quoted on), inputs resident in HBM when the
+timed region starts (they are regenerated on the device before every step, outside the
+timed region, because the solve overwrites A and B as the reference does).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 16384] [--problem gep|sep]
+
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; this round every
+rank solves its own problem (replicas; the 2-D block-cyclic multi-GPU decomposition is the
+next row of SURVEY.md 8(e)) -- no data-path collective, "scaling": "weak".
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline"     : the dominant kernel (symv of the tridiagonalisation, HBM-bound), timed
+                   live with HIP events on its launch stream in the timed region;
+  "cpu_baseline" : the CPU oracle (a port, 1 core) on a bounded sample (smaller N) of the
+                   same generator, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # fp64 matrix peak per GPU
+
+
+def flops(problem, n, n_vec):
+    """Algorithmic flops F(N) of SURVEY.md 8(d)."""
+    n3 = float(n) ** 3
+    if n_vec == n:
+        return 7.0 * n3 if problem == 1 else 14.0 / 3.0 * n3
+    k = float(n_vec)
+    base = 4.0 * n3 / 3.0 + 2.0 * n * n * k
+    return base + (n3 / 3.0 + n3 + n * n * k if problem == 1 else 0.0)
+
+
+def cpu_baseline(problem, sample_n):
+    """The CPU oracle (oracle/ek_oracle.c, scalar C port of the reference's call sequence)
+    timed on one host core on a smaller instance of the same synthetic workload."""
+    import numpy as np  # noqa: F401
+    from oracle import ek_oracle
+    A = ek_oracle.synth_matrix(sample_n, 1)
+    B = ek_oracle.synth_matrix(sample_n, 2) if problem == 1 else None
+    t0 = time.perf_counter()
+    w, Z, info, _ = ek_oracle.solve(A, B)
+    dt = time.perf_counter() - t0
+    assert info == 0
+    return {"value": sample_n / dt, "unit": "eigenpairs/s", "cores": 1, "kind": "port",
+            "seconds": dt,
+            "sample": "oracle/ek_oracle.c ok_solve (unblocked DPOTF2/DSYGS2/DSYTD2/D&C/ORM2L/TRSV "
+                      "restatement), %s N=%d of the same generator, 1 thread"
+                      % ("GEP" if problem == 1 else "SEP", sample_n),
+            "gflops_equiv": flops(problem, sample_n, sample_n) / dt / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--problem", choices=["gep", "sep"], default="gep")
+    ap.add_argument("--cpu-sample-n", type=int, default=1536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-symv-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n, problem = args.n, (1 if args.problem == "gep" else 0)
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    from eigenkernel_amd import solver
+    lib = solver.load_library()
+    rc = lib.ek_hip_init(local_rank)
+    if rc != 0:
+        raise RuntimeError("ek_hip_init(%d) failed: %d" % (local_rank, rc))
+
+    dev = torch.device("cuda", local_rank)
+    # Device-resident operands (torch only owns the memory; the library does all the work).
+    # The solve overwrites A and B (as PDSYTRD / PDPOTRF do), so every timed step gets its own
+    # pre-generated copy of the inputs: 288 GB of HBM holds them easily and the timed region
+    # stays one contiguous run of K solves.
+    K = args.steps
+    dAs = [torch.empty((n, n), dtype=torch.float64, device=dev) for _ in range(K)]
+    dBs = [torch.empty((n, n), dtype=torch.float64, device=dev) for _ in range(K)] if problem == 1 else None
+    dZ = torch.empty((n, n), dtype=torch.float64, device=dev)
+    dw = torch.empty((n,), dtype=torch.float64, device=dev)
+    stage = (ctypes.c_double * 8)()
+    stage_sum = [0.0] * 8
+
+    def regenerate(i):
+        assert lib.ek_hip_synth_matrix_device(n, 1, dAs[i].data_ptr(), n) == 0
+        if problem == 1:
+            assert lib.ek_hip_synth_matrix_device(n, 2, dBs[i].data_ptr(), n) == 0
+
+    def step(i, collect):
+        info = lib.ek_hip_solve_device(problem, n, n, dAs[i].data_ptr(), n,
+                                       dBs[i].data_ptr() if problem == 1 else None, n,
+                                       dw.data_ptr(), dZ.data_ptr(), n, stage, 8)
+        if info != 0:
+            raise RuntimeError("ek_hip_solve_device info=%d" % info)
+        if collect:
+            for q in range(8):
+                stage_sum[q] += stage[q]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        regenerate(0)
+        step(0, False)
+    for i in range(K):
+        regenerate(i)
+    events = not args.no_symv_events
+    if events:
+        lib.ek_hip_profile_symv(1)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i, True)
+    barrier()
+    total = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([total], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        total = float(tt.item())
+
+    symv_s, symv_l, symv_b = ctypes.c_double(0), ctypes.c_longlong(0), ctypes.c_double(0)
+    if events:
+        lib.ek_hip_profile_symv_get(ctypes.byref(symv_s), ctypes.byref(symv_l), ctypes.byref(symv_b))
+        lib.ek_hip_profile_symv(0)
+
+    # parity guard on the timed output: eigenvalues ascending and finite
+    w = dw.cpu().numpy()
+    assert (w[1:] >= w[:-1]).all() and abs(w).max() < 1e6
+
+    if rank == 0:
+        value = world * n * K / total
+        out = {
+            "metric": "eigenpairs/s (full spectrum)", "value": value, "unit": "eigenpairs/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": 1e3 * total / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic dense SPD pair (SURVEY 8(d), seeds 1,2) N=%d %s, "
+                                   "full spectrum, 1 problem per GPU" % (n, "generalized EVP (Cholesky+reduce+SEP)"
+                                                                         if problem == 1 else "standard EVP"),
+                       "n": n, "problem": args.problem, "n_vec": n,
+                       "parallelism": "replicas x%d" % world if world > 1 else "1 GPU"},
+            "tflops_equiv": world * flops(problem, n, n) * K / total / 1e12,
+            "fp64_mfma_peak_tflops": FP64_MFMA_PEAK_TFLOPS,
+            "stage_seconds_per_step": {lib.ek_hip_stage_name(i).decode(): stage_sum[i] / K for i in range(8)},
+        }
+        if events and symv_l.value > 0 and symv_s.value > 0:
+            ach = symv_b.value / symv_s.value / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "symv_traffic.json")
+            if os.path.exists(tpath):   # PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected) if committed
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("n") == n:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "kernel": "symv_kernel (tridiagonalisation panel: y = A22 v, lower triangle read once)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "launches": symv_l.value, "avg_launch_us": 1e6 * symv_s.value / symv_l.value,
+                "algorithmic_bytes_per_launch": symv_b.value / symv_l.value,
+            }
+        else:
+            out["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(problem, args.cpu_sample_n)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

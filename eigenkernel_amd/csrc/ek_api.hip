@@ -389,6 +389,22 @@ int ek_hip_ormtr(int n, int ncols, const double *A_loc, const int desc_A[9], con
   return 0;
 }
 
+int ek_hip_profile_symv(int enable) {
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  EK_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  symv_profile_enable(enable != 0);
+  return 0;
+}
+
+int ek_hip_profile_symv_get(double *seconds, long long *launches, double *algorithmic_bytes) {
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  EK_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  symv_profile_collect(seconds, launches, algorithmic_bytes);
+  return 0;
+}
+
 int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int ldm) {
   if (n < 0) return -1;
   if (ldm < (n > 1 ? n : 1)) return -4;

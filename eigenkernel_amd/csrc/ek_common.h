@@ -85,6 +85,10 @@ size_t sytrd_work_bytes(int n);
 void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e, double *tau,
                  double *V, int ldv, void *work);
 
+// instrumentation: HIP events around every symv launch (bench.py roofline line)
+void symv_profile_enable(bool on);
+void symv_profile_collect(double *seconds, long long *launches, double *bytes);
+
 // ---------------------------------------------------------------- tridiagonal D&C (ek_stedc.hip)
 size_t stedc_work_bytes(int n);
 // d(n), e(n-1) -> eigenvalues ascending in w(n), eigenvectors in Z (n x n, ldz).

@@ -25,6 +25,8 @@
 // column = 4 N^3 / 3 bytes in total; partial sums add ~2/128 of that.
 #include "ek_common.h"
 
+#include <vector>
+
 namespace ek {
 namespace {
 
@@ -345,6 +347,17 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
 
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// Optional instrumentation for bench.py's roofline line: HIP events around every symv launch
+// on the launch stream.  Off by default (events cost host time).
+struct SymvProfile {
+  bool enabled = false;
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  double bytes = 0.0;
+  long long launches = 0;
+  double seconds = 0.0;
+} g_prof;
+
 struct Layout {
   int npad, NRB, nch;
   size_t off_x, off_P, off_y, off_t, off_vav, off_norm, off_dot, off_scal, total;
@@ -409,7 +422,23 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
       sv.dot_r0 = ((j + 1) / 256) * 256;
       sv.ndot = (i > 0) ? ceil_div(npad - sv.dot_r0, 256) : 0;
       sv.nchunks = nchunks_cur;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (g_prof.enabled) {
+        if (g_prof.used + 2 > g_prof.ev.size()) {
+          const size_t old = g_prof.ev.size();
+          g_prof.ev.resize(old + 4096);
+          for (size_t q = old; q < g_prof.ev.size(); ++q) (void)hipEventCreate(&g_prof.ev[q]);
+        }
+        e0 = g_prof.ev[g_prof.used++]; e1 = g_prof.ev[g_prof.used++];
+        (void)hipEventRecord(e0, s);
+      }
       hipLaunchKernelGGL(symv_kernel, dim3(sv.nunits + sv.ndot), dim3(256), 0, s, sv);
+      if (g_prof.enabled) {
+        (void)hipEventRecord(e1, s);
+        const double m = (double)(n - j - 1);
+        g_prof.bytes += 8.0 * m * (m + 1.0) * 0.5;   // lower triangle of the active matrix, once
+        g_prof.launches += 1;
+      }
       // finish w_j, then update column j+1 (unless the panel ends here)
       c.finalize = 1; c.jp = j; c.ip = i; c.S0p = sv.S0; c.Gp = G; c.nchunks_p = nchunks_cur;
       c.ndot_p = sv.ndot; c.nunits_p = sv.nunits;
@@ -433,6 +462,23 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
   // last diagonal entry
   c.finalize = 0; c.update = 1; c.j = n - 1; c.i = 0;
   launch_colupd(n - 1);
+}
+
+void symv_profile_enable(bool on) {
+  g_prof.enabled = on;
+  g_prof.used = 0; g_prof.bytes = 0.0; g_prof.launches = 0; g_prof.seconds = 0.0;
+}
+
+// Call after the stream has been synchronised. Accumulates and resets the event pool.
+void symv_profile_collect(double *seconds, long long *launches, double *bytes) {
+  for (size_t q = 0; q + 1 < g_prof.used; q += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof.ev[q], g_prof.ev[q + 1]) == hipSuccess) g_prof.seconds += ms * 1e-3;
+  }
+  g_prof.used = 0;
+  if (seconds) *seconds = g_prof.seconds;
+  if (launches) *launches = g_prof.launches;
+  if (bytes) *bytes = g_prof.bytes;
 }
 
 }  // namespace ek

@@ -58,13 +58,15 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 
 // M(i,j) = M(j,i) = u(seed, max(i,j), min(i,j)) / sqrt(n) + 2 [i == j]   
 __global__ void synth_kernel(int n, unsigned long long seed, double inv, double *M, int ldm) {
+#pragma clang fp contract(off)   // product and sum round separately, as in the CPU generator
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int j = blockIdx.y; j < n; j += gridDim.y) {
     const unsigned long long hi = i > j ? i : j, lo = i > j ? j : i;
     const unsigned long long r = splitmix64((seed << 40) + hi * (unsigned long long)n + lo);
     const double u = (double)(r >> 11) * (1.0 / 4503599627370496.0) - 1.0;
-    M[(size_t)i + (size_t)j * ldm] = __dadd_rn(__dmul_rn(u, inv), (i == j ? 2.0 : 0.0));  // no FMA: bit-equal to the CPU generator
+    const double prod = u * inv;
+    M[(size_t)i + (size_t)j * ldm] = prod + (i == j ? 2.0 : 0.0);
   }
 }
 

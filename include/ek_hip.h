@@ -116,6 +116,13 @@ int ek_hip_synchronize(void);
  * (seed 1 = A, seed 2 = B), so the large bench configurations need no file or PCIe traffic. */
 int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int ldm);
 
+/* Instrumentation for the roofline line of bench.py: when enabled, every launch of the
+ * HBM-bound symv kernel of the tridiagonalisation is bracketed by HIP events on its own
+ * stream.  _get returns the accumulated device seconds, the number of launches and the
+ * algorithmic bytes (8 B x lower triangle of the active matrix per launch). */
+int ek_hip_profile_symv(int enable);
+int ek_hip_profile_symv_get(double *seconds, long long *launches, double *algorithmic_bytes);
+
 #ifdef __cplusplus
 }
 #endif

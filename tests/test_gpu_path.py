@@ -63,7 +63,7 @@ def test_stedc_matches_oracle(hip, oracle, n, kind):
     assert np.abs(w - w_or).max() <= 4 * n * EPS * scale
     assert np.abs(T @ Z - Z * w).max() <= 32 * n * EPS * scale
     assert np.abs(Z.T @ Z - np.eye(n)).max() <= 32 * n * EPS
-    if kind == "toeplitz":
+    if kind == "toeplitz" and n > 1:
         exact = 2.0 - 2.0 * np.cos(np.arange(1, n + 1) * np.pi / (n + 1))
         assert np.abs(w - exact).max() <= 4 * n * EPS * 4
 
