@@ -1,0 +1,164 @@
+"""CPU suite: host-side mirror of the reference interface (descriptors, grid rules,
+MatrixMarket I/O, result file format, verifier), the C-ABI export check and the N>1 bench
+aggregation under gloo.  No GPU, no compute calls into libek_hip.so."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import eigenkernel_amd as ek
+from eigenkernel_amd import descriptor as dsc
+from eigenkernel_amd import solver
+from eigenkernel_amd.matrix_io import _fortran_e26
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_layout_procs_matches_reference_rule():
+    """processes.f90:56-65; SURVEY.md section 5: 1->1x1, 2->1x2, 4->2x2, 8->2x4."""
+    assert dsc.layout_procs(1) == (1, 1)
+    assert dsc.layout_procs(2) == (1, 2)
+    assert dsc.layout_procs(4) == (2, 2)
+    assert dsc.layout_procs(6) == (2, 3)
+    assert dsc.layout_procs(8) == (2, 4)
+    assert dsc.layout_procs(7) == (1, 7)
+
+
+def test_numroc_partitions_dimension():
+    for n, nb, p in [(30, 15, 2), (400, 64, 2), (16384, 64, 4), (1000, 64, 3), (5, 64, 2)]:
+        assert sum(dsc.numroc(n, nb, i, 0, p) for i in range(p)) == n
+    assert dsc.numroc(30, 15, 0, 0, 2) == 15 and dsc.numroc(30, 15, 1, 0, 2) == 15
+    # 400 = 6 full blocks of 64 + 16: blocks 0,2,4,(6: 16 rows) -> proc 0; blocks 1,3,5 -> proc 1
+    assert dsc.numroc(400, 64, 0, 0, 2) == 208 and dsc.numroc(400, 64, 1, 0, 2) == 192
+
+
+def test_setup_distributed_matrix_block_shrink_rule():
+    """distribute_matrix.f90:114-120: NB shrinks to max(min(rows/P_r, cols/P_c), 1);
+    BNZ30 on 2x2 -> NB = 15."""
+    desc, mat = dsc.setup_distributed_matrix(30, 30, nprow=2, npcol=2, myrow=0, mycol=0)
+    assert desc[dsc.BLOCK_ROW_] == 15 and desc[dsc.BLOCK_COL_] == 15
+    assert mat.shape == (15, 15) and mat.flags.f_contiguous and not mat.any()
+    desc, mat = dsc.setup_distributed_matrix(400, 400)
+    assert list(desc) == [1, 0, 400, 400, 64, 64, 0, 0, 400]
+    desc, _ = dsc.setup_distributed_matrix(400, 400, block_size=25)
+    assert desc[dsc.BLOCK_ROW_] == 25
+    desc, mat = dsc.setup_distributed_matrix(3, 3, nprow=2, npcol=4, myrow=1, mycol=3)
+    assert desc[dsc.BLOCK_ROW_] == 1 and desc[dsc.LOCAL_ROWS_] >= 1
+
+
+def test_matrix_market_roundtrip(tmp_path, golden_dir):
+    A = ek.read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_A.mtx"))
+    assert A.size == 30 and A.num_non_zeros == 303 and A.suffix.shape == (2, 303)
+    D = A.to_dense()
+    assert np.array_equal(D, D.T)
+    p = tmp_path / "a.mtx"
+    ek.write_matrix_file(str(p), D)
+    assert np.array_equal(ek.read_matrix_file(str(p)).to_dense(), D)
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(ValueError):
+        ek.read_matrix_file(str(bad))
+
+
+def test_eigenvalues_file_format_matches_reference_golden(tmp_path, golden_dir):
+    """main.f90:113-118: format (I8, ' ', E26.16e3); the shipped _ev.txt is such a file."""
+    lines = open(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ev.txt")).read().splitlines()
+    vals = [float(l.split()[1]) for l in lines]
+    p = tmp_path / "eigenvalues.dat"
+    ek.write_eigenvalues(str(p), vals)
+    assert p.read_text().splitlines() == lines
+    assert _fortran_e26(0.0).strip() == "0.0000000000000000E+000"
+
+
+def test_verifier_normalisations():
+    """verifier.f90:198-199 (avg = sum/||A||_F/n, max), :310-325 (scale by 1/sqrt(G_jj), zero diag)."""
+    from eigenkernel_amd.verifier import eval_orthogonality, eval_residual_norm, get_ipratios
+    rng = np.random.default_rng(0)
+    n = 12
+    A = rng.normal(size=(n, n)); A = A + A.T
+    w, V = np.linalg.eigh(A)
+    a_norm, ave, mx = eval_residual_norm(A, w, V)
+    assert abs(a_norm - np.linalg.norm(A)) < 1e-12 and mx < 1e-14 and ave <= mx
+    assert eval_orthogonality(V) < 1e-14
+    assert eval_orthogonality(3.0 * V) < 1e-14          # column scaling is normalised away
+    V2 = V.copy(); V2[:, 1] = V2[:, 0]
+    assert eval_orthogonality(V2) > 1.0
+    assert np.allclose(get_ipratios(np.eye(n)), 1.0)
+    assert np.allclose(get_ipratios(np.ones((n, 2)) / np.sqrt(n)), 1.0 / n)
+
+
+def test_header_and_library_export_the_same_symbols():
+    """Every function include/ek_hip.h declares is exported by libek_hip.so and bound by the
+    host mirror (no compute call: works without a GPU)."""
+    hdr = open(os.path.join(ROOT, "include", "ek_hip.h")).read()
+    declared = set(re.findall(r"\b(ek_hip_\w+)\s*\(", hdr))
+    assert declared == set(solver.EXPORTED_SYMBOLS)
+    assert os.path.exists(solver.LIB_PATH), "build with __graft_entry__.build()"
+    lib = ctypes.CDLL(solver.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.ek_hip_stage_name.restype = ctypes.c_char_p
+    names = [lib.ek_hip_stage_name(i).decode() for i in range(8)]
+    # the reference's add_event names (generalized_to_standard.f90:33,44,111; solver_scalapack_all.f90:66,93,104,122)
+    assert names[:7] == ["reduce_generalized:pdpotrf", "reduce_generalized:pdsygst",
+                         "eigen_solver_scalapack_all:pdsytrd", "eigen_solver_scalapack_all:gather1",
+                         "eigen_solver_scalapack_all:pdstedc", "eigen_solver_scalapack_all:pdormtr",
+                         "recovery_generalized"]
+    assert lib.ek_hip_version() >= 1
+
+
+def test_argument_validation_without_gpu():
+    """LAPACK-style info = -k for bad arguments is decided before any device work."""
+    lib = solver.load_library()
+    desc = dsc.descinit(4, 4, 4, 4, 0, 0, 0, 4)
+    a = np.zeros((4, 4), order="F")
+    ip = desc.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    dp = a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert lib.ek_hip_potrf(-1, dp, ip) == -1
+    assert lib.ek_hip_potrf(4, None, ip) == -2
+    bad = desc.copy(); bad[2] = 5
+    assert lib.ek_hip_potrf(4, dp, bad.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == -303
+    assert lib.ek_hip_solve(2, 4, 4, dp, ip, dp, ip, dp, dp, ip, 1, 1, 0, 0, None, 0) == -1
+    assert lib.ek_hip_solve(1, 4, 5, dp, ip, dp, ip, dp, dp, ip, 1, 1, 0, 0, None, 0) == -3
+    assert lib.ek_hip_solve(1, 4, 4, dp, ip, dp, ip, dp, dp, ip, 2, 1, 0, 0, None, 0) == -11
+    assert lib.ek_hip_dgemm(0, 0, 4, 4, -1, 1.0, dp, 4, dp, 4, 0.0, dp, 4, 0) == -5
+
+
+def test_solver_dispatch_rejects_unknown_and_missing_library(tmp_path):
+    with pytest.raises(ValueError):
+        solver.eigen_solver("general_elpa2", np.eye(3), np.eye(3))
+    with pytest.raises(solver.LibraryMissing):
+        solver.load_library(str(tmp_path / "nope.so"))     # product path fails loudly
+
+
+def _bench_agg_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from eigenkernel_amd.parallel import aggregate_throughput, shard_problems
+    mine = shard_problems(5, rank, world)
+    value, t = aggregate_throughput(units_local=len(mine) * 100, seconds_local=1.0 + rank, dist=dist)
+    q.put((rank, mine, value, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_rank_aggregation_gloo():
+    """bench.py --gpus N: independent problems are sharded over ranks with no data-path
+    collective; value = all units / max-over-ranks time (world_size 2, gloo)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_agg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
+    for _, _, value, t in res:
+        assert t == 2.0 and abs(value - 500 / 2.0) < 1e-12

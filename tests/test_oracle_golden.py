@@ -1,0 +1,171 @@
+"""CPU suite: pins the oracle (oracle/ek_oracle.c) to every result file the reference ships
+(SURVEY.md 8(c)), and checks each restated stage against oracle-independent identities and
+an independent LAPACK (scipy) on seeded inputs.  Runs without a GPU."""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+from eigenkernel_amd import read_matrix_file
+from eigenkernel_amd.verifier import eval_orthogonality, eval_residual_norm, get_ipratios
+
+EPS = 2.220446049250313e-16
+
+
+def _golden(golden_dir, name):
+    return np.loadtxt(os.path.join(golden_dir, name))[:, 1]
+
+
+@pytest.mark.parametrize("tri_solver", [0, 1])
+def test_bnz30_generalized_eigenvalues_and_ipr(oracle, golden_dir, tri_solver):
+    """matrix/ELSES_MATRIX_BNZ30_{ev,ipr}.txt: -s general_scalapack on the shipped pair."""
+    A = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_A.mtx")).to_dense()
+    B = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_B.mtx")).to_dense()
+    w, Z, info, L = oracle.solve(A, B, tri_solver=tri_solver)
+    assert info == 0
+    assert np.abs(w - _golden(golden_dir, "ELSES_MATRIX_BNZ30_ev.txt")).max() <= 5e-15
+    ipr = get_ipratios(Z, B)
+    # IPR of near-degenerate pairs (gap 4e-9) is only reproducible to ~1e-8
+    assert np.abs(ipr - _golden(golden_dir, "ELSES_MATRIX_BNZ30_ipr.txt")).max() <= 1e-6
+    a_norm, ave, mx = eval_residual_norm(A, w, Z, B)
+    assert mx <= 1e-14 and eval_orthogonality(Z, B) <= 1e-12
+
+
+@pytest.mark.parametrize("tri_solver", [0, 1])
+def test_vcnt400_standard_eigenvalues(oracle, golden_dir, tri_solver):
+    """matrix/ELSES_MATRIX_VCNT400std_E.txt (12 digits): -s scalapack."""
+    A = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_VCNT400std_A.mtx")).to_dense()
+    w, Z, info, _ = oracle.solve(A, tri_solver=tri_solver)
+    assert info == 0
+    assert np.abs(w - _golden(golden_dir, "ELSES_MATRIX_VCNT400std_E.txt")).max() <= 1e-12
+    assert np.abs(w - sl.eigh(A, eigvals_only=True)).max() <= 400 * EPS
+    _, _, mx = eval_residual_norm(A, w, Z)
+    assert mx <= 1e-14 and eval_orthogonality(Z) <= 1e-12
+
+
+def test_synth_generator_properties(oracle):
+    """symmetric, SPD, spectrum ~[0.84, 3.15]; first entries are pinned."""
+    A = oracle.synth_matrix(256, 1)
+    B = oracle.synth_matrix(256, 2)
+    assert np.array_equal(A, A.T) and np.array_equal(B, B.T)
+    ev = np.linalg.eigvalsh(A)
+    assert 0.5 < ev.min() and ev.max() < 3.5
+    assert not np.array_equal(A, B)
+    # splitmix64 known answer: seed 0 state 0 -> first output of the reference sequence
+    x = (0 + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+    z ^= z >> 31
+    assert z == 0xE220A8397B1DCDAF
+    n = 7
+    M = oracle.synth_matrix(n, 3)
+    for (i, j) in [(0, 0), (3, 1), (6, 6)]:
+        s = ((3 << 40) + i * n + j) & (2 ** 64 - 1)
+        x = (s + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        z ^= z >> 31
+        u = (z >> 11) * 2.0 ** -52 - 1.0
+        assert M[i, j] == u * (1.0 / np.sqrt(n)) + (2.0 if i == j else 0.0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 200])
+def test_stage_identities(oracle, n):
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    L, info = oracle.potrf_lower(B)
+    assert info == 0
+    Lt = np.tril(L)
+    assert np.abs(Lt @ Lt.T - B).max() <= 8 * n * EPS * 4
+    assert np.abs(Lt - np.linalg.cholesky(B)).max() <= 8 * n * EPS * 4
+    C = oracle.sygst_lower(A, L)
+    Cf = np.tril(C) + np.tril(C, -1).T
+    assert np.abs(Lt @ Cf @ Lt.T - A).max() <= 64 * n * EPS * 4
+    Ar, d, e, tau = oracle.sytrd_lower(Cf)
+    T = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    Q = oracle.ormtr_lower(Ar, tau, np.eye(n))
+    assert np.abs(Q @ T @ Q.T - Cf).max() <= 64 * n * EPS * 4
+    assert np.abs(Q.T @ Q - np.eye(n)).max() <= 64 * n * EPS
+    X, info = oracle.trtrs_lt(L, np.eye(n))
+    assert info == 0 and np.abs(Lt.T @ X - np.eye(n)).max() <= 64 * n * EPS
+
+
+def test_potrf_info_and_trtrs_info(oracle):
+    B = oracle.synth_matrix(40, 2)
+    B[17, 17] = -1.0
+    _, info = oracle.potrf_lower(B)
+    assert info == 18            # LAPACK: order of the first non-PD leading minor
+    L = np.tril(oracle.synth_matrix(10, 2))
+    L[4, 4] = 0.0
+    _, info = oracle.trtrs_lt(L, np.ones((10, 1)))
+    assert info == 5
+
+
+def _tridiag(n, kind, seed=0):
+    rng = np.random.default_rng(seed + n)
+    if kind == "random":
+        return rng.uniform(-1, 1, n), rng.uniform(-1, 1, n - 1)
+    if kind == "wilkinson":
+        return np.abs(np.arange(n) - (n - 1) / 2.0), np.ones(n - 1)
+    if kind == "toeplitz":
+        return 2.0 * np.ones(n), -np.ones(n - 1)
+    if kind == "glued":
+        d = np.tile(np.arange(1.0, 11.0), n // 10 + 1)[:n]
+        e = 0.5 * np.ones(n - 1)
+        e[9::10] = 1e-9
+        return d, e
+    if kind == "zero_offdiag":
+        return rng.uniform(-1, 1, n), np.zeros(n - 1)
+    return np.ones(n), np.zeros(n - 1)
+
+
+@pytest.mark.parametrize("kind", ["random", "wilkinson", "toeplitz", "glued", "zero_offdiag", "identity"])
+@pytest.mark.parametrize("n", [2, 26, 51, 130, 300])
+def test_divide_and_conquer_vs_ql_and_lapack(oracle, n, kind):
+    """The D&C restatement (incl. deflation-heavy inputs) against the QL restatement and LAPACK."""
+    d, e = _tridiag(n, kind)
+    w, Z = oracle.stedc(d, e)
+    w2, Z2 = oracle.steqr(d, e)
+    wl = sl.eigh_tridiagonal(d, e, eigvals_only=True) if n > 1 else d
+    T = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    scale = np.abs(T).max()
+    assert np.abs(w - wl).max() <= 4 * n * EPS * scale
+    assert np.abs(w2 - wl).max() <= 4 * n * EPS * scale
+    assert np.abs(T @ Z - Z * w).max() <= 32 * n * EPS * scale
+    assert np.abs(Z.T @ Z - np.eye(n)).max() <= 32 * n * EPS
+
+
+@pytest.mark.parametrize("n,n_vec", [(50, 5), (200, 200), (300, 32)])
+def test_bisection_inverse_iteration(oracle, n, n_vec):
+    """The *_select restatement (PDSYEVX range 'I', solver_scalapack_select.f90:56-60)."""
+    d, e = _tridiag(n, "random")
+    w, Z = oracle.stebz_stein(d, e, n_vec)
+    wl = sl.eigh_tridiagonal(d, e, eigvals_only=True)[:n_vec]
+    T = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    assert np.abs(w - wl).max() <= 8 * n * EPS
+    assert np.abs(T @ Z - Z * w).max() <= 1e-12
+    assert np.abs(Z.T @ Z - np.eye(n_vec)).max() <= 1e-9
+
+
+def test_select_path_matches_full_path(oracle):
+    n, k = 120, 12
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    w_full, _, _, _ = oracle.solve(A, B)
+    w_sel, Z_sel, info, _ = oracle.solve(A, B, n_vec=k, tri_solver=2)
+    assert info == 0
+    assert np.abs(w_sel - w_full[:k]).max() <= 8 * n * EPS * 4
+    assert np.abs(A @ Z_sel - (B @ Z_sel) * w_sel).max() <= 1e-12
+
+
+def test_oracle_vs_scipy_generalized(oracle):
+    """Third opinion (LAPACK dsygvd via scipy), as in SURVEY.md section 4 (noise floor 3e-14)."""
+    for n in (33, 150, 400):
+        A = oracle.synth_matrix(n, 1)
+        B = oracle.synth_matrix(n, 2)
+        w, Z, info, _ = oracle.solve(A, B)
+        assert info == 0
+        assert np.abs(w - sl.eigh(A, B, eigvals_only=True)).max() <= n * EPS * np.abs(w).max() * 4
