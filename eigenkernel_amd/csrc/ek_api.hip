@@ -405,6 +405,41 @@ int ek_hip_profile_symv_get(double *seconds, long long *launches, double *algori
   return 0;
 }
 
+// Tuning hook (not part of the drop-in surface): tridiagonalise a device-generated synthetic
+// matrix of order n held with leading dimension ld, `reps` times; seconds[0] = stage time per
+// repetition.  Honour EK_SYTRD_MAXCOLS to time only the first panels.
+int ek_hip_debug_sytrd(int n, int ld, int reps, double *seconds) {
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  const int npad = pad_ld(n);
+  if (ld < npad) ld = npad;
+  const size_t wb = sytrd_work_bytes(n);
+  void *ws;
+  rc = workspace(al((size_t)ld * npad * 8) + al(wb) + 3 * al((size_t)npad * 8), &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *dA = a.get<double>((size_t)ld * npad);
+  char *work = a.get<char>(wb);
+  double *dd = a.get<double>(npad), *de = a.get<double>(npad), *dt = a.get<double>(npad);
+  hipEvent_t e0, e1;
+  EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
+  double tot = 0.0;
+  for (int r = 0; r < reps; ++r) {
+    EK_HIP_CHECK(hipMemsetAsync(dA, 0, (size_t)ld * npad * 8, s));
+    synth_matrix(s, n, 1, dA, ld);
+    EK_HIP_CHECK(hipEventRecord(e0, s));
+    sytrd_lower(s, n, dA, ld, dd, de, dt, nullptr, 0, work);
+    EK_HIP_CHECK(hipEventRecord(e1, s));
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0.f; EK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    tot += ms * 1e-3;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (seconds) *seconds = tot / (reps > 0 ? reps : 1);
+  return 0;
+}
+
 int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int ldm) {
   if (n < 0) return -1;
   if (ldm < (n > 1 ? n : 1)) return -4;

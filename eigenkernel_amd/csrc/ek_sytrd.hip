@@ -8,8 +8,9 @@
 //   colupd  (HBM-light)  finishes w of the previous column from the partial sums below,
 //                        applies the deferred panel updates to the next column, and
 //                        produces its Householder data (alpha, partial sum of squares);
-//   symv    (HBM-bound)  y = A22 v with the lower triangle read exactly ONCE: a workgroup
-//                        owns a 128-column strip x a run of 128-row blocks; lane l holds
+//   symv    (HBM-bound)  y = A22 v with the lower triangle read exactly ONCE: the 128x128
+//                        tiles are dealt strip-major in equal runs to ~2 workgroups per CU
+//                        (every workgroup streams the same bytes); inside a tile lane l holds
 //                        rows 2l,2l+1 of the block (16-byte coalesced loads down the
 //                        column), accumulates the "row part" A v in registers and the
 //                        "column part" A^T v in 32 per-lane accumulators that are reduced
@@ -25,42 +26,28 @@
 // column = 4 N^3 / 3 bytes in total; partial sums add ~2/128 of that.
 #include "ek_common.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace ek {
 namespace {
 
 constexpr int NBP = 64;      // panel width
-constexpr int CH = 256;      // rows per colupd workgroup
 constexpr int TS = 128;      // symv strip width / row-block height
 
 struct SytrdBufs {
   double *xbuf;      // npad     unscaled current column (0 above the active part)
   double *P;         // npad x 3*NBP  panel image [V | W | V] (so [V|W] and [W|V] are both slices)
   double *ypart;     // NRB x npad   row-part partial sums per strip
-  double *tpart;     // NRB x NRB x 128  column-part partial sums per (strip, segment)
-  double *vavpart;   // NRB*NRB   v^T A v partial sums per unit
-  double *normpart;  // npad/CH + 1
-  double *dotpart;   // (npad/CH + 1) x 2*NBP  panel-dot partial sums
+  double *tpart;     // NRB x NRB x 128  column-part partial sums per (strip, piece)
+  double *vavpart;   // one v^T A v partial sum per symv workgroup
+  double *normpart;  // one partial sum of squares per colupd workgroup
+  double *dotpart;   // (colupd workgroups) x 2*NBP  partial sums of V^T x, W^T x
+  double *dottot;    // 2*NBP  totals V^T v, W^T v of the current column (written by symv)
   double *scal;      // [0] = alpha0 of the current column
 };
 
 struct Refl { double beta, tau, scale; };
-
-// Householder data of the current column from its partial sums; every workgroup of both
-// kernels evaluates this identically (same inputs, same order).
-__device__ __forceinline__ Refl reflector(const double *__restrict__ normpart, int nchunks,
-                                          double alpha0) {
-  double ssq = 0.0;
-  for (int c = 0; c < nchunks; ++c) ssq += normpart[c];
-  Refl r;
-  if (ssq == 0.0) { r.beta = alpha0; r.tau = 0.0; r.scale = 0.0; return r; }
-  const double xnorm = sqrt(ssq);
-  r.beta = -copysign(hypot(alpha0, xnorm), alpha0);
-  r.tau = (r.beta - alpha0) / r.beta;
-  r.scale = 1.0 / (alpha0 - r.beta);
-  return r;
-}
 
 __device__ __forceinline__ double block_sum(double v, double *red /* >= 4 */) {
   // 256 threads = 4 waves; fixed order => deterministic
@@ -72,135 +59,217 @@ __device__ __forceinline__ double block_sum(double v, double *red /* >= 4 */) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Householder data of the current column from its partial sums.  Evaluated cooperatively by
+// every 256-thread workgroup of both kernels in the same order => identical bits everywhere.
+__device__ __forceinline__ Refl reflector(const double *__restrict__ normpart, int nchunks,
+                                          double alpha0, double *red) {
+  double part = 0.0;
+  for (int c = threadIdx.x; c < nchunks; c += 256) part += normpart[c];
+  const double ssq = block_sum(part, red);
+  Refl r;
+  if (ssq == 0.0) { r.beta = alpha0; r.tau = 0.0; r.scale = 0.0; return r; }
+  const double xnorm = sqrt(ssq);
+  r.beta = -copysign(hypot(alpha0, xnorm), alpha0);
+  r.tau = (r.beta - alpha0) / r.beta;
+  r.scale = 1.0 / (alpha0 - r.beta);
+  return r;
+}
+
+// ---- tile bookkeeping shared by symv (producer) and colupd (consumer of its partials) ----
+// The active lower triangle is T strips of 128 columns; strip s (relative to the first active
+// strip) owns the 128x128 tiles rb = s .. T-1.  Tiles are numbered strip-major and dealt to
+// the workgroups in equal contiguous runs of q tiles, so every workgroup streams the same
+// number of bytes; a strip therefore reaches colupd as one partial per workgroup ("piece").
+__device__ __host__ __forceinline__ int tile_start(int s, int T) { return s * T - (s * (s - 1)) / 2; }
+__device__ __forceinline__ int strip_of_tile(int L, int T) {
+  const double b = 2.0 * T + 1.0;
+  int s = (int)((b - sqrt(b * b - 8.0 * (double)L)) * 0.5);
+  if (s < 0) s = 0;
+  if (s > T - 1) s = T - 1;
+  while (s + 1 < T && tile_start(s + 1, T) <= L) ++s;
+  while (s > 0 && tile_start(s, T) > L) --s;
+  return s;
+}
+__device__ __forceinline__ int first_piece(int s, int T, int q) { return tile_start(s, T) / q; }
+__device__ __forceinline__ int num_pieces(int s, int T, int q) {
+  return (tile_start(s + 1, T) - 1) / q - tile_start(s, T) / q + 1;
+}
+
 struct ColupdArgs {
   int n, npad, lda, ldv;
   double *A, *V;          // V: explicit reflector matrix (may be null)
   double *d, *e, *tau;
   SytrdBufs b;
-  int r0;                 // first row handled by workgroup 0 (multiple of CH)
+  int r0;                 // first row handled by workgroup 0 (multiple of CR)
   // finalize part (previous column)
   int finalize;           // 0/1
   int jp, ip;             // global / in-panel index of the column whose w is finished
-  int S0p, Gp, NRB;       // symv launch geometry of that column
-  int nchunks_p;          // chunks that produced normpart for column jp
-  int ndot_p;             // dot blocks of that symv launch
-  int nunits_p;           // units of that symv launch
+  int S0p, NRB;           // symv launch geometry of that column
+  int qp;                 // tiles per symv workgroup
+  int nwg_p;              // symv workgroups (vavpart entries)
+  int nchunks_p;          // colupd workgroups that produced normpart for column jp
   // update part (next column)
   int update;             // 0/1
-  int j, i;               // global / in-panel index of the column to update (i terms)
+  int j;                  // global index of the column to update
+  int i_new;              // finished panel columns once this launch is done (dots needed for them)
 };
 
-__global__ __launch_bounds__(CH) void colupd_kernel(ColupdArgs p) {
-  __shared__ double s_pv[NBP], s_pw[NBP], s_Vj[NBP], s_Wj[NBP];
+constexpr int CR = 64;    // rows per colupd workgroup (x 4 slices = 256 threads)
+
+__global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
+  __shared__ double s_pvw[2 * NBP];          // [0,NBP): V^T v totals, [NBP,2NBP): W^T v totals
+  __shared__ double s_Vj[NBP], s_Wj[NBP];
   __shared__ double s_red[8];
-  const int t = threadIdx.x;
-  const int r = p.r0 + blockIdx.x * CH + t;
+  __shared__ double s_acc[3][4][CR];
+  __shared__ double s_x[CR], s_vn[CR], s_wn[CR];   // new column x, newest panel column (v, w)
+  const int t = threadIdx.x, lane = t & 63, q = t >> 6;
+  const int r = p.r0 + blockIdx.x * CR + lane;
   const int ldp = p.npad;
   double *__restrict__ Pv = p.b.P;                          // V block
   double *__restrict__ Pw = p.b.P + (size_t)NBP * ldp;      // W block
   double *__restrict__ Pv2 = p.b.P + (size_t)2 * NBP * ldp; // V copy
+  const double *s_pv = s_pvw, *s_pw = s_pvw + NBP;
 
-  double v_r = 0.0, w_r = 0.0, accB = 0.0;
-  double wj = 0.0;
-  Refl rf{0.0, 0.0, 0.0};
+  double accB = 0.0;
   if (p.finalize) {
-    const int ip = p.ip, jp = p.jp;
-    rf = reflector(p.b.normpart, p.nchunks_p, p.b.scal[0]);
-    // totals of the panel products
-    if (t < ip) {
-      double a = 0.0;
-      for (int c = 0; c < p.ndot_p; ++c) a += p.b.dotpart[(size_t)c * 2 * NBP + t];
-      s_pv[t] = a;
-    } else if (t >= NBP && t < NBP + ip) {
-      const int k = t - NBP;
-      double a = 0.0;
-      for (int c = 0; c < p.ndot_p; ++c) a += p.b.dotpart[(size_t)c * 2 * NBP + NBP + k];
-      s_pw[k] = a;
-    }
-    // v^T A v
+    const int ip = p.ip, jp = p.jp, j = jp + 1;
+    const int T = p.NRB - p.S0p;
+    const Refl rf = reflector(p.b.normpart, p.nchunks_p, p.b.scal[0], s_red);
+    // totals of the panel products (reduced by the symv launch's reducer workgroup)
+    if (t < 2 * NBP) s_pvw[t] = ((t & (NBP - 1)) < ip) ? p.b.dottot[t] : 0.0;
     double part = 0.0;
-    for (int u = t; u < p.nunits_p; u += CH) part += p.b.vavpart[u];
-    const double vav = block_sum(part, s_red);   // also publishes s_pv / s_pw
+    for (int u = t; u < p.nwg_p; u += 256) part += p.b.vavpart[u];
+    const double vav = block_sum(part, s_red);   // its barriers also publish s_pvw
     double dvw = 0.0;
     for (int k = 0; k < ip; ++k) dvw += s_pv[k] * s_pw[k];
     const double wv = rf.tau * (vav - 2.0 * dvw);
     const double alpha = -0.5 * rf.tau * wv;
     // row j = jp + 1 of the panel (needed by every workgroup for the column update)
-    const int j = jp + 1;
+    double wj;
     {
       const int rbj = j / TS;
       double part2 = 0.0;
       const int nS = rbj - p.S0p + 1;
-      if (t < nS) part2 = p.b.ypart[(size_t)(p.S0p + t) * p.npad + j];
-      const int nseg = (p.NRB - rbj + p.Gp - 1) / p.Gp;
-      if (t >= 128 && t - 128 < nseg)
-        part2 += p.b.tpart[((size_t)rbj * p.NRB + (t - 128)) * TS + (j % TS)];
+      for (int idx = t; idx < nS; idx += 256) part2 += p.b.ypart[(size_t)(p.S0p + idx) * p.npad + j];
+      const int np = num_pieces(rbj - p.S0p, T, p.qp);
+      for (int idx = t; idx < np; idx += 256)
+        part2 += p.b.tpart[((size_t)rbj * p.NRB + idx) * TS + (j % TS)];
       if (t < ip) {
         const double vjk = Pv[(size_t)j + (size_t)t * ldp], wjk = Pw[(size_t)j + (size_t)t * ldp];
         s_Vj[t] = vjk; s_Wj[t] = wjk;
         part2 -= vjk * s_pw[t] + wjk * s_pv[t];
       }
-      const double yj = block_sum(part2, s_red);
-      wj = rf.tau * yj + alpha * 1.0;   // v_j = 1
+      const double yj = block_sum(part2, s_red);   // publishes s_Vj / s_Wj
+      wj = rf.tau * yj + alpha;                    // v_j = 1
     }
+    // per-row sums, 4 slices per row for memory-level parallelism
+    double y = 0.0, accA = 0.0, aB = 0.0;
     if (r >= j && r < p.npad) {
-      // y_r
       const int rb = r / TS;
-      double y = 0.0;
-      for (int S = p.S0p; S <= rb; ++S) y += p.b.ypart[(size_t)S * p.npad + r];
-      const int nseg = (p.NRB - rb + p.Gp - 1) / p.Gp;
-      for (int g = 0; g < nseg; ++g) y += p.b.tpart[((size_t)rb * p.NRB + g) * TS + (r % TS)];
-      double accA = 0.0;
-      for (int k = 0; k < ip; ++k) {
-        const double vrk = Pv[(size_t)r + (size_t)k * ldp], wrk = Pw[(size_t)r + (size_t)k * ldp];
-        accA += vrk * s_pw[k] + wrk * s_pv[k];
-        accB += vrk * s_Wj[k] + wrk * s_Vj[k];
+      {
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+        int S = p.S0p + q;
+        for (; S + 12 <= rb; S += 16) {
+          y0 += p.b.ypart[(size_t)S * p.npad + r];
+          y1 += p.b.ypart[(size_t)(S + 4) * p.npad + r];
+          y2 += p.b.ypart[(size_t)(S + 8) * p.npad + r];
+          y3 += p.b.ypart[(size_t)(S + 12) * p.npad + r];
+        }
+        for (; S <= rb; S += 4) y0 += p.b.ypart[(size_t)S * p.npad + r];
+        const int np = num_pieces(rb - p.S0p, T, p.qp);
+        for (int pc = q; pc < np; pc += 4) y1 += p.b.tpart[((size_t)rb * p.NRB + pc) * TS + (r % TS)];
+        y = (y0 + y1) + (y2 + y3);
       }
-      v_r = (r == j) ? 1.0 : p.b.xbuf[r] * rf.scale;
-      if (r >= p.n) v_r = 0.0;
-      w_r = (r == j) ? wj : rf.tau * (y - accA) + alpha * v_r;
-      if (r >= p.n) w_r = 0.0;
-      Pv[(size_t)r + (size_t)ip * ldp] = v_r;
-      Pv2[(size_t)r + (size_t)ip * ldp] = v_r;
-      Pw[(size_t)r + (size_t)ip * ldp] = w_r;
-      if (r < p.n) {
-        p.A[(size_t)r + (size_t)jp * p.lda] = (r == j) ? rf.beta : v_r;
-        if (p.V) p.V[(size_t)r + (size_t)jp * p.ldv] = v_r;
+      {
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        int k = q;
+        for (; k + 4 < ip; k += 8) {
+          const double v0 = Pv[(size_t)r + (size_t)k * ldp], w0 = Pw[(size_t)r + (size_t)k * ldp];
+          const double v1 = Pv[(size_t)r + (size_t)(k + 4) * ldp], w1 = Pw[(size_t)r + (size_t)(k + 4) * ldp];
+          a0 += v0 * s_pw[k] + w0 * s_pv[k];         b0 += v0 * s_Wj[k] + w0 * s_Vj[k];
+          a1 += v1 * s_pw[k + 4] + w1 * s_pv[k + 4]; b1 += v1 * s_Wj[k + 4] + w1 * s_Vj[k + 4];
+        }
+        for (; k < ip; k += 4) {
+          const double v0 = Pv[(size_t)r + (size_t)k * ldp], w0 = Pw[(size_t)r + (size_t)k * ldp];
+          a0 += v0 * s_pw[k] + w0 * s_pv[k]; b0 += v0 * s_Wj[k] + w0 * s_Vj[k];
+        }
+        accA = a0 + a1; aB = b0 + b1;
       }
-      if (r == j) { p.e[jp] = rf.beta; p.tau[jp] = rf.tau; }
-      accB += v_r * wj + w_r * 1.0;   // k = ip term: V(j,ip) = 1, W(j,ip) = wj
-    } else if (r < j && r < p.npad && r >= p.r0) {
-      Pv[(size_t)r + (size_t)ip * ldp] = 0.0;
-      Pv2[(size_t)r + (size_t)ip * ldp] = 0.0;
-      Pw[(size_t)r + (size_t)ip * ldp] = 0.0;
+    }
+    s_acc[0][q][lane] = y; s_acc[1][q][lane] = accA; s_acc[2][q][lane] = aB;
+    __syncthreads();
+    if (q == 0) {
+      if (r >= j && r < p.npad) {
+        y = (s_acc[0][0][lane] + s_acc[0][1][lane]) + (s_acc[0][2][lane] + s_acc[0][3][lane]);
+        accA = (s_acc[1][0][lane] + s_acc[1][1][lane]) + (s_acc[1][2][lane] + s_acc[1][3][lane]);
+        accB = (s_acc[2][0][lane] + s_acc[2][1][lane]) + (s_acc[2][2][lane] + s_acc[2][3][lane]);
+        double v_r = (r == j) ? 1.0 : p.b.xbuf[r] * rf.scale;
+        if (r >= p.n) v_r = 0.0;
+        double w_r = (r == j) ? wj : rf.tau * (y - accA) + alpha * v_r;
+        if (r >= p.n) w_r = 0.0;
+        Pv[(size_t)r + (size_t)ip * ldp] = v_r;
+        Pv2[(size_t)r + (size_t)ip * ldp] = v_r;
+        Pw[(size_t)r + (size_t)ip * ldp] = w_r;
+        if (r < p.n) {
+          p.A[(size_t)r + (size_t)jp * p.lda] = (r == j) ? rf.beta : v_r;
+          if (p.V) p.V[(size_t)r + (size_t)jp * p.ldv] = v_r;
+        }
+        if (r == j) { p.e[jp] = rf.beta; p.tau[jp] = rf.tau; }
+        accB += v_r * wj + w_r;   // k = ip term: V(j,ip) = 1, W(j,ip) = wj
+        s_vn[lane] = v_r; s_wn[lane] = w_r;
+      } else if (r < j && r < p.npad) {
+        Pv[(size_t)r + (size_t)ip * ldp] = 0.0;
+        Pv2[(size_t)r + (size_t)ip * ldp] = 0.0;
+        Pw[(size_t)r + (size_t)ip * ldp] = 0.0;
+      }
     }
   }
   if (!p.update) return;
 
   const int j = p.j;
-  if (!p.finalize && p.i > 0) {   // not used by the driver (kept for completeness)
-    if (t < p.i) {
-      s_Vj[t] = Pv[(size_t)j + (size_t)t * ldp];
-      s_Wj[t] = Pw[(size_t)j + (size_t)t * ldp];
-    }
-    __syncthreads();
-    if (r >= j && r < p.npad)
-      for (int k = 0; k < p.i; ++k)
-        accB += Pv[(size_t)r + (size_t)k * ldp] * s_Wj[k] + Pw[(size_t)r + (size_t)k * ldp] * s_Vj[k];
-  }
-  double sq = 0.0;
-  if (r >= j && r < p.n) {
+  double sq = 0.0, xr = 0.0;
+  if (q == 0 && r >= j && r < p.n) {
     const double a = p.A[(size_t)r + (size_t)j * p.lda] - accB;
     p.A[(size_t)r + (size_t)j * p.lda] = a;
     if (r == j) { p.d[j] = a; p.b.xbuf[r] = 0.0; }
     else {
       p.b.xbuf[r] = a;
+      xr = a;
       if (r == j + 1) p.b.scal[0] = a;
       else sq = a * a;
     }
   }
-  const double tot = block_sum(sq, s_red);
+  if (q == 0) {
+    s_x[lane] = xr;
+    if (!(p.finalize && r >= j && r < p.npad)) { s_vn[lane] = 0.0; s_wn[lane] = 0.0; }
+  }
+  const double tot = block_sum(sq, s_red);   // its barriers also publish s_x / s_vn / s_wn
   if (t == 0) p.b.normpart[blockIdx.x] = tot;
+  // partial panel products V^T x and W^T x over this workgroup's 64 rows: thread <-> panel
+  // column, no cross-lane reduction; the newest column comes from LDS (not yet visible in P)
+  if (t < 2 * NBP) {
+    const int k = t & (NBP - 1), inew = p.i_new;
+    double acc = 0.0;
+    if (k < inew) {
+      const int rbase = p.r0 + blockIdx.x * CR;
+      if (p.finalize && k == p.ip) {
+        const double *src = (t < NBP) ? s_vn : s_wn;
+        for (int l = 0; l < CR; ++l) acc += src[l] * s_x[l];
+      } else {
+        const double *col = ((t < NBP) ? Pv : Pw) + (size_t)k * ldp + rbase;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const int lim = (p.npad - rbase < CR) ? p.npad - rbase : CR;
+        int l = 0;
+        for (; l + 3 < lim; l += 4) {
+          a0 += col[l] * s_x[l]; a1 += col[l + 1] * s_x[l + 1];
+          a2 += col[l + 2] * s_x[l + 2]; a3 += col[l + 3] * s_x[l + 3];
+        }
+        for (; l < lim; ++l) a0 += col[l] * s_x[l];
+        acc = (a0 + a1) + (a2 + a3);
+      }
+    }
+    p.b.dotpart[(size_t)blockIdx.x * 2 * NBP + t] = acc;
+  }
 }
 
 // ------------------------------------------------------------------------------ symv
@@ -210,139 +279,190 @@ struct SymvArgs {
   SytrdBufs b;
   int j;            // column whose reflector is applied; active rows/cols > j
   int i;            // in-panel index (number of finished panel columns)
-  int S0, G, NRB;   // first active strip, row blocks per unit, total row blocks
-  int nseg_max;     // grid: nseg_max x (NRB - S0) units, then ndot dot blocks
-  int nunits, ndot, dot_r0;
-  int nchunks;      // chunks that produced normpart
+  int S0, NRB;      // first active strip, total row blocks
+  int q, nwg;       // tiles per workgroup, symv workgroups
+  int ntiles;
+  int ndot;         // 1 if a reducer workgroup (blockIdx 0) totals the panel products, else 0
+  int nchunks;      // colupd workgroups that produced normpart / dotpart
 };
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// 8 columns x (2 rows per lane) of a tile: the unit of the software pipeline (a quarter of a
+// wave's 32-column share of a tile; two such buffers are alive at a time)
+constexpr int QC = 8;
+__device__ __forceinline__ void part_load(d2_t (&a)[QC], const double *__restrict__ Acol, int lda) {
+#pragma unroll
+  for (int cc = 0; cc < QC; ++cc)
+    a[cc] = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(Acol + (size_t)cc * lda));
+}
+
 template <bool DIAG>
-__device__ __forceinline__ void symv_block(const double *__restrict__ Acol, int lda, int rloc0,
-                                           int cloc0, const double *__restrict__ svc, double vr0,
-                                           double vr1, double &y0, double &y1, double (&tc)[32]) {
-  // Acol points at A(row0 + 2*lane, col0): rows rloc0, rloc0+1 (indices inside the 128x128
-  // diagonal tile, only meaningful when DIAG), columns cloc0 .. cloc0+31.
+__device__ __forceinline__ void part_fma(const d2_t (&a)[QC], int h, int rloc0, int cloc0,
+                                         const double *__restrict__ svc, double vr0, double vr1,
+                                         double &y0, double &y1, double (&tc)[32]) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    double2 a[16];
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc)
-      a[cc] = *reinterpret_cast<const double2 *>(Acol + (size_t)(h * 16 + cc) * lda);
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      const int c = h * 16 + cc;
-      double ax = a[cc].x, ay = a[cc].y;
-      if (DIAG) {
-        const int cl = cloc0 + c;
-        // row part uses r >= c, column part r > c
-        const double rx = (rloc0 >= cl) ? ax : 0.0, ry = (rloc0 + 1 >= cl) ? ay : 0.0;
-        const double cx = (rloc0 > cl) ? ax : 0.0, cy = (rloc0 + 1 > cl) ? ay : 0.0;
-        const double vc = svc[c];
-        y0 += rx * vc; y1 += ry * vc;
-        tc[c] += cx * vr0 + cy * vr1;
-      } else {
-        const double vc = svc[c];
-        y0 += ax * vc; y1 += ay * vc;
-        tc[c] += ax * vr0 + ay * vr1;
-      }
+  for (int cc = 0; cc < QC; ++cc) {
+    const int c = h * QC + cc;
+    const double ax = a[cc].x, ay = a[cc].y;
+    const double vc = svc[c];
+    if (DIAG) {
+      const int cl = cloc0 + c;   // row part uses r >= c, column part r > c
+      const double rx = (rloc0 >= cl) ? ax : 0.0, ry = (rloc0 + 1 >= cl) ? ay : 0.0;
+      const double cx = (rloc0 > cl) ? ax : 0.0, cy = (rloc0 + 1 > cl) ? ay : 0.0;
+      y0 += rx * vc; y1 += ry * vc;
+      tc[c] += cx * vr0 + cy * vr1;
+    } else {
+      y0 += ax * vc; y1 += ay * vc;
+      tc[c] += ax * vr0 + ay * vr1;
     }
   }
 }
 
 __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
-  __shared__ double s_vc[TS];          // v on the strip's columns
-  __shared__ double s_y[2][4][TS];     // per-wave row-part partials, double buffered
+  __shared__ double s_vc[TS];            // v on the strip's columns
+  __shared__ double s_y[2][4][TS];       // per-wave row-part partials, double buffered
   __shared__ double s_red[8];
-  __shared__ double s_dot[4][2 * NBP];
+  __shared__ double s_dot[2][2 * NBP];
+  __shared__ double s_t[4][16 * 65];     // per-wave transpose buffer for the column-part flush
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const Refl rf = reflector(p.b.normpart, p.nchunks, p.b.scal[0]);
   const int j1 = p.j + 1;
   const double *__restrict__ xbuf = p.b.xbuf;
 
-  if ((int)blockIdx.x >= p.nunits) {
-    // ---- panel products: partial V^T v and W^T v over 256 rows
-    const int blk = blockIdx.x - p.nunits;
-    const int r = p.dot_r0 + blk * 256 + t;
-    double v = 0.0;
-    if (r < p.n && r >= j1) v = (r == j1) ? 1.0 : xbuf[r] * rf.scale;
-    const double *Pv = p.b.P, *Pw = p.b.P + (size_t)NBP * p.npad;
-    for (int k = 0; k < p.i; ++k) {
-      double a = 0.0, b = 0.0;
-      if (r < p.npad) { a = Pv[(size_t)r + (size_t)k * p.npad] * v; b = Pw[(size_t)r + (size_t)k * p.npad] * v; }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
-      if (lane == 0) { s_dot[wave][k] = a; s_dot[wave][NBP + k] = b; }
+  if ((int)blockIdx.x < p.ndot) {
+    // ---- reducer: V^T v = scale * (V^T x - x_{j+1} V(j+1,:)) + V(j+1,:), same for W
+    const Refl rf = reflector(p.b.normpart, p.nchunks, p.b.scal[0], s_red);
+    double a0 = 0.0, a1 = 0.0;
+    const int k2 = t & (2 * NBP - 1), half = t >> 7;
+    int c = half;
+    for (; c + 2 < p.nchunks; c += 4) {
+      a0 += p.b.dotpart[(size_t)c * 2 * NBP + k2];
+      a1 += p.b.dotpart[(size_t)(c + 2) * 2 * NBP + k2];
     }
+    if (c < p.nchunks) a0 += p.b.dotpart[(size_t)c * 2 * NBP + k2];
+    s_dot[half][k2] = a0 + a1;
     __syncthreads();
     if (t < 2 * NBP) {
       const int k = t & (NBP - 1);
-      double a = 0.0;
-      if (k < p.i) a = (s_dot[0][t] + s_dot[1][t]) + (s_dot[2][t] + s_dot[3][t]);
-      p.b.dotpart[(size_t)blk * 2 * NBP + t] = a;
+      double res = 0.0;
+      if (k < p.i) {
+        const double tot = s_dot[0][t] + s_dot[1][t];
+        const double *Pm = p.b.P + (size_t)(t < NBP ? 0 : NBP) * p.npad;
+        const double rowj1 = Pm[(size_t)j1 + (size_t)k * p.npad];
+        res = rf.scale * (tot - rowj1 * p.b.scal[0]) + rowj1;
+      }
+      p.b.dottot[t] = res;
     }
     return;
   }
 
-  // ---- symv unit (strip S, segment g)
-  const int g = blockIdx.x % p.nseg_max, S = p.S0 + blockIdx.x / p.nseg_max;
-  const int rb0 = S + g * p.G;
-  int rb1 = rb0 + p.G; if (rb1 > p.NRB) rb1 = p.NRB;
+  // ---- symv workgroup: a run of q tiles in strip-major order, software-pipelined by halves
+  const int w = blockIdx.x - p.ndot;
+  const int T = p.NRB - p.S0;
+  const int L0 = w * p.q;
+  int L1 = L0 + p.q; if (L1 > p.ntiles) L1 = p.ntiles;
   double vav = 0.0;
-  if (rb0 < p.NRB) {
-    if (t < TS) {
-      const int c = S * TS + t;
-      double v = 0.0;
-      if (c >= j1 && c < p.n) v = (c == j1) ? 1.0 : xbuf[c] * rf.scale;
-      s_vc[t] = v;
-    }
-    __syncthreads();
-    double tc[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) tc[c] = 0.0;
-    const int col0 = S * TS + wave * 32;
-    const double *svc = s_vc + wave * 32;
-    int buf = 0;
-    for (int rb = rb0; rb < rb1; ++rb) {
-      const int row = rb * TS + 2 * lane;
-      // v on this lane's two rows
-      const double2 x = *reinterpret_cast<const double2 *>(xbuf + row);
-      double vr0 = 0.0, vr1 = 0.0;
-      if (row >= j1 && row < p.n) vr0 = (row == j1) ? 1.0 : x.x * rf.scale;
-      if (row + 1 >= j1 && row + 1 < p.n) vr1 = (row + 1 == j1) ? 1.0 : x.y * rf.scale;
-      const double *Acol = p.A + (size_t)row + (size_t)col0 * p.lda;
-      double y0 = 0.0, y1 = 0.0;
-      if (rb == S) symv_block<true>(Acol, p.lda, 2 * lane, wave * 32, svc, vr0, vr1, y0, y1, tc);
-      else symv_block<false>(Acol, p.lda, 0, 0, svc, vr0, vr1, y0, y1, tc);
-      *reinterpret_cast<double2 *>(&s_y[buf][wave][2 * lane]) = make_double2(y0, y1);
-      __syncthreads();
+  if (L0 >= L1) {   // (cannot happen with nwg = ceil(ntiles / q); kept for safety)
+    const Refl rf0 = reflector(p.b.normpart, p.nchunks, p.b.scal[0], s_red);
+    (void)rf0;
+    const double tot0 = block_sum(0.0, s_red);
+    if (t == 0) p.b.vavpart[w] = tot0;
+    return;
+  }
+  int s = strip_of_tile(L0, T);
+  int rbrel = s + (L0 - tile_start(s, T));
+  const size_t lda = (size_t)p.lda;
+  auto tile_ptr = [&](int ss, int rr) {
+    return p.A + (size_t)((p.S0 + rr) * TS + 2 * lane) + (size_t)((p.S0 + ss) * TS + wave * 32) * lda;
+  };
+  d2_t bufA[QC], bufB[QC];
+  const double *cur = tile_ptr(s, rbrel);
+  part_load(bufA, cur, p.lda);                       // in flight while the prologue runs
+  const Refl rf = reflector(p.b.normpart, p.nchunks, p.b.scal[0], s_red);
+  double tc[32];
+  int buf = 0;
+  bool new_strip = true;
+  const double *svc = s_vc + wave * 32;
+  for (int L = L0; L < L1; ++L) {
+    const int S = p.S0 + s, rb = p.S0 + rbrel;
+    part_load(bufB, cur + QC * lda, p.lda);
+    if (new_strip) {
       if (t < TS) {
-        const double ys = (s_y[buf][0][t] + s_y[buf][1][t]) + (s_y[buf][2][t] + s_y[buf][3][t]);
-        const int rr = rb * TS + t;
-        p.b.ypart[(size_t)S * p.npad + rr] = ys;
-        double vr = 0.0;
-        if (rr >= j1 && rr < p.n) vr = (rr == j1) ? 1.0 : xbuf[rr] * rf.scale;
-        vav += vr * ys;
+        const int c = S * TS + t;
+        double v = 0.0;
+        if (c >= j1 && c < p.n) v = (c == j1) ? 1.0 : xbuf[c] * rf.scale;
+        s_vc[t] = v;
       }
-      buf ^= 1;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) tc[c] = 0.0;
+      __syncthreads();
+      new_strip = false;
     }
-    // column part: reduce the 32 accumulators across the wave, once per unit
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      double v = tc[c];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-      tc[c] = v;
+    const int row = rb * TS + 2 * lane;
+    const double2 x = *reinterpret_cast<const double2 *>(xbuf + row);
+    double vr0 = 0.0, vr1 = 0.0;
+    if (row >= j1 && row < p.n) vr0 = (row == j1) ? 1.0 : x.x * rf.scale;
+    if (row + 1 >= j1 && row + 1 < p.n) vr1 = (row + 1 == j1) ? 1.0 : x.y * rf.scale;
+    double y0 = 0.0, y1 = 0.0;
+    const bool diag = (rb == S);
+    if (diag) part_fma<true>(bufA, 0, 2 * lane, wave * 32, svc, vr0, vr1, y0, y1, tc);
+    else part_fma<false>(bufA, 0, 0, 0, svc, vr0, vr1, y0, y1, tc);
+    part_load(bufA, cur + 2 * QC * lda, p.lda);
+    if (diag) part_fma<true>(bufB, 1, 2 * lane, wave * 32, svc, vr0, vr1, y0, y1, tc);
+    else part_fma<false>(bufB, 1, 0, 0, svc, vr0, vr1, y0, y1, tc);
+    part_load(bufB, cur + 3 * QC * lda, p.lda);
+    if (diag) part_fma<true>(bufA, 2, 2 * lane, wave * 32, svc, vr0, vr1, y0, y1, tc);
+    else part_fma<false>(bufA, 2, 0, 0, svc, vr0, vr1, y0, y1, tc);
+    // next tile (possibly in the next strip): issue its first part before finishing this one
+    int s2 = s, rb2 = rbrel + 1;
+    if (rb2 == T) { ++s2; rb2 = s2; }
+    const bool strip_ends = (rb2 == s2 && s2 != s) || (L + 1 == L1);
+    if (L + 1 < L1) { cur = tile_ptr(s2, rb2); part_load(bufA, cur, p.lda); }
+    if (diag) part_fma<true>(bufB, 3, 2 * lane, wave * 32, svc, vr0, vr1, y0, y1, tc);
+    else part_fma<false>(bufB, 3, 0, 0, svc, vr0, vr1, y0, y1, tc);
+    *reinterpret_cast<double2 *>(&s_y[buf][wave][2 * lane]) = make_double2(y0, y1);
+    __syncthreads();
+    if (t < TS) {
+      const double ys = (s_y[buf][0][t] + s_y[buf][1][t]) + (s_y[buf][2][t] + s_y[buf][3][t]);
+      const int rr = rb * TS + t;
+      p.b.ypart[(size_t)S * p.npad + rr] = ys;
+      double vr = 0.0;
+      if (rr >= j1 && rr < p.n) vr = (rr == j1) ? 1.0 : xbuf[rr] * rf.scale;
+      vav += vr * ys;
     }
-    if (lane == 0) {
+    buf ^= 1;
+    if (strip_ends) {
+      // flush the strip's column part: transpose through LDS (16 columns per round), then
+      // lanes 0..15 each add up one column's 64 lane-partials in a fixed order
+      const int piece = w - first_piece(s, T, p.q);
+      double *tp = p.b.tpart + ((size_t)S * p.NRB + piece) * TS + wave * 32;
+      double *st = s_t[wave];
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        p.b.tpart[((size_t)S * p.NRB + g) * TS + wave * 32 + c] = tc[c];
-        vav += svc[c] * tc[c];
+      for (int round = 0; round < 2; ++round) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) st[c * 65 + lane] = tc[round * 16 + c];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
+        if (lane < 16) {
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+          for (int l = 0; l < 64; l += 4) {
+            a0 += st[lane * 65 + l]; a1 += st[lane * 65 + l + 1];
+            a2 += st[lane * 65 + l + 2]; a3 += st[lane * 65 + l + 3];
+          }
+          const double tot = (a0 + a1) + (a2 + a3);
+          tp[round * 16 + lane] = tot;
+          vav += svc[round * 16 + lane] * tot;
+        }
+        __builtin_amdgcn_wave_barrier();
       }
+      new_strip = true;
+      __syncthreads();   // s_vc is about to be rewritten
     }
+    s = s2; rbrel = rb2;
   }
   const double tot = block_sum(vav, s_red);
-  if (t == 0) p.b.vavpart[blockIdx.x] = tot;
+  if (t == 0) p.b.vavpart[w] = tot;
 }
 
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -358,19 +478,33 @@ struct SymvProfile {
   double seconds = 0.0;
 } g_prof;
 
+// bring-up / tuning knobs (environment), read once
+struct Knobs {
+  int max_cols = -1;   // EK_SYTRD_MAXCOLS: stop after this many columns (micro-benchmarks only)
+  int G = 0;           // EK_SYMV_G: minimum tiles per symv workgroup (0 = none)
+  int wgs = 0;         // EK_SYMV_WGS: symv workgroups to aim for (0 = 512)
+  Knobs() {
+    if (const char *e = getenv("EK_SYMV_WGS")) wgs = atoi(e);
+    if (const char *e = getenv("EK_SYTRD_MAXCOLS")) max_cols = atoi(e);
+    if (const char *e = getenv("EK_SYMV_G")) G = atoi(e);
+  }
+};
+const Knobs &knobs() { static Knobs k; return k; }
+
 struct Layout {
   int npad, NRB, nch;
-  size_t off_x, off_P, off_y, off_t, off_vav, off_norm, off_dot, off_scal, total;
+  size_t off_x, off_P, off_y, off_t, off_vav, off_norm, off_dot, off_dtot, off_scal, total;
   explicit Layout(int n) {
-    npad = round_up(n > 0 ? n : 1, TS); NRB = npad / TS; nch = npad / CH + 2;
+    npad = round_up(n > 0 ? n : 1, TS); NRB = npad / TS; nch = npad / CR + 2;
     size_t o = 0;
     off_x = o; o += al256((size_t)npad * 8);
     off_P = o; o += al256((size_t)npad * 3 * NBP * 8);
     off_y = o; o += al256((size_t)NRB * npad * 8);
     off_t = o; o += al256((size_t)NRB * NRB * TS * 8);
-    off_vav = o; o += al256((size_t)NRB * NRB * 8 + 64);
+    off_vav = o; o += al256((size_t)(NRB * NRB + 4096) * 8);
     off_norm = o; o += al256((size_t)nch * 8);
     off_dot = o; o += al256((size_t)nch * 2 * NBP * 8);
+    off_dtot = o; o += al256((size_t)2 * NBP * 8);
     off_scal = o; o += 256;
     total = o;
   }
@@ -389,7 +523,8 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
   b.xbuf = (double *)(w + L.off_x); b.P = (double *)(w + L.off_P);
   b.ypart = (double *)(w + L.off_y); b.tpart = (double *)(w + L.off_t);
   b.vavpart = (double *)(w + L.off_vav); b.normpart = (double *)(w + L.off_norm);
-  b.dotpart = (double *)(w + L.off_dot); b.scal = (double *)(w + L.off_scal);
+  b.dotpart = (double *)(w + L.off_dot); b.dottot = (double *)(w + L.off_dtot);
+  b.scal = (double *)(w + L.off_scal);
   (void)hipMemsetAsync(work, 0, L.total, s);
   const int npad = L.npad, NRB = L.NRB;
 
@@ -400,27 +535,30 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
   sv.n = n; sv.npad = npad; sv.lda = lda; sv.A = A; sv.b = b; sv.NRB = NRB;
 
   auto launch_colupd = [&](int row_from) {
-    c.r0 = (row_from / CH) * CH;
-    const int nblk = ceil_div(npad - c.r0, CH);
-    hipLaunchKernelGGL(colupd_kernel, dim3(nblk), dim3(CH), 0, s, c);
+    c.r0 = (row_from / CR) * CR;
+    const int nblk = ceil_div(npad - c.r0, CR);
+    hipLaunchKernelGGL(colupd_kernel, dim3(nblk), dim3(256), 0, s, c);
     return nblk;
   };
+  const int wg_target = knobs().wgs > 0 ? knobs().wgs : 512;   // 2 resident workgroups per CU
 
   int nchunks_cur = 0;
   for (int j0 = 0; j0 < n - 1; j0 += NBP) {
+    if (knobs().max_cols >= 0 && j0 >= knobs().max_cols) break;
     const int pw = (n - 1 - j0 < NBP) ? n - 1 - j0 : NBP;   // reflector columns j0 .. j0+pw-1
     // first column of the panel: nothing deferred yet
-    c.finalize = 0; c.update = 1; c.j = j0; c.i = 0;
+    c.finalize = 0; c.update = 1; c.j = j0; c.i_new = 0;
     nchunks_cur = launch_colupd(j0);
     for (int i = 0; i < pw; ++i) {
       const int j = j0 + i;
       // y = A22 v and the panel products
       sv.j = j; sv.i = i; sv.S0 = (j + 1) / TS;
       const int T = NRB - sv.S0;
-      int G = (T * T) / 1024; if (G < 1) G = 1; if (G > 8) G = 8;
-      sv.G = G; sv.nseg_max = ceil_div(T, G); sv.nunits = sv.nseg_max * T;
-      sv.dot_r0 = ((j + 1) / 256) * 256;
-      sv.ndot = (i > 0) ? ceil_div(npad - sv.dot_r0, 256) : 0;
+      sv.ntiles = T * (T + 1) / 2;
+      sv.q = ceil_div(sv.ntiles, wg_target);
+      if (knobs().G > 0 && sv.q < knobs().G) sv.q = knobs().G;
+      sv.nwg = ceil_div(sv.ntiles, sv.q);
+      sv.ndot = (i > 0) ? 1 : 0;
       sv.nchunks = nchunks_cur;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (g_prof.enabled) {
@@ -432,7 +570,7 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
         e0 = g_prof.ev[g_prof.used++]; e1 = g_prof.ev[g_prof.used++];
         (void)hipEventRecord(e0, s);
       }
-      hipLaunchKernelGGL(symv_kernel, dim3(sv.nunits + sv.ndot), dim3(256), 0, s, sv);
+      hipLaunchKernelGGL(symv_kernel, dim3(sv.nwg + sv.ndot), dim3(256), 0, s, sv);
       if (g_prof.enabled) {
         (void)hipEventRecord(e1, s);
         const double m = (double)(n - j - 1);
@@ -440,9 +578,9 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
         g_prof.launches += 1;
       }
       // finish w_j, then update column j+1 (unless the panel ends here)
-      c.finalize = 1; c.jp = j; c.ip = i; c.S0p = sv.S0; c.Gp = G; c.nchunks_p = nchunks_cur;
-      c.ndot_p = sv.ndot; c.nunits_p = sv.nunits;
-      c.update = (i + 1 < pw) ? 1 : 0; c.j = j + 1; c.i = i + 1;
+      c.finalize = 1; c.jp = j; c.ip = i; c.S0p = sv.S0; c.qp = sv.q; c.nwg_p = sv.nwg;
+      c.nchunks_p = nchunks_cur;
+      c.update = (i + 1 < pw) ? 1 : 0; c.j = j + 1; c.i_new = i + 1;
       const int nb = launch_colupd(j + 1);
       if (c.update) nchunks_cur = nb;
     }
@@ -460,7 +598,7 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
     }
   }
   // last diagonal entry
-  c.finalize = 0; c.update = 1; c.j = n - 1; c.i = 0;
+  c.finalize = 0; c.update = 1; c.j = n - 1; c.i_new = 0;
   launch_colupd(n - 1);
 }
 

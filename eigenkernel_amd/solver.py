@@ -74,6 +74,7 @@ def load_library(path=None):
         "ek_hip_synchronize": (c_int, []),
         "ek_hip_synth_matrix_device": (c_int, [c_int, c_ull, vp, c_int]),
         "ek_hip_profile_symv": (c_int, [c_int]),
+        "ek_hip_debug_sytrd": (c_int, [c_int, c_int, c_int, _dp]),
         "ek_hip_profile_symv_get": (c_int, [_dp, ctypes.POINTER(ctypes.c_longlong), _dp]),
     }
     for name, (res, args) in sigs.items():
@@ -95,7 +96,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_solve_device", "ek_hip_potrf", "ek_hip_sygst", "ek_hip_sytrd", "ek_hip_stedc",
     "ek_hip_ormtr", "ek_hip_trtrs", "ek_hip_dgemm", "ek_hip_malloc", "ek_hip_free",
     "ek_hip_memcpy_h2d", "ek_hip_memcpy_d2h", "ek_hip_synchronize", "ek_hip_synth_matrix_device",
-    "ek_hip_profile_symv", "ek_hip_profile_symv_get",
+    "ek_hip_profile_symv", "ek_hip_profile_symv_get", "ek_hip_debug_sytrd",
 )
 
 

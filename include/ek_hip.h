@@ -121,6 +121,9 @@ int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int l
  * stream.  _get returns the accumulated device seconds, the number of launches and the
  * algorithmic bytes (8 B x lower triangle of the active matrix per launch). */
 int ek_hip_profile_symv(int enable);
+/* Tuning hook: tridiagonalise a device-generated synthetic matrix (order n, leading dimension
+ * ld >= n rounded up to 128) `reps` times; *seconds = stage time per repetition. */
+int ek_hip_debug_sytrd(int n, int ld, int reps, double *seconds);
 int ek_hip_profile_symv_get(double *seconds, long long *launches, double *algorithmic_bytes);
 
 #ifdef __cplusplus

@@ -125,13 +125,20 @@ def test_sytrd_matches_oracle(hip, oracle, n):
     Ar, d, e, tau, info = hip.sytrd(A)
     assert info == 0
     scale = np.abs(A).max()
-    # same Householder convention => d, e, tau agree element-wise up to rounding growth
-    assert np.abs(d - d_or).max() <= 64 * n * EPS * scale
-    assert np.abs(np.abs(e) - np.abs(e_or)).max() <= 64 * n * EPS * scale
-    assert np.abs(tau - tau_or).max() <= 256 * n * EPS
+    # Same Householder convention => d, e, tau, v agree element-wise, but only up to the
+    # conditioning of the individual entries (the trailing reflectors amplify rounding):
+    # a loose element-wise sanity bound, and the tight bounds on what IS well conditioned --
+    # the backward error ||Q T Q^T - A||, the orthogonality of Q and the spectrum of T.
+    assert np.abs(d - d_or).max() <= 1e-9 * scale
+    assert np.abs(np.abs(e) - np.abs(e_or)).max() <= 1e-9 * scale
+    assert np.abs(tau - tau_or).max() <= 1e-9
     res, orth = _tridiag_check(A, Ar, d, e, tau, oracle)
     assert res <= 64 * n * EPS * scale
     assert orth <= 64 * n * EPS
+    T = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    T_or = np.diag(d_or) + np.diag(e_or, -1) + np.diag(e_or, 1)
+    assert np.abs(np.linalg.eigvalsh(T) - np.linalg.eigvalsh(T_or)).max() <= 8 * n * EPS * scale
+    assert np.abs(np.linalg.eigvalsh(T) - np.linalg.eigvalsh(A)).max() <= 8 * n * EPS * scale
     il = np.tril_indices(n, -2)
     if len(il[0]):
-        assert np.abs(Ar[il] - Ar_or[il]).max() <= 512 * n * EPS
+        assert np.abs(Ar[il] - Ar_or[il]).max() <= 1e-8
