@@ -14,21 +14,25 @@
 namespace ek {
 namespace {
 
-constexpr int KB = 128;
+constexpr int KB = 256;    // reflectors per compact-WY block
+constexpr int SB = 128;    // sub-block factored by one workgroup (two per block)
 
-// T_b from G_b = V_b^T V_b and tau (forward, columnwise: DLARFT):
+// T of one 128-wide sub-block from its Gram matrix and tau (forward, columnwise: DLARFT):
 //   T(i,i) = tau_i,  T(0:i, i) = -tau_i * T(0:i,0:i) * G(0:i, i)
+// Sub-block sb lives on the diagonal of block sb/2: offset (sb%2)*128 in both G and T (ld = KB).
 __global__ __launch_bounds__(128) void larft_kernel(int nrefl, const double *__restrict__ G,
                                                     const double *__restrict__ tau,
                                                     double *__restrict__ T) {
-  extern __shared__ double s[];          // KB x KB image of T + one column of G
-  double *sT = s, *sg = s + KB * KB;
-  const int b = blockIdx.x, t = threadIdx.x;
-  const int c0 = b * KB;
-  const int kb = (nrefl - c0 < KB) ? nrefl - c0 : KB;
-  const double *Gb = G + (size_t)b * KB * KB;
-  double *Tb = T + (size_t)b * KB * KB;
-  for (int idx = t; idx < KB * KB; idx += 128) sT[idx] = 0.0;
+  extern __shared__ double s[];          // SB x SB image of T + one column of G
+  double *sT = s, *sg = s + SB * SB;
+  const int sb = blockIdx.x, t = threadIdx.x;
+  const int c0 = sb * SB;
+  const int kb = (nrefl - c0 < SB) ? nrefl - c0 : SB;
+  if (kb <= 0) return;
+  const size_t off = (size_t)(sb / 2) * KB * KB + (size_t)(sb % 2) * SB * (KB + 1);
+  const double *Gb = G + off;
+  double *Tb = T + off;
+  for (int idx = t; idx < SB * SB; idx += 128) sT[idx] = 0.0;
   __syncthreads();
   for (int i = 0; i < kb; ++i) {
     const double ti = tau[c0 + i];
@@ -36,14 +40,14 @@ __global__ __launch_bounds__(128) void larft_kernel(int nrefl, const double *__r
     __syncthreads();
     if (t < i) {
       double acc = 0.0;
-      for (int c = t; c < i; ++c) acc += sT[t + KB * c] * sg[c];
-      sT[t + KB * i] = -ti * acc;
+      for (int c = t; c < i; ++c) acc += sT[t + SB * c] * sg[c];
+      sT[t + SB * i] = -ti * acc;
     } else if (t == i) {
-      sT[t + KB * i] = ti;
+      sT[t + SB * i] = ti;
     }
     __syncthreads();
   }
-  for (int idx = t; idx < KB * KB; idx += 128) Tb[idx] = sT[idx];
+  for (int idx = t; idx < SB * SB; idx += 128) Tb[(size_t)(idx & (SB - 1)) + (size_t)(idx >> 7) * KB] = sT[idx];
 }
 
 // Explicit V from the PDSYTRD storage (reflectors below the sub-diagonal of A).
@@ -71,7 +75,8 @@ void build_explicit_v(hipStream_t s, int n, const double *A, int lda, double *V,
 
 size_t ormtr_work_bytes(int n, int ncols) {
   const int nblk = ceil_div(n > 1 ? n - 1 : 1, KB);
-  return 2 * al256((size_t)nblk * KB * KB * 8) + 2 * al256((size_t)KB * (ncols > 0 ? ncols : 1) * 8);
+  return 2 * al256((size_t)nblk * KB * KB * 8) + al256((size_t)nblk * SB * SB * 8) +
+         2 * al256((size_t)KB * (ncols > 0 ? ncols : 1) * 8);
 }
 
 void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, const double *tau,
@@ -81,36 +86,65 @@ void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void *)larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (KB * KB + KB) * sizeof(double));
+                              (SB * SB + SB) * sizeof(double));
     attr = true;
   }
   const int nblk = ceil_div(nrefl, KB);
   char *w = (char *)work;
   double *G = (double *)w; w += al256((size_t)nblk * KB * KB * 8);
   double *T = (double *)w; w += al256((size_t)nblk * KB * KB * 8);
+  double *Tmp = (double *)w; w += al256((size_t)nblk * SB * SB * 8);
   double *W1 = (double *)w; w += al256((size_t)KB * ncols * 8);
   double *W2 = (double *)w;
 
-  // all Gram matrices in one batched GEMM (rows above a block's reflectors are zero in V)
-  {
+  // all Gram matrices G_b = V_b^T V_b in one batched GEMM (rows above a block's reflectors
+  // are zero in V, so the full column height can be used for every block)
+  const int full = nrefl / KB;            // blocks with all KB reflectors
+  if (full > 0) {
     GemmDesc g{};
     g.M = KB; g.N = KB; g.K = n; g.transA = true; g.transB = false; g.alpha = 1.0; g.beta = 0.0;
     g.A = V; g.lda = ldv; g.strideA = (long long)KB * ldv;
     g.B = V; g.ldb = ldv; g.strideB = (long long)KB * ldv;
     g.C = G; g.ldc = KB; g.strideC = (long long)KB * KB;
-    g.batch = nblk; g.lower_only = false;
-    if (nrefl % KB != 0) {      // last block is short: run it separately with its true width
-      g.batch = nblk - 1;
-      if (g.batch > 0) gemm(s, g);
-      const int c0 = (nblk - 1) * KB, kb = nrefl - c0;
-      gemm(s, true, false, kb, kb, n, 1.0, V + (size_t)c0 * ldv, ldv, V + (size_t)c0 * ldv, ldv, 0.0,
-           G + (size_t)(nblk - 1) * KB * KB, KB);
-    } else {
+    g.batch = full; g.lower_only = false;
+    gemm(s, g);
+  }
+  if (full < nblk) {
+    const int c0 = full * KB, kb = nrefl - c0;
+    gemm(s, true, false, kb, kb, n, 1.0, V + (size_t)c0 * ldv, ldv, V + (size_t)c0 * ldv, ldv, 0.0,
+         G + (size_t)full * KB * KB, KB);
+  }
+  // T_b = [T11, -T11 G12 T22; 0, T22]: the diagonal parts by one batched LDS kernel, the
+  // coupling by two batched 128^3 GEMMs
+  (void)hipMemsetAsync(T, 0, (size_t)nblk * KB * KB * 8, s);
+  hipLaunchKernelGGL(larft_kernel, dim3(2 * nblk), dim3(128), (SB * SB + SB) * sizeof(double), s, nrefl,
+                     G, tau, T);
+  {
+    const int nb2 = (nrefl - SB > 0) ? ceil_div(nrefl - SB, KB) : 0;   // blocks that have a 2nd half
+    const int fullb = (nrefl >= KB) ? nrefl / KB : 0;
+    if (fullb > 0) {
+      GemmDesc g{};
+      g.M = SB; g.N = SB; g.K = SB; g.transA = false; g.transB = false; g.alpha = 1.0; g.beta = 0.0;
+      g.A = G + (size_t)SB * KB; g.lda = KB; g.strideA = (long long)KB * KB;            // G12
+      g.B = T + (size_t)SB * (KB + 1); g.ldb = KB; g.strideB = (long long)KB * KB;       // T22
+      g.C = Tmp; g.ldc = SB; g.strideC = (long long)SB * SB;
+      g.batch = fullb; g.lower_only = false;
+      gemm(s, g);
+      g.alpha = -1.0;
+      g.A = T; g.lda = KB; g.strideA = (long long)KB * KB;                               // T11
+      g.B = Tmp; g.ldb = SB; g.strideB = (long long)SB * SB;
+      g.C = T + (size_t)SB * KB; g.ldc = KB; g.strideC = (long long)KB * KB;             // T12
       gemm(s, g);
     }
+    if (nb2 > fullb) {   // last block has a short second half of kb2 reflectors
+      const int b = fullb, kb2 = nrefl - b * KB - SB;
+      const double *Gb = G + (size_t)b * KB * KB;
+      double *Tb = T + (size_t)b * KB * KB, *Tm = Tmp + (size_t)b * SB * SB;
+      gemm(s, false, false, SB, kb2, kb2, 1.0, Gb + (size_t)SB * KB, KB, Tb + (size_t)SB * (KB + 1), KB,
+           0.0, Tm, SB);
+      gemm(s, false, false, SB, kb2, SB, -1.0, Tb, KB, Tm, SB, 0.0, Tb + (size_t)SB * KB, KB);
+    }
   }
-  hipLaunchKernelGGL(larft_kernel, dim3(nblk), dim3(128), (KB * KB + KB) * sizeof(double), s, nrefl, G,
-                     tau, T);
   for (int b = nblk - 1; b >= 0; --b) {
     const int c0 = b * KB;
     const int kb = (nrefl - c0 < KB) ? nrefl - c0 : KB;

@@ -32,6 +32,11 @@ struct DcBufs {
   double *zhat, *tauv;           // n: Loewner weights, secular shifts
   int *korig;                    // n: origin pole of each root
   int *perm, *wcol;              // n: sorted position -> local column / W column
+  int *grp;                      // n: survivor (ascending pole order) -> W column = row of S
+  int *spos;                     // n: survivor -> sorted position (scratch of the deflation scan)
+  long long *goffs;              // per merge 2 x {A, B, C} element offsets of the two merge GEMMs
+  int *gdims;                    // per merge 2 x {M, N, K}
+  int ldw, ldq, lds;             // leading dimensions of W (the output array), Q, S
   int *rotp, *rotn;              // n: rotation list (sorted positions)
   double *rotc, *rots;           // n
   double *rho;                   // per merge
@@ -179,19 +184,25 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
   const double rho = fabs(2.0 * b.e[off + mg.n1 - 1]);
   const double tol = 8.0 * eps * fmax(dm, zm);
   int *wcol = b.wcol + off, *rotp = b.rotp + off, *rotn = b.rotn + off;
+  int *grp = b.grp + off, *spos = b.spos + off;
+  const int *perm = b.perm + off;
+  // column types (DLAED2's COLTYP): 1 = non-zero in the top n1 rows only (from Q1),
+  // 3 = bottom rows only (from Q2), 2 = dense (a rotated pair from both); stored in grp[]
+  // temporarily as the survivor's type
   double *rotc = b.rotc + off, *rots = b.rots + off, *dl = b.dl + off, *zl = b.zl + off;
   double *dout = b.d + off;
   int k = 0, ndf = 0, nrot = 0;
   if (rho * zm <= tol) {
     for (int i = 0; i < n; ++i) { wcol[i] = n - 1 - ndf; dout[n - 1 - ndf] = ds[i]; ++ndf; }
   } else {
-    int pj = -1;
+    int pj = -1, tpj = 0;
     double dpj = 0.0, zpj = 0.0;
     for (int i = 0; i < n; ++i) {
       const double zi = zs[i], di = ds[i];
       if (rho * fabs(zi) <= tol) { wcol[i] = n - 1 - ndf; dout[n - 1 - ndf] = di; ++ndf; continue; }
-      if (pj < 0) { pj = i; dpj = di; zpj = zi; continue; }
+      if (pj < 0) { pj = i; dpj = di; zpj = zi; tpj = (perm[i] < mg.n1) ? 1 : 3; continue; }
       double s = zpj, c = zi;
+      const int ti = (perm[i] < mg.n1) ? 1 : 3;
       const double tau = hypot(c, s), tt = di - dpj;
       c /= tau; s = -s / tau;
       if (fabs(tt * c * s) <= tol) {
@@ -200,13 +211,29 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
         const double dnew_p = dpj * c * c + di * s * s;
         const double dnew_i = dpj * s * s + di * c * c;
         wcol[pj] = n - 1 - ndf; dout[n - 1 - ndf] = dnew_p; ++ndf;
-        pj = i; dpj = dnew_i; zpj = tau;
+        pj = i; dpj = dnew_i; zpj = tau; tpj = (tpj == ti) ? ti : 2;
       } else {
-        wcol[pj] = k; dl[k] = dpj; zl[k] = zpj; ++k;
-        pj = i; dpj = di; zpj = zi;
+        spos[k] = pj; grp[k] = tpj; dl[k] = dpj; zl[k] = zpj; ++k;
+        pj = i; dpj = di; zpj = zi; tpj = ti;
       }
     }
-    if (pj >= 0) { wcol[pj] = k; dl[k] = dpj; zl[k] = zpj; ++k; }
+    if (pj >= 0) { spos[k] = pj; grp[k] = tpj; dl[k] = dpj; zl[k] = zpj; ++k; }
+  }
+  // group the survivors' W columns by type: [top-only | dense | bottom-only]
+  int cnt[4] = {0, 0, 0, 0};
+  for (int a = 0; a < k; ++a) ++cnt[grp[a]];
+  int nxt[4] = {0, 0, cnt[1], cnt[1] + cnt[2]};
+  for (int a = 0; a < k; ++a) { const int g = nxt[grp[a]]++; grp[a] = g; wcol[spos[a]] = g; }
+  const int k1 = cnt[1], k12 = cnt[1] + cnt[2], k23 = cnt[2] + cnt[3];
+  // the two merge GEMMs: Q(top, 0:k) = W(top, 0:k12) S(0:k12, 0:k); Q(bot, 0:k) = W(bot, k1:k) S(k1:k, 0:k)
+  {
+    const long long o = off;
+    long long *go = b.goffs + 6 * (size_t)mi;
+    int *gd = b.gdims + 6 * (size_t)mi;
+    go[0] = o + o * b.ldw;                       go[1] = o + o * b.lds;        go[2] = o + o * b.ldq;
+    go[3] = o + mg.n1 + (o + k1) * b.ldw;        go[4] = o + k1 + o * b.lds;   go[5] = o + mg.n1 + o * b.ldq;
+    gd[0] = mg.n1;        gd[1] = k; gd[2] = k12;
+    gd[3] = n - mg.n1;    gd[4] = k; gd[5] = k23;
   }
   b.k[mi] = k; b.nrot[mi] = nrot; b.rho[mi] = rho;
 }
@@ -348,22 +375,19 @@ __global__ void dc_zhat_kernel(int mbeg, DcBufs b) {
   b.zhat[mg.off + j] = copysign(sqrt(fabs(p)), b.zl[mg.off + j]);
 }
 
-// Column c of S (n x n): c < k: normalised eigenvector of the rank-one update in rows 0..k-1;
-// c >= k: unit vector (deflated column passes through the GEMM unchanged).
+// Column c < k of S: the normalised eigenvector of the rank-one update, entry of pole a stored
+// in row grp[a] (the W column that carries pole a).  Rows >= k are never read by the GEMMs.
 __global__ __launch_bounds__(256) void dc_vectors_kernel(int mbeg, DcBufs b, double *__restrict__ S,
                                                          int lds) {
   __shared__ double red[4];
   const int mi = mbeg + blockIdx.y;
   const Merge mg = b.merges[mi];
   const int c = blockIdx.x, t = threadIdx.x;
-  if (c >= mg.n) return;
-  const int k = b.k[mi], n = mg.n;
+  const int k = b.k[mi];
+  if (c >= k) return;
   double *col = S + (size_t)mg.off + (size_t)(mg.off + c) * lds;
-  if (c >= k) {
-    for (int r = t; r < n; r += 256) col[r] = (r == c) ? 1.0 : 0.0;
-    return;
-  }
   const double *dl = b.dl + mg.off, *zh = b.zhat + mg.off;
+  const int *grp = b.grp + mg.off;
   const double dK = dl[b.korig[mg.off + c]], tau = b.tauv[mg.off + c];
   double ss = 0.0;
   for (int j = t; j < k; j += 256) {
@@ -375,8 +399,19 @@ __global__ __launch_bounds__(256) void dc_vectors_kernel(int mbeg, DcBufs b, dou
   if ((t & 63) == 0) red[t >> 6] = ss;
   __syncthreads();
   const double inv = 1.0 / sqrt((red[0] + red[1]) + (red[2] + red[3]));
-  for (int j = t; j < n; j += 256)
-    col[j] = (j < k) ? zh[j] / ((dl[j] - dK) - tau) * inv : 0.0;
+  for (int j = t; j < k; j += 256) col[grp[j]] = zh[j] / ((dl[j] - dK) - tau) * inv;
+}
+
+// Deflated eigenpairs: columns c >= k of W are final eigenvectors
+__global__ void dc_copy_deflated_kernel(int mbeg, DcBufs b, const double *__restrict__ W, int ldw,
+                                        double *__restrict__ Q, int ldq) {
+  const int mi = mbeg + blockIdx.z;
+  const Merge mg = b.merges[mi];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= mg.n) return;
+  const int k = b.k[mi], off = mg.off;
+  for (int c = k + blockIdx.y; c < mg.n; c += gridDim.y)
+    Q[(size_t)(off + r) + (size_t)(off + c) * ldq] = W[(size_t)(off + r) + (size_t)(off + c) * ldw];
 }
 
 // ------------------------------------------------------------------ final ordering
@@ -418,11 +453,11 @@ struct WorkLayout {
     off_Q = o; o += al256((size_t)n * n * 8);
     off_S = o; o += al256((size_t)n * n * 8);
     off_vec = o; o += 12 * al256((size_t)(n + 8) * 8) + al256((size_t)nmerge_cap * 8) + 256;
-    off_int = o; o += 6 * al256((size_t)(n + 8) * 4) + 2 * al256((size_t)nmerge_cap * 4);
+    off_int = o; o += 8 * al256((size_t)(n + 8) * 4) + 2 * al256((size_t)nmerge_cap * 4);
     off_merge = o; o += al256((size_t)nmerge_cap * sizeof(Merge));
     off_leaf = o; o += al256((size_t)nleaf_cap * sizeof(Leaf));
-    off_offs = o; o += al256((size_t)nmerge_cap * 3 * 8);
-    off_dims = o; o += al256((size_t)nmerge_cap * 3 * 4);
+    off_offs = o; o += al256((size_t)nmerge_cap * 6 * 8);
+    off_dims = o; o += al256((size_t)nmerge_cap * 6 * 4);
     total = o;
   }
 };
@@ -451,38 +486,29 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     auto iv = [&](size_t cnt) { int *r = (int *)q; q += al256(cnt * 4); return r; };
     b.korig = iv(n + 8); b.perm = iv(n + 8); b.wcol = iv(n + 8); b.rotp = iv(n + 8); b.rotn = iv(n + 8);
     int *fperm = iv(n + 8); (void)fperm;
+    b.grp = iv(n + 8); b.spos = iv(n + 8);
     b.k = iv(L.nmerge_cap); b.nrot = iv(L.nmerge_cap);
     b.merges = (Merge *)(base + L.off_merge);
+    b.goffs = (long long *)(base + L.off_offs);
+    b.gdims = (int *)(base + L.off_dims);
+    b.ldw = ldz; b.ldq = ldq; b.lds = lds;
   }
   int *fperm = (int *)(base + L.off_int + 5 * al256((size_t)(n + 8) * 4));
   Leaf *d_leaves = (Leaf *)(base + L.off_leaf);
-  long long *d_offs = (long long *)(base + L.off_offs);
-  int *d_dims = (int *)(base + L.off_dims);
 
   Plan plan;
   plan.height(0, n);
   std::vector<Merge> all;
-  std::vector<long long> offs;
-  std::vector<int> dims;
   std::vector<int> lvl_beg;
   for (auto &lv : plan.levels) {
     lvl_beg.push_back((int)all.size());
-    for (auto &m : lv) {
-      all.push_back(m);
-      const long long o = (long long)m.off + (long long)m.off * n;
-      offs.push_back((long long)m.off + (long long)m.off * ldz);   // A = W (in Z buffer)
-      offs.push_back(o);                                           // B = S
-      offs.push_back(o);                                           // C = Q
-      dims.push_back(m.n); dims.push_back(m.n); dims.push_back(m.n);
-    }
+    for (auto &m : lv) all.push_back(m);
   }
   lvl_beg.push_back((int)all.size());
   (void)hipMemcpyAsync(d_leaves, plan.leaves.data(), plan.leaves.size() * sizeof(Leaf),
                        hipMemcpyHostToDevice, s);
   if (!all.empty()) {
     (void)hipMemcpyAsync(b.merges, all.data(), all.size() * sizeof(Merge), hipMemcpyHostToDevice, s);
-    (void)hipMemcpyAsync(d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s);
-    (void)hipMemcpyAsync(d_dims, dims.data(), dims.size() * 4, hipMemcpyHostToDevice, s);
   }
   (void)hipStreamSynchronize(s);   // host vectors go out of scope; pageable copies are staged anyway
 
@@ -508,12 +534,17 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     hipLaunchKernelGGL(dc_secular_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b);
     hipLaunchKernelGGL(dc_zhat_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b);
     hipLaunchKernelGGL(dc_vectors_kernel, dim3(maxn, cnt), dim3(256), 0, s, mbeg, b, S, lds);
+    // two GEMMs per merge (top rows x [top-only|dense] columns, bottom rows x [dense|bottom-only]
+    // columns), all merges of this height in one launch; sizes and offsets come from the
+    // deflation kernel, so nothing returns to the host
     GemmDesc g{};
-    g.M = maxn; g.N = maxn; g.K = maxn; g.transA = false; g.transB = false; g.alpha = 1.0; g.beta = 0.0;
+    g.M = (maxn + 1) / 2; g.N = maxn; g.K = maxn; g.transA = false; g.transB = false;
+    g.alpha = 1.0; g.beta = 0.0;
     g.A = W; g.lda = ldz; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
-    g.C = Q; g.ldc = ldq; g.strideC = 0; g.batch = cnt; g.lower_only = false;
-    g.d_offs = d_offs + 3 * (size_t)mbeg; g.d_dims = d_dims + 3 * (size_t)mbeg;
+    g.C = Q; g.ldc = ldq; g.strideC = 0; g.batch = 2 * cnt; g.lower_only = false;
+    g.d_offs = b.goffs + 6 * (size_t)mbeg; g.d_dims = b.gdims + 6 * (size_t)mbeg;
     gemm(s, g);
+    hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldz, Q, ldq);
   }
   hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, b, w, fperm);
   gather_columns(s, n, n, Q, ldq, fperm, Z, ldz);

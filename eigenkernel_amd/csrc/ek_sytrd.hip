@@ -41,10 +41,12 @@ struct SytrdBufs {
   double *ypart;     // NRB x npad   row-part partial sums per strip
   double *tpart;     // NRB x NRB x 128  column-part partial sums per (strip, piece)
   double *vavpart;   // one v^T A v partial sum per symv workgroup
-  double *normpart;  // one partial sum of squares per colupd workgroup
+  double *normpart;  // 2 x nch: one partial sum of squares per colupd workgroup, double-buffered
+                     // by column parity (a launch reads the previous column's while writing its own)
+  int nch;           // stride between the two normpart buffers
   double *dotpart;   // (colupd workgroups) x 2*NBP  partial sums of V^T x, W^T x
   double *dottot;    // 2*NBP  totals V^T v, W^T v of the current column (written by symv)
-  double *scal;      // [0] = alpha0 of the current column
+  double *scal;      // [c & 1] = alpha0 (first entry of the unscaled column) of column c
 };
 
 struct Refl { double beta, tau, scale; };
@@ -59,13 +61,24 @@ __device__ __forceinline__ double block_sum(double v, double *red /* >= 4 */) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// Householder data of the current column from its partial sums.  Evaluated cooperatively by
-// every 256-thread workgroup of both kernels in the same order => identical bits everywhere.
-__device__ __forceinline__ Refl reflector(const double *__restrict__ normpart, int nchunks,
-                                          double alpha0, double *red) {
-  double part = 0.0;
-  for (int c = threadIdx.x; c < nchunks; c += 256) part += normpart[c];
-  const double ssq = block_sum(part, red);
+// N sums at once (one barrier pair); red holds 4*N doubles
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double *red) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[4 * i + (threadIdx.x >> 6)] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = (red[4 * i] + red[4 * i + 1]) + (red[4 * i + 2] + red[4 * i + 3]);
+}
+
+// Householder data (DLARFG) from alpha = x_1 and the sum of squares of x_2..x_m.
+__device__ __forceinline__ Refl reflector(double ssq, double alpha0) {
   Refl r;
   if (ssq == 0.0) { r.beta = alpha0; r.tau = 0.0; r.scale = 0.0; return r; }
   const double xnorm = sqrt(ssq);
@@ -130,38 +143,55 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
   double *__restrict__ Pv2 = p.b.P + (size_t)2 * NBP * ldp; // V copy
   const double *s_pv = s_pvw, *s_pw = s_pvw + NBP;
 
-  double accB = 0.0;
+  double accB = 0.0, a_old = 0.0;
   if (p.finalize) {
+    // symv ran on the UNSCALED column x (x_j = alpha0 included): with v = scale*x + corr*e_j,
+    // corr = 1 - scale*alpha0, everything it produced is corrected here by linearity:
+    //   A v = scale*(A x) + corr*A(:,j),  V^T v = scale*(V^T x) + corr*V(j,:),
+    //   v^T A v = scale^2 x^T A x + 2 scale corr (A x)_j + corr^2 A(j,j).
     const int ip = p.ip, jp = p.jp, j = jp + 1;
     const int T = p.NRB - p.S0p;
-    const Refl rf = reflector(p.b.normpart, p.nchunks_p, p.b.scal[0], s_red);
-    // totals of the panel products (reduced by the symv launch's reducer workgroup)
-    if (t < 2 * NBP) s_pvw[t] = ((t & (NBP - 1)) < ip) ? p.b.dottot[t] : 0.0;
-    double part = 0.0;
-    for (int u = t; u < p.nwg_p; u += 256) part += p.b.vavpart[u];
-    const double vav = block_sum(part, s_red);   // its barriers also publish s_pvw
-    double dvw = 0.0;
-    for (int k = 0; k < ip; ++k) dvw += s_pv[k] * s_pw[k];
-    const double wv = rf.tau * (vav - 2.0 * dvw);
-    const double alpha = -0.5 * rf.tau * wv;
-    // row j = jp + 1 of the panel (needed by every workgroup for the column update)
-    double wj;
+    const int rbj = j / TS;
+    double red3[3] = {0.0, 0.0, 0.0};   // ssq, x^T A x, (A x)_j
+    const double *normp = p.b.normpart + (size_t)(jp & 1) * p.b.nch;
+    for (int c = t; c < p.nchunks_p; c += 256) red3[0] += normp[c];
+    for (int u = t; u < p.nwg_p; u += 256) red3[1] += p.b.vavpart[u];
     {
-      const int rbj = j / TS;
-      double part2 = 0.0;
       const int nS = rbj - p.S0p + 1;
-      for (int idx = t; idx < nS; idx += 256) part2 += p.b.ypart[(size_t)(p.S0p + idx) * p.npad + j];
+      for (int idx = t; idx < nS; idx += 256) red3[2] += p.b.ypart[(size_t)(p.S0p + idx) * p.npad + j];
       const int np = num_pieces(rbj - p.S0p, T, p.qp);
       for (int idx = t; idx < np; idx += 256)
-        part2 += p.b.tpart[((size_t)rbj * p.NRB + idx) * TS + (j % TS)];
-      if (t < ip) {
-        const double vjk = Pv[(size_t)j + (size_t)t * ldp], wjk = Pw[(size_t)j + (size_t)t * ldp];
-        s_Vj[t] = vjk; s_Wj[t] = wjk;
-        part2 -= vjk * s_pw[t] + wjk * s_pv[t];
-      }
-      const double yj = block_sum(part2, s_red);   // publishes s_Vj / s_Wj
-      wj = rf.tau * yj + alpha;                    // v_j = 1
+        red3[2] += p.b.tpart[((size_t)rbj * p.NRB + idx) * TS + (j % TS)];
     }
+    double vjk = 0.0, wjk = 0.0, dtot = 0.0;
+    if (t < 2 * NBP && (t & (NBP - 1)) < ip) {
+      const int k = t & (NBP - 1);
+      vjk = Pv[(size_t)j + (size_t)k * ldp]; wjk = Pw[(size_t)j + (size_t)k * ldp];
+      dtot = p.b.dottot[t];
+    }
+    const double alpha0 = p.b.scal[jp & 1];
+    const double ajj = p.A[(size_t)j + (size_t)j * p.lda];   // still the panel-start value: A(:,j)
+                                                             // is not written until column j is finalized
+    if (r >= j && r < p.n) a_old = p.A[(size_t)r + (size_t)j * p.lda];
+    block_sum_n<3>(red3, s_red);
+    const Refl rf = reflector(red3[0], alpha0);
+    const double corr = 1.0 - rf.scale * alpha0;
+    if (t < 2 * NBP) {
+      const int k = t & (NBP - 1);
+      double pvw = 0.0;
+      if (k < ip) pvw = rf.scale * dtot + corr * (t < NBP ? vjk : wjk);
+      s_pvw[t] = pvw;
+      if (t < NBP) { s_Vj[k] = vjk; } else { s_Wj[k] = wjk; }
+    }
+    __syncthreads();
+    double red2[2] = {0.0, 0.0};   // sum_k pv*pw,  sum_k (Vj pw + Wj pv)
+    if (t < ip) { red2[0] = s_pv[t] * s_pw[t]; red2[1] = s_Vj[t] * s_pw[t] + s_Wj[t] * s_pv[t]; }
+    block_sum_n<2>(red2, s_red);
+    const double vav = rf.scale * rf.scale * red3[1] + 2.0 * rf.scale * corr * red3[2] + corr * corr * ajj;
+    const double wv = rf.tau * (vav - 2.0 * red2[0]);
+    const double alpha = -0.5 * rf.tau * wv;
+    const double yj = rf.scale * red3[2] + corr * ajj;
+    const double wj = rf.tau * (yj - red2[1]) + alpha;   // v_j = 1
     // per-row sums, 4 slices per row for memory-level parallelism
     double y = 0.0, accA = 0.0, aB = 0.0;
     if (r >= j && r < p.npad) {
@@ -205,7 +235,8 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
         accB = (s_acc[2][0][lane] + s_acc[2][1][lane]) + (s_acc[2][2][lane] + s_acc[2][3][lane]);
         double v_r = (r == j) ? 1.0 : p.b.xbuf[r] * rf.scale;
         if (r >= p.n) v_r = 0.0;
-        double w_r = (r == j) ? wj : rf.tau * (y - accA) + alpha * v_r;
+        const double y_r = rf.scale * y + corr * a_old;
+        double w_r = (r == j) ? wj : rf.tau * (y_r - accA) + alpha * v_r;
         if (r >= p.n) w_r = 0.0;
         Pv[(size_t)r + (size_t)ip * ldp] = v_r;
         Pv2[(size_t)r + (size_t)ip * ldp] = v_r;
@@ -229,13 +260,13 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
   const int j = p.j;
   double sq = 0.0, xr = 0.0;
   if (q == 0 && r >= j && r < p.n) {
-    const double a = p.A[(size_t)r + (size_t)j * p.lda] - accB;
-    p.A[(size_t)r + (size_t)j * p.lda] = a;
+    if (!p.finalize) a_old = p.A[(size_t)r + (size_t)j * p.lda];
+    const double a = a_old - accB;   // the updated column lives in xbuf / d only
     if (r == j) { p.d[j] = a; p.b.xbuf[r] = 0.0; }
     else {
       p.b.xbuf[r] = a;
       xr = a;
-      if (r == j + 1) p.b.scal[0] = a;
+      if (r == j + 1) p.b.scal[j & 1] = a;
       else sq = a * a;
     }
   }
@@ -244,7 +275,7 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
     if (!(p.finalize && r >= j && r < p.npad)) { s_vn[lane] = 0.0; s_wn[lane] = 0.0; }
   }
   const double tot = block_sum(sq, s_red);   // its barriers also publish s_x / s_vn / s_wn
-  if (t == 0) p.b.normpart[blockIdx.x] = tot;
+  if (t == 0) p.b.normpart[(size_t)(j & 1) * p.b.nch + blockIdx.x] = tot;
   // partial panel products V^T x and W^T x over this workgroup's 64 rows: thread <-> panel
   // column, no cross-lane reduction; the newest column comes from LDS (not yet visible in P)
   if (t < 2 * NBP) {
@@ -256,15 +287,17 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
         const double *src = (t < NBP) ? s_vn : s_wn;
         for (int l = 0; l < CR; ++l) acc += src[l] * s_x[l];
       } else {
-        const double *col = ((t < NBP) ? Pv : Pw) + (size_t)k * ldp + rbase;
+        // rbase is a multiple of 64 and npad of 128: the 64 rows are in bounds and 16-B aligned
+        const double2 *col = reinterpret_cast<const double2 *>(((t < NBP) ? Pv : Pw) + (size_t)k * ldp + rbase);
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        const int lim = (p.npad - rbase < CR) ? p.npad - rbase : CR;
-        int l = 0;
-        for (; l + 3 < lim; l += 4) {
-          a0 += col[l] * s_x[l]; a1 += col[l + 1] * s_x[l + 1];
-          a2 += col[l + 2] * s_x[l + 2]; a3 += col[l + 3] * s_x[l + 3];
+#pragma unroll
+        for (int l = 0; l < CR / 2; l += 4) {
+          const double2 c0 = col[l], c1 = col[l + 1], c2 = col[l + 2], c3 = col[l + 3];
+          a0 += c0.x * s_x[2 * l] + c0.y * s_x[2 * l + 1];
+          a1 += c1.x * s_x[2 * l + 2] + c1.y * s_x[2 * l + 3];
+          a2 += c2.x * s_x[2 * l + 4] + c2.y * s_x[2 * l + 5];
+          a3 += c3.x * s_x[2 * l + 6] + c3.y * s_x[2 * l + 7];
         }
-        for (; l < lim; ++l) a0 += col[l] * s_x[l];
         acc = (a0 + a1) + (a2 + a3);
       }
     }
@@ -326,12 +359,10 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
   __shared__ double s_dot[2][2 * NBP];
   __shared__ double s_t[4][16 * 65];     // per-wave transpose buffer for the column-part flush
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int j1 = p.j + 1;
   const double *__restrict__ xbuf = p.b.xbuf;
 
   if ((int)blockIdx.x < p.ndot) {
-    // ---- reducer: V^T v = scale * (V^T x - x_{j+1} V(j+1,:)) + V(j+1,:), same for W
-    const Refl rf = reflector(p.b.normpart, p.nchunks, p.b.scal[0], s_red);
+    // ---- reducer: totals of the raw panel products V^T x, W^T x (colupd applies the scaling)
     double a0 = 0.0, a1 = 0.0;
     const int k2 = t & (2 * NBP - 1), half = t >> 7;
     int c = half;
@@ -342,17 +373,7 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
     if (c < p.nchunks) a0 += p.b.dotpart[(size_t)c * 2 * NBP + k2];
     s_dot[half][k2] = a0 + a1;
     __syncthreads();
-    if (t < 2 * NBP) {
-      const int k = t & (NBP - 1);
-      double res = 0.0;
-      if (k < p.i) {
-        const double tot = s_dot[0][t] + s_dot[1][t];
-        const double *Pm = p.b.P + (size_t)(t < NBP ? 0 : NBP) * p.npad;
-        const double rowj1 = Pm[(size_t)j1 + (size_t)k * p.npad];
-        res = rf.scale * (tot - rowj1 * p.b.scal[0]) + rowj1;
-      }
-      p.b.dottot[t] = res;
-    }
+    if (t < 2 * NBP) p.b.dottot[t] = ((t & (NBP - 1)) < p.i) ? s_dot[0][t] + s_dot[1][t] : 0.0;
     return;
   }
 
@@ -363,10 +384,7 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
   int L1 = L0 + p.q; if (L1 > p.ntiles) L1 = p.ntiles;
   double vav = 0.0;
   if (L0 >= L1) {   // (cannot happen with nwg = ceil(ntiles / q); kept for safety)
-    const Refl rf0 = reflector(p.b.normpart, p.nchunks, p.b.scal[0], s_red);
-    (void)rf0;
-    const double tot0 = block_sum(0.0, s_red);
-    if (t == 0) p.b.vavpart[w] = tot0;
+    if (t == 0) p.b.vavpart[w] = 0.0;
     return;
   }
   int s = strip_of_tile(L0, T);
@@ -377,8 +395,7 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
   };
   d2_t bufA[QC], bufB[QC];
   const double *cur = tile_ptr(s, rbrel);
-  part_load(bufA, cur, p.lda);                       // in flight while the prologue runs
-  const Refl rf = reflector(p.b.normpart, p.nchunks, p.b.scal[0], s_red);
+  part_load(bufA, cur, p.lda);
   double tc[32];
   int buf = 0;
   bool new_strip = true;
@@ -387,12 +404,7 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
     const int S = p.S0 + s, rb = p.S0 + rbrel;
     part_load(bufB, cur + QC * lda, p.lda);
     if (new_strip) {
-      if (t < TS) {
-        const int c = S * TS + t;
-        double v = 0.0;
-        if (c >= j1 && c < p.n) v = (c == j1) ? 1.0 : xbuf[c] * rf.scale;
-        s_vc[t] = v;
-      }
+      if (t < TS) s_vc[t] = xbuf[S * TS + t];   // x is 0 outside the active range j1 .. n-1
 #pragma unroll
       for (int c = 0; c < 32; ++c) tc[c] = 0.0;
       __syncthreads();
@@ -400,9 +412,7 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
     }
     const int row = rb * TS + 2 * lane;
     const double2 x = *reinterpret_cast<const double2 *>(xbuf + row);
-    double vr0 = 0.0, vr1 = 0.0;
-    if (row >= j1 && row < p.n) vr0 = (row == j1) ? 1.0 : x.x * rf.scale;
-    if (row + 1 >= j1 && row + 1 < p.n) vr1 = (row + 1 == j1) ? 1.0 : x.y * rf.scale;
+    const double vr0 = x.x, vr1 = x.y;
     double y0 = 0.0, y1 = 0.0;
     const bool diag = (rb == S);
     if (diag) part_fma<true>(bufA, 0, 2 * lane, wave * 32, svc, vr0, vr1, y0, y1, tc);
@@ -426,9 +436,7 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
       const double ys = (s_y[buf][0][t] + s_y[buf][1][t]) + (s_y[buf][2][t] + s_y[buf][3][t]);
       const int rr = rb * TS + t;
       p.b.ypart[(size_t)S * p.npad + rr] = ys;
-      double vr = 0.0;
-      if (rr >= j1 && rr < p.n) vr = (rr == j1) ? 1.0 : xbuf[rr] * rf.scale;
-      vav += vr * ys;
+      vav += xbuf[rr] * ys;
     }
     buf ^= 1;
     if (strip_ends) {
@@ -463,6 +471,12 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
   }
   const double tot = block_sum(vav, s_red);
   if (t == 0) p.b.vavpart[w] = tot;
+}
+
+// PDSYTRD leaves d on the diagonal and e on the sub-diagonal of A
+__global__ void put_diag_kernel(int n, double *A, int lda, const double *__restrict__ d) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) A[(size_t)j + (size_t)j * lda] = d[j];
 }
 
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -502,7 +516,7 @@ struct Layout {
     off_y = o; o += al256((size_t)NRB * npad * 8);
     off_t = o; o += al256((size_t)NRB * NRB * TS * 8);
     off_vav = o; o += al256((size_t)(NRB * NRB + 4096) * 8);
-    off_norm = o; o += al256((size_t)nch * 8);
+    off_norm = o; o += al256((size_t)2 * nch * 8);
     off_dot = o; o += al256((size_t)nch * 2 * NBP * 8);
     off_dtot = o; o += al256((size_t)2 * NBP * 8);
     off_scal = o; o += 256;
@@ -522,7 +536,7 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
   SytrdBufs b;
   b.xbuf = (double *)(w + L.off_x); b.P = (double *)(w + L.off_P);
   b.ypart = (double *)(w + L.off_y); b.tpart = (double *)(w + L.off_t);
-  b.vavpart = (double *)(w + L.off_vav); b.normpart = (double *)(w + L.off_norm);
+  b.vavpart = (double *)(w + L.off_vav); b.normpart = (double *)(w + L.off_norm); b.nch = L.nch;
   b.dotpart = (double *)(w + L.off_dot); b.dottot = (double *)(w + L.off_dtot);
   b.scal = (double *)(w + L.off_scal);
   (void)hipMemsetAsync(work, 0, L.total, s);
@@ -600,6 +614,7 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
   // last diagonal entry
   c.finalize = 0; c.update = 1; c.j = n - 1; c.i_new = 0;
   launch_colupd(n - 1);
+  hipLaunchKernelGGL(put_diag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, A, lda, d);
 }
 
 void symv_profile_enable(bool on) {
