@@ -1,0 +1,10 @@
+#!/bin/sh
+# Regenerates the ScaLAPACK golden eigenvalues (oneMKL ScaLAPACK from /opt/conda, MPICH):
+# the reference's own call sequence (oracle/scalapack_path.c) on the synthetic inputs of
+# SURVEY.md 8(d), on the reference's 2x2 grid.  Run from the repo root after `make -C oracle`.
+set -e
+for spec in "256 1 gep" "256 0 sep" "1000 1 gep"; do
+  set -- $spec
+  /opt/conda/bin/mpiexec -np 4 oracle/scalapack_path $1 $2 tests/golden/scalapack_synth_$3_n$1_np4.txt > /dev/null
+done
+/opt/conda/bin/mpiexec -np 1 oracle/scalapack_path 256 1 tests/golden/scalapack_synth_gep_n256_np1.txt > /dev/null

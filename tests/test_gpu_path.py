@@ -186,3 +186,15 @@ def test_device_resident_solve_and_synth(hip, oracle):
     assert st[:7].sum() > 0
     for p in ptrs:
         lib.ek_hip_free(p)
+
+
+@pytest.mark.parametrize("name,n,gep", [("gep_n256_np4", 256, True), ("sep_n256_np4", 256, False),
+                                         ("gep_n1000_np4", 1000, True)])
+def test_hip_vs_scalapack_goldens(hip, oracle, golden_dir, name, n, gep):
+    """The HIP path against eigenvalues of the reference's ScaLAPACK path on the same inputs
+    (fixtures from tests/golden/make_scalapack_goldens.sh). Tolerance N*eps*max|lambda|."""
+    w_ref = np.loadtxt(os.path.join(golden_dir, "scalapack_synth_%s.txt" % name))
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2) if gep else None
+    ep, _ = hip.eigen_solver("general_hip" if gep else "hip", A, B)
+    assert np.abs(ep.values - w_ref).max() <= n * EPS * np.abs(w_ref).max()

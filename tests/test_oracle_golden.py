@@ -169,3 +169,18 @@ def test_oracle_vs_scipy_generalized(oracle):
         w, Z, info, _ = oracle.solve(A, B)
         assert info == 0
         assert np.abs(w - sl.eigh(A, B, eigvals_only=True)).max() <= n * EPS * np.abs(w).max() * 4
+
+
+@pytest.mark.parametrize("name,n,gep", [("gep_n256_np4", 256, True), ("sep_n256_np4", 256, False),
+                                         ("gep_n1000_np4", 1000, True), ("gep_n256_np1", 256, True)])
+def test_oracle_vs_scalapack_goldens(oracle, golden_dir, name, n, gep):
+    """Eigenvalues produced by the reference's own library path (oneMKL ScaLAPACK: PDPOTRF,
+    PDSYGST, PDSYTRD, PDSTEDC, ... via oracle/scalapack_path.c, 2x2 and 1x1 grids) on the
+    synthetic inputs; fixtures generated by tests/golden/make_scalapack_goldens.sh.
+    Tolerance N*eps*max|lambda| (reference cross-grid noise is 5e-15)."""
+    w_ref = np.loadtxt(os.path.join(golden_dir, "scalapack_synth_%s.txt" % name))
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2) if gep else None
+    w, _, info, _ = oracle.solve(A, B)
+    assert info == 0
+    assert np.abs(w - w_ref).max() <= n * EPS * np.abs(w_ref).max()
