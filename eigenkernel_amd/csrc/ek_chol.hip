@@ -23,13 +23,25 @@ constexpr int NB = kDiagNB;   // 128
 // One workgroup: B(0:nb,0:nb) = L L^T in LDS, then inv(L).  s is the 128x128 column-major
 // image; positions outside nb are the identity so that short edge blocks need no special
 // casing.  info (device): first non-positive pivot (1-based, global numbering) or 0.
+// Both phases are blocked by 16 so that almost all arithmetic runs on register tiles fed
+// from LDS, with a handful of barriers per 16 columns instead of three per column:
+//   factor : 16x16 diagonal block by one wavefront -> row-per-thread solve of the 16-column
+//            panel -> rank-16 update of the trailing block in 4x4 register tiles;
+//   invert : diagonal 16x16 blocks by forward substitution (a column per thread), then block
+//            row by block row  X_IJ = -inv(L_II) * sum_K L_IK X_KJ.
+// inv(L)(i,c), i > c, lives at s[c + 128*i] (the mirrored, strictly-upper position); its
+// diagonal 1/L(c,c) in sd[].
 // FACTOR = false: B already holds L; only the inverses are formed, one workgroup per
 // diagonal block (blockIdx.x), for stage-level calls that receive L from the host.
+constexpr int PB = 16;
+
 template <bool FACTOR>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(int nb_or_n, double *B, int ldb,
                                                          double *inv, int *info, int info_base) {
   extern __shared__ double s[];
-  const int t = threadIdx.x;
+  double *sd = s + NB * NB;            // 1 / L(i,i)
+  __shared__ int s_fail;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int nb = nb_or_n;
   if (!FACTOR) {
     const int off = blockIdx.x * NB;
@@ -43,61 +55,160 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(int nb_or_n, double *B,
     if (i < nb && j < nb && i >= j) v = B[(size_t)i + (size_t)j * ldb];
     s[idx] = v;
   }
-  bool failed = false;
-  for (int j = 0; FACTOR && j < nb; ++j) {
-    __syncthreads();
-    const double d = s[j + NB * j];
-    if (!(d > 0.0)) {
-      if (t == 0) atomicCAS(info, 0, info_base + j + 1);
-      failed = true;
-      break;
-    }
-    const double l = sqrt(d), r = 1.0 / l;
-    __syncthreads();
-    if (t < NB) {
-      if (t > j) s[t + NB * j] *= r;
-      else if (t == j) s[t + NB * j] = l;
-    }
-    __syncthreads();
-    const int i = j + 1 + (t & (NB - 1));
-    if (i < nb) {
-      const double lij = s[i + NB * j];
-      for (int k = j + 1 + (t >> 7); k <= i; k += 2) s[i + NB * k] -= lij * s[k + NB * j];
-    }
-  }
+  if (t == 0) s_fail = 0;
   __syncthreads();
-  if (FACTOR)
+  bool failed = false;
+  if (FACTOR) {
+    for (int p0 = 0; p0 < nb; p0 += PB) {
+      // (a) 16x16 diagonal block, one wavefront (LDS operations of a wave execute in order)
+      if (wave == 0) {
+        for (int j = 0; j < PB; ++j) {
+          const double d = s[(p0 + j) + NB * (p0 + j)];
+          if (!(d > 0.0)) {
+            if (lane == 0) { s_fail = 1; atomicCAS(info, 0, info_base + p0 + j + 1); }
+            break;
+          }
+          const double l = sqrt(d), r = 1.0 / l;
+          if (lane < PB) {
+            if (lane > j) s[(p0 + lane) + NB * (p0 + j)] *= r;
+            else if (lane == j) s[(p0 + j) + NB * (p0 + j)] = l;
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * u, i = e & (PB - 1), k = e >> 4;
+            if (k > j && i >= k) s[(p0 + i) + NB * (p0 + k)] -= s[(p0 + i) + NB * (p0 + j)] * s[(p0 + k) + NB * (p0 + j)];
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      __syncthreads();
+      if (s_fail) { failed = true; break; }
+      const int r0 = p0 + PB;
+      if (r0 >= NB) break;
+      // (b) panel below: row r solves x L11^T = a (forward substitution along the row)
+      if (t < NB - r0) {
+        const int r = r0 + t;
+        double x[PB];
+#pragma unroll
+        for (int c = 0; c < PB; ++c) x[c] = s[r + NB * (p0 + c)];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+          double a = x[j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) a -= x[k] * s[(p0 + j) + NB * (p0 + k)];
+          x[j] = a / s[(p0 + j) + NB * (p0 + j)];
+        }
+#pragma unroll
+        for (int c = 0; c < PB; ++c) s[r + NB * (p0 + c)] = x[c];
+      }
+      __syncthreads();
+      // (c) trailing block -= X X^T, lower part, 4x4 register tiles
+      const int m = NB - r0, nt = m >> 2;
+      for (int idx = t; idx < nt * nt; idx += 256) {
+        const int ti = idx % nt, tj = idx / nt;
+        if (ti < tj) continue;
+        const int i0 = r0 + 4 * ti, k0 = r0 + 4 * tj;
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+          const double4 xi = *reinterpret_cast<const double4 *>(&s[i0 + NB * (p0 + c)]);
+          const double4 xk = *reinterpret_cast<const double4 *>(&s[k0 + NB * (p0 + c)]);
+          const double xiv[4] = {xi.x, xi.y, xi.z, xi.w}, xkv[4] = {xk.x, xk.y, xk.z, xk.w};
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += xiv[a] * xkv[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            if (i0 + a >= k0 + b) s[(i0 + a) + NB * (k0 + b)] -= acc[a][b];
+      }
+      __syncthreads();
+    }
+    __syncthreads();
     for (int idx = t; idx < NB * NB; idx += 256) {
       const int i = idx & (NB - 1), j = idx >> 7;
       if (i < nb && j < nb && i >= j) B[(size_t)i + (size_t)j * ldb] = s[idx];
     }
+  }
   if (failed) {   // leave a harmless inverse so later kernels stay finite
     for (int idx = t; idx < NB * NB; idx += 256)
       inv[idx] = ((idx & (NB - 1)) == (idx >> 7)) ? 1.0 : 0.0;
     return;
   }
-  // inv(L): thread c owns column c of X = inv(L); X(i,c), i > c, lives at s[c + NB*i]
-  // (the mirrored, strictly-upper position), so lanes touch consecutive LDS words while
-  // L(i,k) is one broadcast word.  A column only reads its own earlier entries: no barrier.
+  // ---- inverse
+  if (t < NB) sd[t] = 1.0 / s[t + NB * t];
+  __syncthreads();
+  // step 1: inverses of the diagonal 16x16 blocks, a column per thread
   if (t < NB) {
-    const int c = t;
-    const double dinv = 1.0 / s[c + NB * c];
-    for (int i = 1; i < NB; ++i) {
-      double acc = 0.0;
-      for (int k = 0; k < i; ++k) {
-        const double lik = s[i + NB * k];
-        const double xkc = (k > c) ? s[c + NB * k] : (k == c ? dinv : 0.0);
-        acc += lik * xkc;
+    const int c = t, cl = c & (PB - 1), b0 = c - cl;
+    double x[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      if (i == cl) x[i] = sd[c];
+      else if (i > cl) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+          if (k >= cl && k < i) a += s[(b0 + i) + NB * (b0 + k)] * x[k];
+        x[i] = -a * sd[b0 + i];
       }
-      if (i > c) s[c + NB * i] = -acc / s[i + NB * i];
     }
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      if (i > cl) s[c + NB * (b0 + i)] = x[i];
   }
   __syncthreads();
+  // step 2: block rows I = 1..7; X_IJ = -inv(L_II) * T, T = sum_{K=J..I-1} L_IK X_KJ
+  for (int I = 1; I < NB / PB; ++I) {
+    const int ib = I * PB, ncol = ib;       // columns c < ib
+    // T(i, c) -> s[c + NB*i] (the final location of X(i,c))
+    for (int idx = t; idx < PB * ncol; idx += 256) {
+      const int il = idx & (PB - 1), c = idx >> 4;
+      const int i = ib + il;
+      double a = 0.0;
+      for (int k = c; k < ib; ++k) {
+        const double xkc = (k == c) ? sd[c] : s[c + NB * k];
+        a += s[i + NB * k] * xkc;
+      }
+      s[c + NB * i] = a;
+    }
+    __syncthreads();
+    // X(ib.., c) = -inv(L_II) T(ib.., c): a column segment per thread (in registers)
+    if (t < ncol) {
+      const int c = t;
+      double tv[PB], xv[PB];
+#pragma unroll
+      for (int i = 0; i < PB; ++i) tv[i] = s[c + NB * (ib + i)];
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        double a = sd[ib + i] * tv[i];
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+          if (k < i) a += s[(ib + k) + NB * (ib + i)] * tv[k];   // inv(L_II)(i,k), mirrored
+        xv[i] = -a;
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) s[c + NB * (ib + i)] = xv[i];
+    }
+    __syncthreads();
+  }
   for (int idx = t; idx < NB * NB; idx += 256) {
     const int i = idx & (NB - 1), c = idx >> 7;
     double v = 0.0;
     if (i > c) v = s[c + NB * i];
-    else if (i == c) v = 1.0 / s[c + NB * c];
+    else if (i == c) v = sd[c];
     inv[idx] = v;
   }
 }
@@ -113,7 +224,7 @@ void potrf_rec(hipStream_t s, int n, double *B, int ldb, int off, double *invdia
                double *work) {
   double *Bd = B + (size_t)off + (size_t)off * ldb;
   if (n <= NB) {
-    hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), NB * NB * sizeof(double), s, n,
+    hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), (NB * NB + NB) * sizeof(double), s, n,
                        Bd, ldb, invdiag + (size_t)(off / NB) * NB * NB, d_info, off);
     return;
   }
@@ -131,9 +242,9 @@ static void set_attrs() {
   static bool attr_set = false;
   if (attr_set) return;
   (void)hipFuncSetAttribute((const void *)potrf_diag_kernel<true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, NB * NB * sizeof(double));
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + NB) * sizeof(double));
   (void)hipFuncSetAttribute((const void *)potrf_diag_kernel<false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, NB * NB * sizeof(double));
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + NB) * sizeof(double));
   attr_set = true;
 }
 
@@ -148,7 +259,7 @@ void trtri_diag_blocks(hipStream_t s, int n, const double *L, int ldl, double *i
   set_attrs();
   if (n <= 0) return;
   hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(ceil_div(n, NB)), dim3(256),
-                     NB * NB * sizeof(double), s, n, const_cast<double *>(L), ldl, invdiag,
+                     (NB * NB + NB) * sizeof(double), s, n, const_cast<double *>(L), ldl, invdiag,
                      (int *)nullptr, 0);
 }
 
@@ -206,6 +317,20 @@ void trsm_llt(hipStream_t s, int n, int m, const double *L, int ldl, const doubl
   trsm_llt(s, n1, m, L, ldl, invdiag, X, ldx, work);
 }
 
+// X <- X L^-T where only the lower triangle of the (square, n x n) result is wanted: column
+// block 2 is then only needed on rows >= n1, which removes ~43% of the flops of a full solve.
+static void trsm_rlt_lower(hipStream_t s, int n, const double *L, int ldl, const double *invdiag,
+                           double *X, int ldx, double *work) {
+  if (n <= 0) return;
+  if (n <= NB) { trsm_rlt(s, n, n, L, ldl, invdiag, X, ldx, work); return; }
+  const int n1 = split(n), n2 = n - n1;
+  const double *L21 = L + n1, *L22 = L + (size_t)n1 + (size_t)n1 * ldl;
+  double *X21 = X + n1, *X22 = X + (size_t)n1 + (size_t)n1 * ldx;
+  trsm_rlt(s, n, n1, L, ldl, invdiag, X, ldx, work);                       // all rows of block column 1
+  gemm(s, false, true, n2, n2, n1, -1.0, X21, ldx, L21, ldl, 1.0, X22, ldx);  // rows >= n1 only
+  trsm_rlt_lower(s, n2, L22, ldl, invdiag + (size_t)(n1 / NB) * NB * NB, X22, ldx, work);
+}
+
 // A <- L^-1 A L^-T.  The lower triangle of A is the input (as PDSYGST 'L'); the result is
 // returned in full storage (both triangles), of which later stages reference the lower.
 // Two recursive triangular solves on the whole matrix: 2 N^3 MFMA flops, all in GEMMs
@@ -215,7 +340,7 @@ void sygst_lower(hipStream_t s, int n, double *A, int lda, const double *L, int 
   if (n <= 0) return;
   symmetrize_lower(s, n, A, lda);
   trsm_lln(s, n, n, L, ldl, invdiag, A, lda, work);
-  trsm_rlt(s, n, n, L, ldl, invdiag, A, lda, work);
+  trsm_rlt_lower(s, n, L, ldl, invdiag, A, lda, work);
 }
 
 }  // namespace ek
