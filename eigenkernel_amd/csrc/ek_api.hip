@@ -629,4 +629,120 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
   return info;
 }
 
+
+// ---- acceptance checks on the GPU: device-resident and host-array forms ----
+int ek_hip_residual_device(int problem, int n, int n_check, const double *dA, int lda, const double *dB,
+                           int ldb, const double *dw, const double *dZ, int ldz, double *a_norm,
+                           double *res_ave, double *res_max) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_check < 0 || n_check > n) return -3;
+  if (n > 0 && !dA) return -4;
+  if (problem == 1 && n > 0 && !dB) return -6;
+  int rc = ensure_init(); if (rc) return rc;
+  if (n == 0 || n_check == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  void *ws;
+  rc = workspace(verify_work_bytes(n, n_check) + 256, &ws); if (rc) return rc;
+  double *d_res = (double *)((char *)ws + verify_work_bytes(n, n_check));
+  residual_norms(s, n, n_check, dA, lda, problem ? dB : nullptr, ldb, dw, dZ, ldz, d_res, ws);
+  EK_HIP_CHECK(hipGetLastError());
+  double r[3];
+  EK_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  if (a_norm) *a_norm = r[2];
+  if (res_ave) *res_ave = r[0] / r[2] / (double)n_check;      /* verifier.f90:198 */
+  if (res_max) *res_max = r[1] / r[2];                        /* verifier.f90:199 */
+  return 0;
+}
+
+int ek_hip_orthogonality_device(int problem, int n, int index1, int index2, const double *dB, int ldb,
+                                const double *dZ, int ldz, double *orthogonality) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (index1 < 1 || index1 > n) return -3;
+  if (index2 < index1 || index2 > n) return -4;
+  if (problem == 1 && !dB) return -5;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  const int nc = index2 - index1 + 1;
+  void *ws;
+  rc = workspace(verify_work_bytes(n, nc) + 256, &ws); if (rc) return rc;
+  double *d_res = (double *)((char *)ws + verify_work_bytes(n, nc));
+  ek::orthogonality(s, n, index1 - 1, nc, problem ? dB : nullptr, ldb, dZ, ldz, d_res, ws);
+  EK_HIP_CHECK(hipGetLastError());
+  double r[3];
+  EK_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  if (orthogonality) *orthogonality = r[2];
+  return 0;
+}
+
+int ek_hip_ipratios_device(int problem, int n, int n_vec, const double *dB, int ldb, const double *dZ,
+                           int ldz, double *ipratios_host) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_vec < 0 || n_vec > n) return -3;
+  if (problem == 1 && n > 0 && !dB) return -4;
+  int rc = ensure_init(); if (rc) return rc;
+  if (n == 0 || n_vec == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  void *ws;
+  rc = workspace(verify_work_bytes(n, n_vec) + al((size_t)n * 8), &ws); if (rc) return rc;
+  double *d_ipr = (double *)((char *)ws + verify_work_bytes(n, n_vec));
+  ek::ipratios(s, n, n_vec, problem ? dB : nullptr, ldb, dZ, ldz, d_ipr, ws);
+  EK_HIP_CHECK(hipGetLastError());
+  EK_HIP_CHECK(hipMemcpyAsync(ipratios_host, d_ipr, (size_t)n_vec * 8, hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// Host-array form: what the Fortran host calls in place of eval_residual_norm (verifier.f90:207),
+// eval_orthogonality (:333) and get_ipratios (distribute_matrix.f90:18). what: 0 residual
+// (out[0..2] = A_norm, res_ave, res_max; uses n_check columns), 1 orthogonality (out[0]; columns
+// index1..index2, 1-based), 2 IPR (out[0..n_vec-1]).
+int ek_hip_check(int what, int problem, int n, int n_cols, int index1, int index2, const double *A_loc,
+                 const int desc_A[9], const double *B_loc, const int desc_B[9], const double *w,
+                 const double *Z_loc, const int desc_Z[9], double *out) {
+  if (what < 0 || what > 2) return -1;
+  if (problem != 0 && problem != 1) return -2;
+  if (n < 0) return -3;
+  if (n_cols < 0 || n_cols > n) return -4;
+  int rc;
+  if (what == 0) { if (!A_loc) return -7; rc = check_desc(desc_A, 8, n, n); if (rc) return rc; }
+  if (problem == 1) { if (!B_loc) return -9; rc = check_desc(desc_B, 10, n, n); if (rc) return rc; }
+  if (!Z_loc) return -12;
+  rc = check_desc(desc_Z, 13, n, n); if (rc) return rc;
+  if (!out) return -14;
+  rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
+  const size_t nn = (size_t)n * n * 8;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipStream_t s = g_ctx.stream;
+    EK_HIP_CHECK(hipMalloc((void **)&uZ, nn));
+    rc = h2d_matrix(n, n, Z_loc, desc_Z[8], uZ, n, s); if (rc) return rc;
+    if (what == 0) {
+      EK_HIP_CHECK(hipMalloc((void **)&uA, nn));
+      EK_HIP_CHECK(hipMalloc((void **)&uw, (size_t)n * 8));
+      rc = h2d_matrix(n, n, A_loc, desc_A[8], uA, n, s); if (rc) return rc;
+      EK_HIP_CHECK(hipMemcpyAsync(uw, w, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    }
+    if (problem == 1) {
+      EK_HIP_CHECK(hipMalloc((void **)&uB, nn));
+      rc = h2d_matrix(n, n, B_loc, desc_B[8], uB, n, s); if (rc) return rc;
+    }
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  if (what == 0) rc = ek_hip_residual_device(problem, n, n_cols, uA, n, uB, n, uw, uZ, n, &out[0], &out[1], &out[2]);
+  else if (what == 1) rc = ek_hip_orthogonality_device(problem, n, index1, index2, uB, n, uZ, n, &out[0]);
+  else rc = ek_hip_ipratios_device(problem, n, n_cols, uB, n, uZ, n, out);
+  (void)hipFree(uZ); if (uA) (void)hipFree(uA); if (uB) (void)hipFree(uB); if (uw) (void)hipFree(uw);
+  return rc;
+}
+
 }  // extern "C"

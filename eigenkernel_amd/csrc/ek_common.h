@@ -105,4 +105,13 @@ void build_explicit_v(hipStream_t s, int n, const double *A, int lda, double *V,
 // synthetic SPD generator of SURVEY.md 8(d) on the device
 void synth_matrix(hipStream_t s, int n, unsigned long long seed, double *M, int ldm);
 
+// ---------------------------------------------------------------- verifier / IPR (ek_verify.hip)
+size_t verify_work_bytes(int n, int ncols);
+void residual_norms(hipStream_t s, int n, int n_check, const double *A, int lda, const double *B, int ldb,
+                    const double *w, const double *V, int ldv, double *d_result, void *work);
+void orthogonality(hipStream_t s, int n, int c0, int nc, const double *B, int ldb, const double *V, int ldv,
+                   double *d_result, void *work);
+void ipratios(hipStream_t s, int n, int n_vec, const double *B, int ldb, const double *V, int ldv,
+              double *d_ipr, void *work);
+
 }  // namespace ek

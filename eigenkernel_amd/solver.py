@@ -73,6 +73,10 @@ def load_library(path=None):
         "ek_hip_memcpy_d2h": (c_int, [vp, vp, c_ull]),
         "ek_hip_synchronize": (c_int, []),
         "ek_hip_synth_matrix_device": (c_int, [c_int, c_ull, vp, c_int]),
+        "ek_hip_residual_device": (c_int, [c_int, c_int, c_int, vp, c_int, vp, c_int, vp, vp, c_int, _dp, _dp, _dp]),
+        "ek_hip_orthogonality_device": (c_int, [c_int, c_int, c_int, c_int, vp, c_int, vp, c_int, _dp]),
+        "ek_hip_ipratios_device": (c_int, [c_int, c_int, c_int, vp, c_int, vp, c_int, _dp]),
+        "ek_hip_check": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _dp, _ip, _dp, _ip, _dp, _dp, _ip, _dp]),
         "ek_hip_profile_symv": (c_int, [c_int]),
         "ek_hip_debug_sytrd": (c_int, [c_int, c_int, c_int, _dp]),
         "ek_hip_profile_symv_get": (c_int, [_dp, ctypes.POINTER(ctypes.c_longlong), _dp]),
@@ -97,7 +101,49 @@ EXPORTED_SYMBOLS = (
     "ek_hip_ormtr", "ek_hip_trtrs", "ek_hip_dgemm", "ek_hip_malloc", "ek_hip_free",
     "ek_hip_memcpy_h2d", "ek_hip_memcpy_d2h", "ek_hip_synchronize", "ek_hip_synth_matrix_device",
     "ek_hip_profile_symv", "ek_hip_profile_symv_get", "ek_hip_debug_sytrd",
+    "ek_hip_residual_device", "ek_hip_orthogonality_device", "ek_hip_ipratios_device", "ek_hip_check",
 )
+
+
+def _check(what, A, B, w, Z, n_cols, index1=1, index2=1):
+    lib = load_library()
+    Z = _farr(Z)
+    n = Z.shape[0]
+    A_ = _farr(A) if A is not None else None
+    B_ = _farr(B) if B is not None else None
+    out = np.zeros(max(3, n))
+    wv = np.ascontiguousarray(np.asarray(w, dtype=np.float64)) if w is not None else np.zeros(max(n, 1))
+    info = lib.ek_hip_check(what, 1 if B is not None else 0, n, n_cols, index1, index2,
+                            _P(A_) if A_ is not None else None, _I(_desc_for(A_)) if A_ is not None else None,
+                            _P(B_) if B_ is not None else None, _I(_desc_for(B_)) if B_ is not None else None,
+                            _P(wv), _P(Z), _I(_desc_for(Z)), _P(out))
+    if info:
+        raise RuntimeError("ek_hip_check(%d) info=%d" % (what, info))
+    return out
+
+
+def eval_residual_norm(A, values, V, B=None, n_check=None):
+    """verifier.f90:207 on the GPU. Returns (A_norm, res_norm_ave, res_norm_max)."""
+    n_check = V.shape[1] if n_check is None else n_check
+    Zf = np.zeros((V.shape[0], V.shape[0]), order="F"); Zf[:, :V.shape[1]] = V
+    wv = np.zeros(V.shape[0]); wv[:len(values)] = values
+    out = _check(0, A, B, wv, Zf, n_check)
+    return out[0], out[1], out[2]
+
+
+def eval_orthogonality(V, B=None, index1=1, index2=None):
+    """verifier.f90:333 on the GPU."""
+    index2 = V.shape[1] if index2 is None else index2
+    Zf = np.zeros((V.shape[0], V.shape[0]), order="F"); Zf[:, :V.shape[1]] = V
+    return _check(1, None, B, None, Zf, 0, index1, index2)[0]
+
+
+def get_ipratios(V, S=None, n_vec=None):
+    """distribute_matrix.f90:18 on the GPU."""
+    n_vec = V.shape[1] if n_vec is None else n_vec
+    Zf = np.zeros((V.shape[0], V.shape[0]), order="F"); Zf[:, :V.shape[1]] = V
+    return _check(2, None, S, None, Zf, n_vec)[:n_vec].copy()
+
 
 
 def _P(a):

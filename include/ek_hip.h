@@ -116,6 +116,27 @@ int ek_hip_synchronize(void);
  * (seed 1 = A, seed 2 = B), so the large bench configurations need no file or PCIe traffic. */
 int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int ldm);
 
+/* Acceptance checks and IPR on the GPU, with the reference's
+ * normalisations.  A and B are the ORIGINAL matrices (the reference rebuilds them from the
+ * triplets for the check, verifier.f90:122-131); only their lower triangles are referenced,
+ * as PDSYMM('L','L') does.
+ *   residual      verifier.f90:75-204   A_norm = ||A||_F, res_ave = sum_j||A v_j - l_j B v_j||/A_norm/n_check,
+ *                                       res_max = max_j ||.|| / A_norm   (first n_check columns)
+ *   orthogonality verifier.f90:233-330  ||D^-1/2 (V^T B V) D^-1/2 - diag||_F over columns index1..index2 (1-based)
+ *   ipratios      distribute_matrix.f90:18-78  sum_i v_ij^4 / (sum_i v_ij (S v)_ij)^2, j < n_vec (host output) */
+int ek_hip_residual_device(int problem, int n, int n_check, const double *dA, int lda,
+                           const double *dB, int ldb, const double *dw, const double *dZ, int ldz,
+                           double *a_norm, double *res_ave, double *res_max);
+int ek_hip_orthogonality_device(int problem, int n, int index1, int index2, const double *dB, int ldb,
+                                const double *dZ, int ldz, double *orthogonality);
+int ek_hip_ipratios_device(int problem, int n, int n_vec, const double *dB, int ldb,
+                           const double *dZ, int ldz, double *ipratios_host);
+/* Host-array form for the Fortran host: what = 0 residual (out = A_norm, res_ave, res_max; n_cols =
+ * n_check), 1 orthogonality (out[0]; index1..index2), 2 IPR (out[0..n_cols-1]). */
+int ek_hip_check(int what, int problem, int n, int n_cols, int index1, int index2,
+                 const double *A_loc, const int desc_A[9], const double *B_loc, const int desc_B[9],
+                 const double *w, const double *Z_loc, const int desc_Z[9], double *out);
+
 /* Instrumentation for the roofline line of bench.py: when enabled, every launch of the
  * HBM-bound symv kernel of the tridiagonalisation is bracketed by HIP events on its own
  * stream.  _get returns the accumulated device seconds, the number of launches and the

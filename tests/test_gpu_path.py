@@ -198,3 +198,40 @@ def test_hip_vs_scalapack_goldens(hip, oracle, golden_dir, name, n, gep):
     B = oracle.synth_matrix(n, 2) if gep else None
     ep, _ = hip.eigen_solver("general_hip" if gep else "hip", A, B)
     assert np.abs(ep.values - w_ref).max() <= n * EPS * np.abs(w_ref).max()
+
+
+@pytest.mark.parametrize("n,gep", [(30, True), (200, True), (333, False)])
+def test_gpu_verifier_and_ipr_match_host_mirror(hip, oracle, n, gep):
+    """residual / orthogonality / IPR computed on the GPU reproduce
+    the reference's normalisations (host mirror = eigenkernel_amd/verifier.py)."""
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2) if gep else None
+    w, Z, info, _ = oracle.solve(A, B)
+    # make the check non-trivial: perturb one vector
+    Zp = Z.copy(); Zp[:, 3] += 1e-6 * Z[:, 5]
+    a_h, ave_h, mx_h = eval_residual_norm(A, w, Zp, B)
+    a_g, ave_g, mx_g = hip.eval_residual_norm(A, w, Zp, B)
+    assert abs(a_g - a_h) <= 1e-13 * a_h
+    assert abs(ave_g - ave_h) <= 1e-10 * ave_h and abs(mx_g - mx_h) <= 1e-10 * mx_h
+    o_h = eval_orthogonality(Zp, B)
+    o_g = hip.eval_orthogonality(Zp, B)
+    assert abs(o_g - o_h) <= 1e-9 * o_h
+    o_h2 = eval_orthogonality(Zp, B, 2, 20)
+    o_g2 = hip.eval_orthogonality(Zp, B, 2, 20)
+    assert abs(o_g2 - o_h2) <= 1e-9 * o_h2
+    i_h = get_ipratios(Zp, B)
+    i_g = hip.get_ipratios(Zp, B)
+    assert np.abs(i_g - i_h).max() <= 1e-12 * np.abs(i_h).max()
+    # partial check (n_check < n), as `-c <n>` does
+    a2, ave2, mx2 = hip.eval_residual_norm(A, w, Zp, B, n_check=7)
+    _, ave2h, mx2h = eval_residual_norm(A, w[:7], Zp[:, :7], B)
+    assert abs(ave2 - ave2h) <= 1e-10 * ave2h and abs(mx2 - mx2h) <= 1e-10 * mx2h
+
+
+def test_gpu_ipr_matches_reference_golden(hip, golden_dir):
+    A = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_A.mtx"))
+    B = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_B.mtx"))
+    ipr = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ipr.txt"))[:, 1]
+    ep, _ = hip.eigen_solver("general_hip", A, B)
+    got = hip.get_ipratios(ep.Vectors, B.to_dense())
+    assert np.abs(got - ipr).max() <= 1e-6
