@@ -235,3 +235,44 @@ def test_gpu_ipr_matches_reference_golden(hip, golden_dir):
     ep, _ = hip.eigen_solver("general_hip", A, B)
     got = hip.get_ipratios(ep.Vectors, B.to_dense())
     assert np.abs(got - ipr).max() <= 1e-6
+
+
+def test_fortran_host_end_to_end(tmp_path, golden_dir):
+    """The ISO_C_BINDING boundary for real: the flang-built host (host/eigenkernel_hip_app.f90,
+    same CLI / file contract as the reference: SURVEY.md App. C) solves the shipped BNZ30 pair
+    through libek_hip.so and reproduces the reference's golden eigenvalue and IPR files."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "eigenkernel_hip_app")
+    if not os.path.exists(exe):
+        flang = "/opt/rocm/lib/llvm/bin/flang"
+        assert os.path.exists(flang), "flang missing: cannot build the Fortran host"
+        subprocess.check_call(["make", "-C", os.path.join(root, "host")])
+    out = subprocess.run([exe, "-s", "general_hip", "-c", "-1", "-t", "1,30",
+                          os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_A.mtx"),
+                          os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_B.mtx")],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    ev = np.loadtxt(tmp_path / "eigenvalues.dat")
+    gold = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ev.txt"))
+    assert ev.shape == gold.shape and np.array_equal(ev[:, 0], gold[:, 0])
+    assert np.abs(ev[:, 1] - gold[:, 1]).max() <= 1e-14
+    # the file format itself is the reference's: (I8, " ", E26.16e3)
+    first = open(tmp_path / "eigenvalues.dat").readline().rstrip("\n")
+    gfirst = open(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ev.txt")).readline().rstrip("\n")
+    assert len(first) == len(gfirst) and first[:9] == gfirst[:9] and first[-5:] == gfirst[-5:]
+    ipr = np.loadtxt(tmp_path / "ipratios.dat")[:, 1]
+    gipr = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ipr.txt"))[:, 1]
+    assert np.abs(ipr - gipr).max() <= 1e-6
+    txt = out.stdout
+    res_max = float([l for l in txt.splitlines() if l.startswith("residual norm (max):")][0].split(":")[1])
+    orth = float([l for l in txt.splitlines() if l.startswith("orthogonality criterion:")][0].split(":")[1])
+    assert res_max <= 1e-14 and orth <= 1e-11
+    log = json.load(open(tmp_path / "log.json"))
+    assert set(log) == {"setting", "events"} and log["setting"]["dimension"] == 30
+    names = {e["name"] for e in log["events"]}
+    assert {"reduce_generalized:pdpotrf", "eigen_solver_scalapack_all:pdsytrd", "recovery_generalized"} <= names
+    # error contract: unknown solver -> "[Error] ..." on stderr, non-zero exit (processes.f90:133-138)
+    bad = subprocess.run([exe, "-s", "general_elpa1", "a.mtx", "b.mtx"], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and bad.stderr.startswith("[Error]")
