@@ -276,3 +276,39 @@ def test_fortran_host_end_to_end(tmp_path, golden_dir):
     # error contract: unknown solver -> "[Error] ..." on stderr, non-zero exit (processes.f90:133-138)
     bad = subprocess.run([exe, "-s", "general_elpa1", "a.mtx", "b.mtx"], cwd=tmp_path, capture_output=True, text=True)
     assert bad.returncode != 0 and bad.stderr.startswith("[Error]")
+
+
+@pytest.mark.parametrize("n,gep", [(2048, True), (4096, False)])
+def test_large_sizes_through_invariants(hip, n, gep):
+    """Sizes the CPU oracle cannot reach in seconds: parity through size-independent
+    properties evaluated on the GPU (residual, B-orthogonality, ordering, trace identities)."""
+    import ctypes
+    lib = hip.load_library()
+    nn = n * n * 8
+    ptrs = [ctypes.c_void_p() for _ in range(6)]
+    for p, sz in zip(ptrs, (nn, nn, nn, n * 8, nn, nn)):
+        assert lib.ek_hip_malloc(ctypes.byref(p), sz) == 0
+    dA, dB, dZ, dw, dA0, dB0 = ptrs
+    for dst in (dA, dA0):
+        assert lib.ek_hip_synth_matrix_device(n, 1, dst, n) == 0
+    for dst in (dB, dB0):
+        assert lib.ek_hip_synth_matrix_device(n, 2, dst, n) == 0
+    info = lib.ek_hip_solve_device(1 if gep else 0, n, n, dA, n, dB if gep else None, n, dw, dZ, n, None, 0)
+    assert info == 0
+    an, ave, mx, orth = (ctypes.c_double(0) for _ in range(4))
+    assert lib.ek_hip_residual_device(1 if gep else 0, n, n, dA0, n, dB0 if gep else None, n, dw, dZ, n,
+                                      ctypes.byref(an), ctypes.byref(ave), ctypes.byref(mx)) == 0
+    assert lib.ek_hip_orthogonality_device(1 if gep else 0, n, 1, n, dB0 if gep else None, n, dZ, n,
+                                           ctypes.byref(orth)) == 0
+    assert mx.value <= 1e-14 * max(1.0, np.sqrt(n / 1024.0)), mx.value
+    assert orth.value <= 1e-11, orth.value
+    w = np.zeros(n)
+    lib.ek_hip_memcpy_d2h(w.ctypes.data, dw, n * 8)
+    assert np.all(np.diff(w) >= 0)
+    if not gep:   # trace(A) = sum of eigenvalues; the generator's diagonal is 2 + u/sqrt(n)
+        hA = np.zeros((n, n), order="F")
+        lib.ek_hip_memcpy_d2h(hA.ctypes.data, dA0, nn)
+        assert abs(w.sum() - np.trace(hA)) <= 64 * n * EPS * np.abs(w).sum()
+        assert abs((w ** 2).sum() - (hA ** 2).sum()) <= 64 * n * EPS * (w ** 2).sum()
+    for p in ptrs:
+        lib.ek_hip_free(p)
