@@ -8,7 +8,7 @@ configs[2], the configuration the metric is quoted on), inputs resident in HBM w
 timed region starts (they are regenerated on the device before every step, outside the
 timed region, because the solve overwrites A and B as the reference does).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 16384] [--problem gep|sep]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--order 16384] [--problem gep|sep]
 
 For N > 1 the driver launches one rank per GPU with torch.distributed.run; this round every
 rank solves its own problem (replicas; the 2-D block-cyclic multi-GPU decomposition is the
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--order", dest="n", type=int, default=16384, help="matrix order N")
     ap.add_argument("--problem", choices=["gep", "sep"], default="gep")
     ap.add_argument("--cpu-sample-n", type=int, default=1536,
                     help="order of the CPU-oracle sample (scalar C port, 1 core)")
@@ -121,14 +121,14 @@ def main():
     n, problem = args.n, (1 if args.problem == "gep" else 0)
 
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    dist = None
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:   # launched by torch.distributed.run
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world
 
     from eigenkernel_amd import solver
     lib = solver.load_library()

@@ -199,13 +199,20 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
       {
         double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
         int S = p.S0p + q;
-        for (; S + 12 <= rb; S += 16) {
-          y0 += p.b.ypart[(size_t)S * p.npad + r];
-          y1 += p.b.ypart[(size_t)(S + 4) * p.npad + r];
-          y2 += p.b.ypart[(size_t)(S + 8) * p.npad + r];
-          y3 += p.b.ypart[(size_t)(S + 12) * p.npad + r];
+        const double *yp = p.b.ypart + r;
+        const size_t st4 = (size_t)4 * p.npad;
+        for (; S + 28 <= rb; S += 32) {          // 8 loads in flight per thread
+          const double *b0 = yp + (size_t)S * p.npad;
+          const double u0 = b0[0], u1 = b0[st4], u2 = b0[2 * st4], u3 = b0[3 * st4];
+          const double u4 = b0[4 * st4], u5 = b0[5 * st4], u6 = b0[6 * st4], u7 = b0[7 * st4];
+          y0 += u0; y1 += u1; y2 += u2; y3 += u3; y0 += u4; y1 += u5; y2 += u6; y3 += u7;
         }
-        for (; S <= rb; S += 4) y0 += p.b.ypart[(size_t)S * p.npad + r];
+        for (; S + 12 <= rb; S += 16) {
+          const double *b0 = yp + (size_t)S * p.npad;
+          const double u0 = b0[0], u1 = b0[st4], u2 = b0[2 * st4], u3 = b0[3 * st4];
+          y0 += u0; y1 += u1; y2 += u2; y3 += u3;
+        }
+        for (; S <= rb; S += 4) y0 += yp[(size_t)S * p.npad];
         const int np = num_pieces(rb - p.S0p, T, p.qp);
         for (int pc = q; pc < np; pc += 4) y1 += p.b.tpart[((size_t)rb * p.NRB + pc) * TS + (r % TS)];
         y = (y0 + y1) + (y2 + y3);
@@ -213,14 +220,19 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
       {
         double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
         int k = q;
-        for (; k + 4 < ip; k += 8) {
-          const double v0 = Pv[(size_t)r + (size_t)k * ldp], w0 = Pw[(size_t)r + (size_t)k * ldp];
-          const double v1 = Pv[(size_t)r + (size_t)(k + 4) * ldp], w1 = Pw[(size_t)r + (size_t)(k + 4) * ldp];
-          a0 += v0 * s_pw[k] + w0 * s_pv[k];         b0 += v0 * s_Wj[k] + w0 * s_Vj[k];
-          a1 += v1 * s_pw[k + 4] + w1 * s_pv[k + 4]; b1 += v1 * s_Wj[k + 4] + w1 * s_Vj[k + 4];
+        const double *pvr = Pv + r, *pwr = Pw + r;
+        for (; k + 12 < ip; k += 16) {           // 8 loads in flight per thread
+          const double v0 = pvr[(size_t)k * ldp], w0 = pwr[(size_t)k * ldp];
+          const double v1 = pvr[(size_t)(k + 4) * ldp], w1 = pwr[(size_t)(k + 4) * ldp];
+          const double v2 = pvr[(size_t)(k + 8) * ldp], w2 = pwr[(size_t)(k + 8) * ldp];
+          const double v3 = pvr[(size_t)(k + 12) * ldp], w3 = pwr[(size_t)(k + 12) * ldp];
+          a0 += v0 * s_pw[k] + w0 * s_pv[k];             b0 += v0 * s_Wj[k] + w0 * s_Vj[k];
+          a1 += v1 * s_pw[k + 4] + w1 * s_pv[k + 4];     b1 += v1 * s_Wj[k + 4] + w1 * s_Vj[k + 4];
+          a0 += v2 * s_pw[k + 8] + w2 * s_pv[k + 8];     b0 += v2 * s_Wj[k + 8] + w2 * s_Vj[k + 8];
+          a1 += v3 * s_pw[k + 12] + w3 * s_pv[k + 12];   b1 += v3 * s_Wj[k + 12] + w3 * s_Vj[k + 12];
         }
         for (; k < ip; k += 4) {
-          const double v0 = Pv[(size_t)r + (size_t)k * ldp], w0 = Pw[(size_t)r + (size_t)k * ldp];
+          const double v0 = pvr[(size_t)k * ldp], w0 = pwr[(size_t)k * ldp];
           a0 += v0 * s_pw[k] + w0 * s_pv[k]; b0 += v0 * s_Wj[k] + w0 * s_Vj[k];
         }
         accA = a0 + a1; aB = b0 + b1;
@@ -451,16 +463,20 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
         for (int c = 0; c < 16; ++c) st[c * 65 + lane] = tc[round * 16 + c];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
-        if (lane < 16) {
+        {
+          // all 64 lanes: 4 lanes per column, 16 lane-partials each, then two butterfly steps
+          const int cidx = lane >> 2, part = lane & 3;
+          const double *src = st + cidx * 65 + part * 16;
           double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-          for (int l = 0; l < 64; l += 4) {
-            a0 += st[lane * 65 + l]; a1 += st[lane * 65 + l + 1];
-            a2 += st[lane * 65 + l + 2]; a3 += st[lane * 65 + l + 3];
+          for (int l = 0; l < 16; l += 4) { a0 += src[l]; a1 += src[l + 1]; a2 += src[l + 2]; a3 += src[l + 3]; }
+          double tot = (a0 + a1) + (a2 + a3);
+          tot += __shfl_xor(tot, 1, 64);
+          tot += __shfl_xor(tot, 2, 64);
+          if (part == 0) {
+            tp[round * 16 + cidx] = tot;
+            vav += svc[round * 16 + cidx] * tot;
           }
-          const double tot = (a0 + a1) + (a2 + a3);
-          tp[round * 16 + lane] = tot;
-          vav += svc[round * 16 + lane] * tot;
         }
         __builtin_amdgcn_wave_barrier();
       }
