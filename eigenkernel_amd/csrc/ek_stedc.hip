@@ -179,7 +179,11 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
   red[t] = zm; __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmax(red[t], red[t + o]); __syncthreads(); }
   zm = red[0];
-  if (t != 0) return;
+  // the scan itself is sequential (thread 0); the other threads stage the sorted poles,
+  // weights and origins through LDS in chunks so that thread 0 never waits on global memory
+  constexpr int CHUNK = 1024;
+  __shared__ double c_d[CHUNK], c_z[CHUNK];
+  __shared__ int c_p[CHUNK];
   const double eps = 1.1102230246251565e-16;
   const double rho = fabs(2.0 * b.e[off + mg.n1 - 1]);
   const double tol = 8.0 * eps * fmax(dm, zm);
@@ -192,17 +196,26 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
   double *rotc = b.rotc + off, *rots = b.rots + off, *dl = b.dl + off, *zl = b.zl + off;
   double *dout = b.d + off;
   int k = 0, ndf = 0, nrot = 0;
-  if (rho * zm <= tol) {
-    for (int i = 0; i < n; ++i) { wcol[i] = n - 1 - ndf; dout[n - 1 - ndf] = ds[i]; ++ndf; }
-  } else {
-    int pj = -1, tpj = 0;
-    double dpj = 0.0, zpj = 0.0;
-    for (int i = 0; i < n; ++i) {
-      const double zi = zs[i], di = ds[i];
+  const bool all_deflate = (rho * zm <= tol);
+  int pj = -1, tpj = 0;
+  double dpj = 0.0, zpj = 0.0;
+  for (int c0 = 0; c0 < n; c0 += CHUNK) {
+    const int cn = (n - c0 < CHUNK) ? n - c0 : CHUNK;
+    __syncthreads();
+    for (int i = t; i < cn; i += 256) { c_d[i] = ds[c0 + i]; c_z[i] = zs[c0 + i]; c_p[i] = perm[c0 + i]; }
+    __syncthreads();
+    if (t != 0) continue;
+    if (all_deflate) {
+      for (int ii = 0; ii < cn; ++ii) { wcol[c0 + ii] = n - 1 - ndf; dout[n - 1 - ndf] = c_d[ii]; ++ndf; }
+      continue;
+    }
+    for (int ii = 0; ii < cn; ++ii) {
+      const int i = c0 + ii;
+      const double zi = c_z[ii], di = c_d[ii];
+      const int ti = (c_p[ii] < mg.n1) ? 1 : 3;
       if (rho * fabs(zi) <= tol) { wcol[i] = n - 1 - ndf; dout[n - 1 - ndf] = di; ++ndf; continue; }
-      if (pj < 0) { pj = i; dpj = di; zpj = zi; tpj = (perm[i] < mg.n1) ? 1 : 3; continue; }
+      if (pj < 0) { pj = i; dpj = di; zpj = zi; tpj = ti; continue; }
       double s = zpj, c = zi;
-      const int ti = (perm[i] < mg.n1) ? 1 : 3;
       const double tau = hypot(c, s), tt = di - dpj;
       c /= tau; s = -s / tau;
       if (fabs(tt * c * s) <= tol) {
@@ -217,8 +230,9 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
         pj = i; dpj = di; zpj = zi; tpj = ti;
       }
     }
-    if (pj >= 0) { spos[k] = pj; grp[k] = tpj; dl[k] = dpj; zl[k] = zpj; ++k; }
   }
+  if (t != 0) return;
+  if (pj >= 0) { spos[k] = pj; grp[k] = tpj; dl[k] = dpj; zl[k] = zpj; ++k; }
   // group the survivors' W columns by type: [top-only | dense | bottom-only]
   int cnt[4] = {0, 0, 0, 0};
   for (int a = 0; a < k; ++a) ++cnt[grp[a]];
@@ -270,8 +284,17 @@ __global__ void dc_rotate_kernel(int mbeg, DcBufs b, double *__restrict__ W, int
 // ------------------------------------------------------------------ merge step 4: secular equation (DLAED4)
 // root i of 1 + rho * sum_j z_j^2 / (d_j - lambda) = 0 in shifted form lambda = d_K + tau,
 // K the nearer pole, so that d_j - lambda_i = (d_j - d_K) - tau keeps full relative accuracy.
-__device__ void secular_root(int k, int i, const double *__restrict__ d, const double *__restrict__ z,
-                             double rho, int *Kout, double *tauout) {
+constexpr int SP = 4;   // lanes that share one root (they split the sum over the poles)
+
+__device__ __forceinline__ double group_sum(double v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
+// The SP lanes of a group run the same control flow on the same (reduced) values.
+__device__ void secular_root(int k, int i, int sub, const double *__restrict__ d,
+                             const double *__restrict__ z, double rho, int *Kout, double *tauout) {
   if (k == 1) { *Kout = 0; *tauout = rho * z[0] * z[0]; return; }
   const double eps = 1.1102230246251565e-16;
   int K;
@@ -279,35 +302,39 @@ __device__ void secular_root(int k, int i, const double *__restrict__ d, const d
   if (i < k - 1) {
     const double di = d[i];
     const double mid = 0.5 * (d[i + 1] - di);
-    double f = 1.0;
-    for (int j = 0; j < k; ++j) f += rho * z[j] * z[j] / ((d[j] - di) - mid);
+    double f = 0.0;
+    for (int j = sub; j < k; j += SP) f += z[j] * z[j] / ((d[j] - di) - mid);
+    f = 1.0 + rho * group_sum(f);
     if (f > 0.0) { K = i; lo = 0.0; hi = mid; }
     else { K = i + 1; lo = -mid; hi = 0.0; }
   } else {
     double zn = 0.0;
-    for (int j = 0; j < k; ++j) zn += z[j] * z[j];
+    for (int j = sub; j < k; j += SP) zn += z[j] * z[j];
+    zn = group_sum(zn);
     K = k - 1; lo = 0.0; hi = rho * zn;
   }
   const double dK = d[K];
   double tau = 0.5 * (lo + hi);
   if (i == k - 1) {
-    double f = 1.0;
-    for (int j = 0; j < k; ++j) f += rho * z[j] * z[j] / ((d[j] - dK) - tau);
+    double f = 0.0;
+    for (int j = sub; j < k; j += SP) f += z[j] * z[j] / ((d[j] - dK) - tau);
+    f = 1.0 + rho * group_sum(f);
     if (f > 0.0) hi = tau; else lo = tau;
     tau = 0.5 * (lo + hi);
   }
   for (int it = 0; it < 100; ++it) {
     double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, err = 0.0;
-    for (int j = 0; j <= i; ++j) {
+    for (int j = sub; j <= i; j += SP) {
       const double t = z[j] / ((d[j] - dK) - tau);
-      psi += z[j] * t; dpsi += t * t; err += psi;
+      psi += z[j] * t; dpsi += t * t; err += fabs(psi);
     }
-    err = fabs(err);
-    for (int j = k - 1; j > i; --j) {
+    for (int j = i + 1 + sub; j < k; j += SP) {
       const double t = z[j] / ((d[j] - dK) - tau);
-      phi += z[j] * t; dphi += t * t; err += phi;
+      phi += z[j] * t; dphi += t * t; err += fabs(phi);
     }
-    psi *= rho; dpsi *= rho; phi *= rho; dphi *= rho; err *= rho;
+    psi = rho * group_sum(psi); dpsi = rho * group_sum(dpsi);
+    phi = rho * group_sum(phi); dphi = rho * group_sum(dphi);
+    err = rho * group_sum(err);
     const double f = 1.0 + psi + phi;
     err = 8.0 * (phi - psi) + err + 2.0 + fabs(tau) * (dpsi + dphi);
     if (fabs(f) <= eps * err) break;
@@ -347,14 +374,17 @@ __device__ void secular_root(int k, int i, const double *__restrict__ d, const d
 __global__ void dc_secular_kernel(int mbeg, DcBufs b) {
   const int mi = mbeg + blockIdx.y;
   const Merge mg = b.merges[mi];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid / SP, sub = gid % SP;
   const int k = b.k[mi];
   if (i >= k) return;
   int K; double tau;
-  secular_root(k, i, b.dl + mg.off, b.zl + mg.off, b.rho[mi], &K, &tau);
-  b.korig[mg.off + i] = K;
-  b.tauv[mg.off + i] = tau;
-  b.d[mg.off + i] = b.dl[mg.off + K] + tau;    // new eigenvalue, W column i
+  secular_root(k, i, sub, b.dl + mg.off, b.zl + mg.off, b.rho[mi], &K, &tau);
+  if (sub == 0) {
+    b.korig[mg.off + i] = K;
+    b.tauv[mg.off + i] = tau;
+    b.d[mg.off + i] = b.dl[mg.off + K] + tau;    // new eigenvalue, W column i
+  }
 }
 
 // Loewner / Gu-Eisenstat weights: zhat_j = sign(z_j) sqrt(| prod_i (d_j - lam_i) / prod_{i!=j} (d_j - d_i) |)
@@ -531,7 +561,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     const int gy = std::min(maxn, std::max(1, 4096 / std::max(1, gx * cnt)));
     hipLaunchKernelGGL(dc_permute_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, Q, ldq, W, ldz);
     hipLaunchKernelGGL(dc_rotate_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, W, ldz);
-    hipLaunchKernelGGL(dc_secular_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b);
+    hipLaunchKernelGGL(dc_secular_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
     hipLaunchKernelGGL(dc_zhat_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b);
     hipLaunchKernelGGL(dc_vectors_kernel, dim3(maxn, cnt), dim3(256), 0, s, mbeg, b, S, lds);
     // two GEMMs per merge (top rows x [top-only|dense] columns, bottom rows x [dense|bottom-only]
