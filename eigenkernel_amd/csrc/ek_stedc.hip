@@ -215,11 +215,13 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
       const int ti = (c_p[ii] < mg.n1) ? 1 : 3;
       if (rho * fabs(zi) <= tol) { wcol[i] = n - 1 - ndf; dout[n - 1 - ndf] = di; ++ndf; continue; }
       if (pj < 0) { pj = i; dpj = di; zpj = zi; tpj = ti; continue; }
-      double s = zpj, c = zi;
-      const double tau = hypot(c, s), tt = di - dpj;
-      c /= tau; s = -s / tau;
-      if (fabs(tt * c * s) <= tol) {
+      // DLAED2's test |t c s| <= tol with c = z_i/tau, s = -z_pj/tau, tau^2 = z_i^2 + z_pj^2,
+      // evaluated division- and sqrt-free on the (serial) common path
+      const double tau2 = zi * zi + zpj * zpj, tt = di - dpj;
+      if (fabs(tt * zi * zpj) <= tol * tau2) {
         // deflate pj: rotate columns (pj, i); the combined weight moves to i
+        const double tau = sqrt(tau2);
+        const double c = zi / tau, s = -zpj / tau;
         rotp[nrot] = pj; rotn[nrot] = i; rotc[nrot] = c; rots[nrot] = s; ++nrot;
         const double dnew_p = dpj * c * c + di * s * s;
         const double dnew_i = dpj * s * s + di * c * c;
