@@ -1,12 +1,15 @@
 // ek_ormtr.hip -- back-transformation Z <- Q Z, Q = H(0) H(1) ... H(n-2).
 // Replaces PDORMTR('L','L','N') at solver_scalapack_all.f90:115 (1x1 grid).
 //
-// Compact-WY on the matrix cores: reflectors are grouped KB = 128 at a time,
+// Compact-WY on the matrix cores: reflectors are grouped KB = 512 at a time,
 // Q_b = I - V_b T_b V_b^T, and each group costs three GEMMs
 //     W1 = V_b^T Z      W2 = T_b W1      Z -= V_b W2
 // applied from the last group to the first.  All Gram matrices V_b^T V_b are formed by ONE
-// batched GEMM and all triangular factors T_b by ONE batched launch (a 128x128 LDS image
-// per workgroup) before the sweep, so the sweep itself is nothing but large GEMMs.
+// batched GEMM; the triangular factors T_b = [T11, -T11 G12 T22; 0, T22] by ONE batched
+// launch for the 128x128 diagonal parts (an LDS image per workgroup) plus two batched 128^3
+// GEMMs for the coupling, all before the sweep, so the sweep itself is nothing but large
+// GEMMs (wide blocks cut the C traffic per flop of the rank-k update and give the V^T Z product
+// 512 output tiles = two resident workgroups per CU).
 // V is the explicit unit-lower-trapezoidal reflector matrix the tridiagonalisation writes
 // (zeros above the unit diagonal), so no masking is needed inside the GEMMs.
 #include "ek_common.h"
@@ -14,12 +17,12 @@
 namespace ek {
 namespace {
 
-constexpr int KB = 256;    // reflectors per compact-WY block
-constexpr int SB = 128;    // sub-block factored by one workgroup (two per block)
+constexpr int KB = 512;    // reflectors per compact-WY block
+constexpr int SB = 128;    // sub-block factored by one workgroup (KB/SB per block)
 
 // T of one 128-wide sub-block from its Gram matrix and tau (forward, columnwise: DLARFT):
 //   T(i,i) = tau_i,  T(0:i, i) = -tau_i * T(0:i,0:i) * G(0:i, i)
-// Sub-block sb lives on the diagonal of block sb/2: offset (sb%2)*128 in both G and T (ld = KB).
+// Sub-block sb lives on the diagonal of block sb/(KB/SB): offset (sb%(KB/SB))*128 in G and T (ld = KB).
 __global__ __launch_bounds__(128) void larft_kernel(int nrefl, const double *__restrict__ G,
                                                     const double *__restrict__ tau,
                                                     double *__restrict__ T) {
@@ -29,7 +32,8 @@ __global__ __launch_bounds__(128) void larft_kernel(int nrefl, const double *__r
   const int c0 = sb * SB;
   const int kb = (nrefl - c0 < SB) ? nrefl - c0 : SB;
   if (kb <= 0) return;
-  const size_t off = (size_t)(sb / 2) * KB * KB + (size_t)(sb % 2) * SB * (KB + 1);
+  constexpr int NSUB = KB / SB;
+  const size_t off = (size_t)(sb / NSUB) * KB * KB + (size_t)(sb % NSUB) * SB * (KB + 1);
   const double *Gb = G + off;
   double *Tb = T + off;
   for (int idx = t; idx < SB * SB; idx += 128) sT[idx] = 0.0;
@@ -75,7 +79,7 @@ void build_explicit_v(hipStream_t s, int n, const double *A, int lda, double *V,
 
 size_t ormtr_work_bytes(int n, int ncols) {
   const int nblk = ceil_div(n > 1 ? n - 1 : 1, KB);
-  return 2 * al256((size_t)nblk * KB * KB * 8) + al256((size_t)nblk * SB * SB * 8) +
+  return 2 * al256((size_t)nblk * KB * KB * 8) + al256((size_t)nblk * (KB / 2) * (KB / 2) * 8) +
          2 * al256((size_t)KB * (ncols > 0 ? ncols : 1) * 8);
 }
 
@@ -93,12 +97,15 @@ void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
   char *w = (char *)work;
   double *G = (double *)w; w += al256((size_t)nblk * KB * KB * 8);
   double *T = (double *)w; w += al256((size_t)nblk * KB * KB * 8);
-  double *Tmp = (double *)w; w += al256((size_t)nblk * SB * SB * 8);
+  double *Tmp = (double *)w; w += al256((size_t)nblk * (KB / 2) * (KB / 2) * 8);
   double *W1 = (double *)w; w += al256((size_t)KB * ncols * 8);
   double *W2 = (double *)w;
 
   // all Gram matrices G_b = V_b^T V_b in one batched GEMM (rows above a block's reflectors
-  // are zero in V, so the full column height can be used for every block)
+  // are zero in V, so the full column height can be used for every block); a short last
+  // block is zero padded
+  (void)hipMemsetAsync(G, 0, (size_t)nblk * KB * KB * 8, s);
+  (void)hipMemsetAsync(T, 0, (size_t)nblk * KB * KB * 8, s);
   const int full = nrefl / KB;            // blocks with all KB reflectors
   if (full > 0) {
     GemmDesc g{};
@@ -114,35 +121,24 @@ void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
     gemm(s, true, false, kb, kb, n, 1.0, V + (size_t)c0 * ldv, ldv, V + (size_t)c0 * ldv, ldv, 0.0,
          G + (size_t)full * KB * KB, KB);
   }
-  // T_b = [T11, -T11 G12 T22; 0, T22]: the diagonal parts by one batched LDS kernel, the
-  // coupling by two batched 128^3 GEMMs
-  (void)hipMemsetAsync(T, 0, (size_t)nblk * KB * KB * 8, s);
-  hipLaunchKernelGGL(larft_kernel, dim3(2 * nblk), dim3(128), (SB * SB + SB) * sizeof(double), s, nrefl,
-                     G, tau, T);
-  {
-    const int nb2 = (nrefl - SB > 0) ? ceil_div(nrefl - SB, KB) : 0;   // blocks that have a 2nd half
-    const int fullb = (nrefl >= KB) ? nrefl / KB : 0;
-    if (fullb > 0) {
+  // T_b: the 128x128 diagonal parts by one batched LDS kernel, then pairs are coupled bottom-up,
+  //   T = [T11, -T11 G12 T22; 0, T22]   (128 -> 256 -> ... -> KB), two batched GEMMs per step
+  hipLaunchKernelGGL(larft_kernel, dim3(nblk * (KB / SB)), dim3(128), (SB * SB + SB) * sizeof(double), s,
+                     nrefl, G, tau, T);
+  for (int sz = SB; sz < KB; sz *= 2) {
+    for (int o = 0; o < KB; o += 2 * sz) {
       GemmDesc g{};
-      g.M = SB; g.N = SB; g.K = SB; g.transA = false; g.transB = false; g.alpha = 1.0; g.beta = 0.0;
-      g.A = G + (size_t)SB * KB; g.lda = KB; g.strideA = (long long)KB * KB;            // G12
-      g.B = T + (size_t)SB * (KB + 1); g.ldb = KB; g.strideB = (long long)KB * KB;       // T22
-      g.C = Tmp; g.ldc = SB; g.strideC = (long long)SB * SB;
-      g.batch = fullb; g.lower_only = false;
+      g.M = sz; g.N = sz; g.K = sz; g.transA = false; g.transB = false; g.alpha = 1.0; g.beta = 0.0;
+      g.A = G + (size_t)o + (size_t)(o + sz) * KB; g.lda = KB; g.strideA = (long long)KB * KB;         // G12
+      g.B = T + (size_t)(o + sz) * (KB + 1); g.ldb = KB; g.strideB = (long long)KB * KB;               // T22
+      g.C = Tmp; g.ldc = sz; g.strideC = (long long)sz * sz;
+      g.batch = nblk; g.lower_only = false;
       gemm(s, g);
       g.alpha = -1.0;
-      g.A = T; g.lda = KB; g.strideA = (long long)KB * KB;                               // T11
-      g.B = Tmp; g.ldb = SB; g.strideB = (long long)SB * SB;
-      g.C = T + (size_t)SB * KB; g.ldc = KB; g.strideC = (long long)KB * KB;             // T12
+      g.A = T + (size_t)o * (KB + 1); g.lda = KB; g.strideA = (long long)KB * KB;                      // T11
+      g.B = Tmp; g.ldb = sz; g.strideB = (long long)sz * sz;
+      g.C = T + (size_t)o + (size_t)(o + sz) * KB; g.ldc = KB; g.strideC = (long long)KB * KB;         // T12
       gemm(s, g);
-    }
-    if (nb2 > fullb) {   // last block has a short second half of kb2 reflectors
-      const int b = fullb, kb2 = nrefl - b * KB - SB;
-      const double *Gb = G + (size_t)b * KB * KB;
-      double *Tb = T + (size_t)b * KB * KB, *Tm = Tmp + (size_t)b * SB * SB;
-      gemm(s, false, false, SB, kb2, kb2, 1.0, Gb + (size_t)SB * KB, KB, Tb + (size_t)SB * (KB + 1), KB,
-           0.0, Tm, SB);
-      gemm(s, false, false, SB, kb2, SB, -1.0, Tb, KB, Tm, SB, 0.0, Tb + (size_t)SB * KB, KB);
     }
   }
   for (int b = nblk - 1; b >= 0; --b) {

@@ -7,12 +7,16 @@
 //     input-independent launch sequence with NO device->host synchronisation
 //     (deflation counts stay on the device);
 //   * leaves (order <= 32): implicit QL, one wavefront per leaf, Z block in LDS;
-//   * a merge is: rank-sort of the poles -> deflation scan -> column permutation +
-//     Givens rotations -> secular equation (one root per lane, origin shifted to the
-//     nearer pole) -> Loewner weights -> eigenvector matrix of the rank-one update ->
-//     ONE batched MFMA GEMM  Q <- W * S  per tree height.  Deflated columns ride through
-//     the same GEMM as unit columns of S.
-// The O(n^3) part (4/3 N^3 nominal) is therefore entirely in ek::gemm.
+//   * a merge is: rank-sort of the poles -> deflation scan (DLAED2, incl. the column types
+//     top-only / dense / bottom-only) -> column permutation + Givens rotations -> secular
+//     equation (4 lanes per root, origin shifted to the nearer pole) -> Loewner weights ->
+//     eigenvector matrix S of the rank-one update -> ONE batched MFMA launch per tree height
+//     holding two GEMMs per merge, Q(top) = W(top, [top|dense]) S and Q(bottom) =
+//     W(bottom, [dense|bottom]) S, whose sizes and offsets (functions of the deflation
+//     counts) are written by the deflation kernel and read by the GEMM on the device.
+//     Deflated columns are copied.
+// The O(n^3) part (4/3 N^3 nominal) is therefore entirely in ek::gemm and
+// shrinks with deflation exactly as LAPACK's does.
 #include "ek_common.h"
 
 #include <algorithm>
