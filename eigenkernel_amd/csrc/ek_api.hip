@@ -228,17 +228,18 @@ int ek_hip_sygst(int n, double *A_loc, const int desc_A[9], const double *L_loc,
   const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
   void *ws;
   rc = workspace(2 * al((size_t)ld * n * 8) + al((size_t)nblk * kDiagNB * kDiagNB * 8) +
-                 al((size_t)128 * ld * 8), &ws);
+                 al((size_t)128 * ld * 8) + al(sygst_scratch_doubles(n) * 8), &ws);
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
   double *dA = a.get<double>((size_t)ld * n);
   double *dL = a.get<double>((size_t)ld * n);
   double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
   double *work = a.get<double>((size_t)128 * ld);
+  double *scr = a.get<double>(sygst_scratch_doubles(n));
   rc = h2d_matrix(n, n, A_loc, desc_A[8], dA, ld, s); if (rc) return rc;
   rc = h2d_matrix(n, n, L_loc, desc_B[8], dL, ld, s); if (rc) return rc;
   trtri_diag_blocks(s, n, dL, ld, dInv);
-  sygst_lower(s, n, dA, ld, dL, ld, dInv, work);
+  sygst_lower(s, n, dA, ld, dL, ld, dInv, work, scr);
   EK_HIP_CHECK(hipGetLastError());
   rc = d2h_matrix(n, n, dA, ld, A_loc, desc_A[8], s); if (rc) return rc;
   EK_HIP_CHECK(hipStreamSynchronize(s));
@@ -481,8 +482,9 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   if (wb_ormtr > scratch) scratch = wb_ormtr;
   const size_t trsm_work = al((size_t)128 * ld * 8);
   void *ws;
+  const size_t sygst_scr = (problem == 1) ? al(sygst_scratch_doubles(n) * 8) : 0;
   int rc = workspace(4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
-                     4 * al((size_t)ld * 8), &ws);
+                     4 * al((size_t)ld * 8) + sygst_scr, &ws);
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
   double *wA = a.get<double>((size_t)ld * ld);
@@ -493,6 +495,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   double *twork = a.get<double>((size_t)128 * ld);
   char *work = a.get<char>(scratch);
   double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
+  double *sscr = (problem == 1) ? a.get<double>(sygst_scratch_doubles(n)) : nullptr;
 
   StageTimer tm;
   const bool timing = stage_seconds && n_stages > 0;
@@ -514,7 +517,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   mark();                                                              // 1
   if (problem == 1) potrf_lower(s, n, wB, ld, dInv, g_ctx.d_info, twork);
   mark();                                                              // 2
-  if (problem == 1) sygst_lower(s, n, wA, ld, wB, ld, dInv, twork);
+  if (problem == 1) sygst_lower(s, n, wA, ld, wB, ld, dInv, twork, sscr);
   mark();                                                              // 3
   sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, work);
   mark();                                                              // 4

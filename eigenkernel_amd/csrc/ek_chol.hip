@@ -317,6 +317,24 @@ void trsm_llt(hipStream_t s, int n, int m, const double *L, int ldl, const doubl
   trsm_llt(s, n1, m, L, ldl, invdiag, X, ldx, work);
 }
 
+// dst <- dst + alpha * src  (m x n)
+__global__ void axpy_matrix_kernel(int m, int n, double alpha, const double *__restrict__ src, int lds,
+                                   double *__restrict__ dst, int ldd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  for (int j = blockIdx.y; j < n; j += gridDim.y)
+    dst[(size_t)i + (size_t)j * ldd] += alpha * src[(size_t)i + (size_t)j * lds];
+}
+// dst (full, ld n) <- symmetric matrix given by the lower triangle of src
+__global__ void full_from_lower_kernel(int n, const double *__restrict__ src, int lds,
+                                       double *__restrict__ dst, int ldd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int j = blockIdx.y; j < n; j += gridDim.y)
+    dst[(size_t)i + (size_t)j * ldd] = (i >= j) ? src[(size_t)i + (size_t)j * lds] : src[(size_t)j + (size_t)i * lds];
+}
+static inline dim3 grid_mn(int m, int n) { return dim3(ceil_div(m, 256), n < 2048 ? (n > 0 ? n : 1) : 2048); }
+
 // X <- X L^-T where only the lower triangle of the (square, n x n) result is wanted: column
 // block 2 is then only needed on rows >= n1, which removes ~43% of the flops of a full solve.
 static void trsm_rlt_lower(hipStream_t s, int n, const double *L, int ldl, const double *invdiag,
@@ -326,21 +344,58 @@ static void trsm_rlt_lower(hipStream_t s, int n, const double *L, int ldl, const
   const int n1 = split(n), n2 = n - n1;
   const double *L21 = L + n1, *L22 = L + (size_t)n1 + (size_t)n1 * ldl;
   double *X21 = X + n1, *X22 = X + (size_t)n1 + (size_t)n1 * ldx;
-  trsm_rlt(s, n, n1, L, ldl, invdiag, X, ldx, work);                       // all rows of block column 1
+  trsm_rlt(s, n, n1, L, ldl, invdiag, X, ldx, work);                          // all rows of block column 1
   gemm(s, false, true, n2, n2, n1, -1.0, X21, ldx, L21, ldl, 1.0, X22, ldx);  // rows >= n1 only
   trsm_rlt_lower(s, n2, L22, ldl, invdiag + (size_t)(n1 / NB) * NB * NB, X22, ldx, work);
 }
 
-// A <- L^-1 A L^-T.  The lower triangle of A is the input (as PDSYGST 'L'); the result is
-// returned in full storage (both triangles), of which later stages reference the lower.
-// Two recursive triangular solves on the whole matrix: 2 N^3 MFMA flops, all in GEMMs
-// of order N/2, N/4, ... rather than NB-wide panels.
-void sygst_lower(hipStream_t s, int n, double *A, int lda, const double *L, int ldl,
-                 const double *invdiag, double *work) {
+// Below this order a block is reduced by two triangular solves.  Measured on MI355X at N = 16384:
+// recursion to 128 -> 0.175 s, to 2048 -> 0.142 s, none (two solves on the whole matrix, 1.57 N^3
+// flops but the fewest and largest GEMMs) -> 0.135 s; so the blocked recursion stays disabled
+// until the small-GEMM latency is fixed.
+constexpr int kSygstDirect = 1 << 30;
+
+// Recursive blocked DSYGST(itype = 1, 'L'):  with A = [A11 .; A21 A22], L = [L11 0; L21 L22]
+//   C11 = sygst(A11, L11)
+//   A21 <- A21 L11^-T;  A21 <- A21 - 1/2 L21 C11
+//   A22 <- A22 - A21 L21^T - L21 A21^T            (SYR2K, lower)
+//   A21 <- A21 - 1/2 L21 C11;  A21 <- L22^-1 A21
+//   C22 = sygst(A22, L22)
+// ~n^3 flops in total (the count of the blocked LAPACK routine) down to blocks of order 2048,
+// every update a GEMM of order n/2, n/4, ...  scratch: n^2/2 doubles (the symmetric C11 in full storage + the product L21 C11).
+static void sygst_rec(hipStream_t s, int n, double *A, int lda, const double *L, int ldl,
+                      const double *invdiag, double *work, double *scratch) {
   if (n <= 0) return;
-  symmetrize_lower(s, n, A, lda);
-  trsm_lln(s, n, n, L, ldl, invdiag, A, lda, work);
-  trsm_rlt_lower(s, n, L, ldl, invdiag, A, lda, work);
+  if (n <= kSygstDirect) {
+    // small block: the recursion would drown in tiny launches; a full left solve plus a right
+    // solve restricted to the lower triangle (1.57 n^3 flops, but few and larger GEMMs)
+    symmetrize_lower(s, n, A, lda);
+    trsm_lln(s, n, n, L, ldl, invdiag, A, lda, work);
+    trsm_rlt_lower(s, n, L, ldl, invdiag, A, lda, work);
+    return;
+  }
+  const int n1 = split(n), n2 = n - n1;
+  double *A21 = A + n1, *A22 = A + (size_t)n1 + (size_t)n1 * lda;
+  const double *L21 = L + n1, *L22 = L + (size_t)n1 + (size_t)n1 * ldl;
+  const double *inv2 = invdiag + (size_t)(n1 / NB) * NB * NB;
+  sygst_rec(s, n1, A, lda, L, ldl, invdiag, work, scratch);
+  trsm_rlt(s, n2, n1, L, ldl, invdiag, A21, lda, work);
+  double *C11 = scratch, *M = scratch + (size_t)n1 * n1;          // n1 x n1, n2 x n1
+  hipLaunchKernelGGL(full_from_lower_kernel, grid_mn(n1, n1), dim3(256), 0, s, n1, A, lda, C11, n1);
+  gemm(s, false, false, n2, n1, n1, 1.0, L21, ldl, C11, n1, 0.0, M, n2);
+  hipLaunchKernelGGL(axpy_matrix_kernel, grid_mn(n2, n1), dim3(256), 0, s, n2, n1, -0.5, M, n2, A21, lda);
+  gemm(s, false, true, n2, n2, n1, -1.0, A21, lda, L21, ldl, 1.0, A22, lda, /*lower_only=*/true);
+  gemm(s, false, true, n2, n2, n1, -1.0, L21, ldl, A21, lda, 1.0, A22, lda, /*lower_only=*/true);
+  hipLaunchKernelGGL(axpy_matrix_kernel, grid_mn(n2, n1), dim3(256), 0, s, n2, n1, -0.5, M, n2, A21, lda);
+  trsm_lln(s, n2, n1, L22, ldl, inv2, A21, lda, work);
+  sygst_rec(s, n2, A22, lda, L22, ldl, inv2, work, scratch);
+}
+
+// A <- L^-1 A L^-T, lower triangles in and out (as PDSYGST 'L').  scratch: >= max(n^2/2 + n, 2*128^2) doubles.
+void sygst_lower(hipStream_t s, int n, double *A, int lda, const double *L, int ldl,
+                 const double *invdiag, double *work, double *scratch) {
+  if (n <= 0) return;
+  sygst_rec(s, n, A, lda, L, ldl, invdiag, work, scratch);
 }
 
 }  // namespace ek

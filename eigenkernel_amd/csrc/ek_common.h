@@ -72,8 +72,14 @@ void trsm_lln(hipStream_t s, int n, int m, const double *L, int ldl, const doubl
               double *X, int ldx, double *work);   // X <- L^-1 X   (X n x m)
 void trsm_llt(hipStream_t s, int n, int m, const double *L, int ldl, const double *invdiag,
               double *X, int ldx, double *work);   // X <- L^-T X   (X n x m)
+// scratch: >= sygst_scratch_doubles(n) doubles
+inline size_t sygst_scratch_doubles(int n) {
+  const size_t h = (size_t)(n / 2 + 128);
+  const size_t a = 2 * h * h, b = 2 * 128 * 128;
+  return a > b ? a : b;
+}
 void sygst_lower(hipStream_t s, int n, double *A, int lda, const double *L, int ldl,
-                 const double *invdiag, double *work);
+                 const double *invdiag, double *work, double *scratch);
 
 // ---------------------------------------------------------------- tridiagonalisation (ek_sytrd.hip)
 struct SytrdWork;   // opaque, sized by sytrd_work_bytes
