@@ -161,6 +161,118 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Small-grid variant: 64x64 tile, BK = 32, same 256 threads (2x2 waves of 32x32 = 2x2 MFMA
+// tiles).  Used when the 128x128 tiling would leave most CUs idle (the leaves of the
+// recursive Cholesky / triangular solves, low D&C levels): 4x the workgroups and half the
+// K iterations, so these latency-bound launches finish in roughly a third of the time.
+constexpr int SM = 64, SN = 64, SK = 32;
+constexpr int SMC_LD = SM + 16;   // 640-byte row stride: k-rows alternate bank halves
+constexpr int SKC_LD = 49;        // 98 dwords = 34 mod 64: conflict-free fragment reads
+constexpr int STILE_DOUBLES = (SK * SMC_LD > SM * SKC_LD) ? SK * SMC_LD : SM * SKC_LD;
+
+template <bool KCONTIG>
+__device__ __forceinline__ void sload_slab(double (&r)[8], const double *__restrict__ P, int ld,
+                                           int x0, int X, int k0, int K, int t) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = t + 256 * i;
+    int x, k;
+    if (KCONTIG) { k = idx & 31; x = idx >> 5; }
+    else         { x = idx & 63; k = idx >> 6; }
+    const int gx = x0 + x, gk = k0 + k;
+    double v = 0.0;
+    if (gx < X && gk < K)
+      v = KCONTIG ? P[(size_t)gk + (size_t)gx * ld] : P[(size_t)gx + (size_t)gk * ld];
+    r[i] = v;
+  }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void sstore_slab(const double (&r)[8], double *s, int t) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = t + 256 * i;
+    if (KCONTIG) { const int k = idx & 31, x = idx >> 5; s[x * SKC_LD + k] = r[i]; }
+    else         { const int x = idx & 63, k = idx >> 6; s[k * SMC_LD + x] = r[i]; }
+  }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ double sfrag(const double *s, int x, int k) {
+  return KCONTIG ? s[x * SKC_LD + k] : s[k * SMC_LD + x];
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs p) {
+  __shared__ double smem[2 * STILE_DOUBLES];
+  double *sA = smem, *sB = smem + STILE_DOUBLES;
+  const int tile = blockIdx.x;
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int m0 = tm * SM, n0 = tn * SN;
+  if (p.lower_only && n0 > m0 + SM - 1) return;
+  if (p.dims) {
+    p.M = p.dims[3 * blockIdx.y]; p.N = p.dims[3 * blockIdx.y + 1]; p.K = p.dims[3 * blockIdx.y + 2];
+    if (m0 >= p.M || n0 >= p.N) return;
+  }
+  const double *__restrict__ A = p.A + (size_t)blockIdx.y * p.sA;
+  const double *__restrict__ B = p.B + (size_t)blockIdx.y * p.sB;
+  double *__restrict__ C = p.C + (size_t)blockIdx.y * p.sC;
+  if (p.offs) {
+    A += p.offs[3 * blockIdx.y]; B += p.offs[3 * blockIdx.y + 1]; C += p.offs[3 * blockIdx.y + 2];
+  }
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double ra[8], rb[8];
+  sload_slab<TA>(ra, A, p.lda, m0, p.M, 0, p.K, t);
+  sload_slab<!TB>(rb, B, p.ldb, n0, p.N, 0, p.K, t);
+  for (int k0 = 0; k0 < p.K; k0 += SK) {
+    __syncthreads();
+    sstore_slab<TA>(ra, sA, t);
+    sstore_slab<!TB>(rb, sB, t);
+    __syncthreads();
+    if (k0 + SK < p.K) {
+      sload_slab<TA>(ra, A, p.lda, m0, p.M, k0 + SK, p.K, t);
+      sload_slab<!TB>(rb, B, p.ldb, n0, p.N, k0 + SK, p.K, t);
+    }
+#pragma unroll
+    for (int kk = 0; kk < SK; kk += 4) {
+      double fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = sfrag<TA>(sA, wm + i * 16 + l15, kk + l4);
+        fb[i] = sfrag<!TB>(sB, wn + i * 16 + l15, kk + l4);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+  }
+  const double alpha = p.alpha, beta = p.beta;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm + mi * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + ni * 16 + l4 + 4 * r;
+        if (m < p.M && n < p.N) {
+          double *c = C + (size_t)m + (size_t)n * p.ldc;
+          double v = alpha * acc[ni][mi][r];
+          if (beta != 0.0) v += beta * *c;
+          *c = v;
+        }
+      }
+    }
+}
+
 }  // namespace
 
 void gemm(hipStream_t s, const GemmDesc &g) {
@@ -172,8 +284,20 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   p.B = g.B; p.ldb = g.ldb; p.sB = g.strideB;
   p.C = g.C; p.ldc = g.ldc; p.sC = g.strideC;
   p.lower_only = g.lower_only ? 1 : 0;
-  p.tiles_m = ceil_div(g.M, BM); p.tiles_n = ceil_div(g.N, BN);
   p.offs = g.d_offs; p.dims = g.d_dims;
+  // lower_only is defined on the 128x128 tiling (callers rely on whole diagonal tiles being
+  // written), so the small-grid variant is used for plain products only
+  const long long big_tiles = (long long)ceil_div(g.M, BM) * ceil_div(g.N, BN) * g.batch;
+  if (big_tiles < 96 && !g.lower_only) {
+    p.tiles_m = ceil_div(g.M, SM); p.tiles_n = ceil_div(g.N, SN);
+    dim3 sgrid(p.tiles_m * p.tiles_n, g.batch), sblock(256);
+    if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, false>), sgrid, sblock, 0, s, p);
+    else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, sblock, 0, s, p);
+    else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<true, false>), sgrid, sblock, 0, s, p);
+    else hipLaunchKernelGGL((gemm_small_kernel<true, true>), sgrid, sblock, 0, s, p);
+    return;
+  }
+  p.tiles_m = ceil_div(g.M, BM); p.tiles_n = ceil_div(g.N, BN);
   dim3 grid(p.tiles_m * p.tiles_n, g.batch), block(256);
   if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, p);
   else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, p);
