@@ -349,11 +349,10 @@ static void trsm_rlt_lower(hipStream_t s, int n, const double *L, int ldl, const
   trsm_rlt_lower(s, n2, L22, ldl, invdiag + (size_t)(n1 / NB) * NB * NB, X22, ldx, work);
 }
 
-// Below this order a block is reduced by two triangular solves.  Measured on MI355X at N = 16384:
-// recursion to 128 -> 0.175 s, to 2048 -> 0.142 s, none (two solves on the whole matrix, 1.57 N^3
-// flops but the fewest and largest GEMMs) -> 0.135 s; so the blocked recursion stays disabled
-// until the small-GEMM latency is fixed.
-constexpr int kSygstDirect = 1 << 30;
+// Below this order a block is reduced by two triangular solves (1.57 n^3 flops but the fewest
+// and largest GEMMs); above it the blocked recursion (n^3).  Measured on MI355X at N = 16384
+// (sygst stage): no recursion 0.133 s, threshold 2048 -> 0.115 s, 1024 -> 0.120 s, 512 -> 0.126 s.
+constexpr int kSygstDirect = 2048;
 
 // Recursive blocked DSYGST(itype = 1, 'L'):  with A = [A11 .; A21 A22], L = [L11 0; L21 L22]
 //   C11 = sygst(A11, L11)
