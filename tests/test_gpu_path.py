@@ -312,3 +312,65 @@ def test_large_sizes_through_invariants(hip, n, gep):
         assert abs((w ** 2).sum() - (hA ** 2).sum()) <= 64 * n * EPS * (w ** 2).sum()
     for p in ptrs:
         lib.ek_hip_free(p)
+
+
+@pytest.mark.parametrize("kind", ["zero", "identity", "diagonal", "scaled_up", "scaled_down", "negative",
+                                  "rank_one", "arrowhead", "repeated_blocks"])
+@pytest.mark.parametrize("n", [5, 64, 200])
+def test_degenerate_inputs(hip, oracle, n, kind):
+    """Corner paths of the reduction (tau = 0 reflectors, already-tridiagonal input), of the
+    D&C (total deflation, multiple eigenvalues) and scaling robustness, against the oracle."""
+    rng = np.random.default_rng(n)
+    if kind == "zero":
+        A = np.zeros((n, n))
+    elif kind == "identity":
+        A = np.eye(n)
+    elif kind == "diagonal":
+        A = np.diag(rng.uniform(-1, 1, n))
+    elif kind == "scaled_up":
+        A = oracle.synth_matrix(n, 1) * 1e8
+    elif kind == "scaled_down":
+        A = oracle.synth_matrix(n, 1) * 1e-8
+    elif kind == "negative":
+        A = -oracle.synth_matrix(n, 1)
+    elif kind == "rank_one":
+        u = rng.uniform(-1, 1, n)
+        A = np.outer(u, u)
+    elif kind == "arrowhead":
+        A = np.diag(rng.uniform(1, 2, n)); A[:, 0] = A[0, :] = rng.uniform(-1, 1, n); A[0, 0] = 3.0
+    else:  # repeated_blocks: many exactly repeated eigenvalues
+        blk = oracle.synth_matrix(5, 3)
+        A = np.kron(np.eye(n // 5 + 1), blk)[:n, :n]
+    A = np.asfortranarray(A)
+    scale = max(np.abs(A).max(), 1e-300)
+    # standard problem
+    w_or, _, info_or, _ = oracle.solve(A)
+    ep, _ = hip.eigen_solver("hip", A)
+    assert info_or == 0
+    assert np.abs(ep.values - w_or).max() <= 8 * n * EPS * max(np.abs(w_or).max(), scale)
+    Z = ep.Vectors
+    assert np.abs(A @ Z - Z * ep.values).max() <= 64 * n * EPS * scale
+    assert np.abs(Z.T @ Z - np.eye(n)).max() <= 64 * n * EPS
+    # generalized problem with a well conditioned B
+    B = oracle.synth_matrix(n, 2)
+    w_or, _, info_or, _ = oracle.solve(A, B)
+    ep, _ = hip.eigen_solver("general_hip", A, B)
+    assert np.abs(ep.values - w_or).max() <= 8 * n * EPS * max(np.abs(w_or).max(), scale)
+    Z = ep.Vectors
+    assert np.abs(A @ Z - (B @ Z) * ep.values).max() <= 256 * n * EPS * scale
+    assert np.abs(Z.T @ B @ Z - np.eye(n)).max() <= 256 * n * EPS
+
+
+def test_ill_conditioned_B(hip, oracle):
+    """cond(B) ~ 1e8: both paths lose the same digits; eigenvalues agree to cond(B)*eps."""
+    n = 120
+    A = oracle.synth_matrix(n, 1)
+    Q, _ = np.linalg.qr(np.random.default_rng(1).normal(size=(n, n)))
+    B = np.asfortranarray((Q * np.logspace(0, -8, n)) @ Q.T)
+    B = 0.5 * (B + B.T)
+    w_or, _, info_or, _ = oracle.solve(A, B)
+    ep, _ = hip.eigen_solver("general_hip", A, B)
+    assert info_or == 0
+    assert np.abs(ep.values - w_or).max() <= 1e-5 * np.abs(w_or).max()
+    Z = ep.Vectors
+    assert np.abs(Z.T @ B @ Z - np.eye(n)).max() <= 1e-6
