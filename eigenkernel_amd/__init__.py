@@ -9,12 +9,14 @@ missing.
 """
 from .descriptor import (DESC_SIZE, descinit, layout_procs, numroc, setup_distributed_matrix,
                          g_block_size)
-from .matrix_io import read_matrix_file, write_matrix_file, write_eigenvalues, SparseMat
+from .matrix_io import (read_matrix_file, write_matrix_file, write_eigenvalues, write_eigenvectors,
+                        parse_printed_vecs_ranges, SparseMat)
 from .solver import (eigen_solver, EigenpairsBlacs, Process, load_library, LibraryMissing,
                      SOLVERS)
 
 __all__ = [
     "DESC_SIZE", "descinit", "layout_procs", "numroc", "setup_distributed_matrix",
-    "g_block_size", "read_matrix_file", "write_matrix_file", "write_eigenvalues", "SparseMat",
+    "g_block_size", "read_matrix_file", "write_matrix_file", "write_eigenvalues", "write_eigenvectors",
+    "parse_printed_vecs_ranges", "SparseMat",
     "eigen_solver", "EigenpairsBlacs", "Process", "load_library", "LibraryMissing", "SOLVERS",
 ]

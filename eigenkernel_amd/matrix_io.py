@@ -80,3 +80,34 @@ def write_eigenvalues(path, values):
     with open(path, "w") as f:
         for k, v in enumerate(values):
             f.write("%8d %s\n" % (k + 1, _fortran_e26(float(v))))
+
+
+def parse_printed_vecs_ranges(spec):
+    """`-p` syntax of the reference (command_argument.f90:271-316): "1-3,7" -> [(1, 3), (7, 7)]."""
+    out = []
+    for part in spec.split(","):
+        if not part or part.startswith("-") or part.endswith("-"):
+            raise ValueError("invalid range %r" % part)
+        a, _, b = part.partition("-")
+        out.append((int(a), int(b) if b else int(a)))
+    return out
+
+
+def write_eigenvectors(directory, Z, ranges, binary=False):
+    """print_eigenvectors (matrix_io.f90:173-285): one file `<dir>/%08d.dat` per index; text lines
+    `(I8,' ',I8,' ',E26.16e3)` = i j value, or with binary=True one Fortran sequential
+    unformatted record of N doubles (4-byte record markers)."""
+    import os
+    import struct
+    n = Z.shape[0]
+    for a, b in ranges:
+        for j in range(a, b + 1):
+            path = os.path.join(directory, "%08d.dat" % j)
+            col = np.ascontiguousarray(Z[:, j - 1], dtype=np.float64)
+            if binary:
+                with open(path, "wb") as f:
+                    f.write(struct.pack("<i", 8 * n)); f.write(col.tobytes()); f.write(struct.pack("<i", 8 * n))
+            else:
+                with open(path, "w") as f:
+                    for i in range(n):
+                        f.write("%8d %8d %s\n" % (i + 1, j, _fortran_e26(float(col[i]))))

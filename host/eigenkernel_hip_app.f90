@@ -9,6 +9,9 @@
 !     -o <file>   eigenvalue file (default eigenvalues.dat)              main.f90:111-121
 !     -i <file>   IPR file (default ipratios.dat)                        main.f90:131-143
 !     -l <file>   log file (default log.json)                            main.f90:185-190
+!     -p <ranges> eigenvectors to print, e.g. 1-3,7                      command_argument.f90:271-316
+!     -d <dir>    directory of the eigenvector files <dir>/%08d.dat      matrix_io.f90:173-231
+!     --binary    one unformatted sequential record of N doubles per file (else `i j value` lines)
 !     --block-size <nb>   block size recorded in the descriptors
 !     --dry-run   read the matrices and stop                             main.f90:89-93
 !
@@ -46,7 +49,10 @@ program eigenkernel_hip_app
   use ek_hip_binding
   implicit none
 
-  character(len=1024) :: arg, solver, file_a, file_b, out_ev, out_ipr, out_log, cmdline
+  character(len=1024) :: arg, solver, file_a, file_b, out_ev, out_ipr, out_log, cmdline, vec_dir, vec_ranges
+  logical :: binary_out
+  integer, parameter :: max_ranges = 100
+  integer :: n_ranges, ranges(2, max_ranges), ir
   integer :: nargs, iarg, n_files, n_vec, n_check, ortho_a, ortho_b, block_size, ios, comma
   logical :: dry_run, generalized, is_select
   integer :: n, nb, info, problem, i, j
@@ -71,6 +77,7 @@ program eigenkernel_hip_app
   out_ev = 'eigenvalues.dat'; out_ipr = 'ipratios.dat'; out_log = 'log.json'
   n_vec = -1; n_check = 0; ortho_a = 0; ortho_b = 0; block_size = 0
   dry_run = .false.; n_files = 0; n_events = 0
+  vec_dir = '.'; vec_ranges = ''; binary_out = .false.; n_ranges = 0
   call get_command(cmdline)
 
   nargs = command_argument_count()
@@ -86,6 +93,9 @@ program eigenkernel_hip_app
     case ('-l'); call next_arg(out_log)
     case ('--block-size'); call next_int(block_size)
     case ('--dry-run'); dry_run = .true.
+    case ('-p'); call next_arg(vec_ranges)
+    case ('-d'); call next_arg(vec_dir)
+    case ('--binary'); binary_out = .true.
     case ('-t')
       call next_arg(arg)
       comma = index(arg, ',')
@@ -137,6 +147,11 @@ program eigenkernel_hip_app
   if (n_vec > n) call die('-n exceeds the matrix dimension', 1)
   if (n_check < 0 .or. n_check > n_vec) n_check = n_vec
   if (ortho_b > n_vec) call die('-t range exceeds the number of computed vectors', 1)
+  if (len_trim(vec_ranges) > 0) call parse_ranges(trim(vec_ranges))
+  do ir = 1, n_ranges
+    if (ranges(1, ir) < 1 .or. ranges(2, ir) > n_vec .or. ranges(1, ir) > ranges(2, ir)) &
+         call die('-p range outside 1..n_vec', 1)      ! command_argument.f90:202-208
+  end do
 
   ! setup_distributed_matrix on the 1x1 grid (distribute_matrix.f90:92-148 incl. the shrink rule)
   nb = 64
@@ -205,6 +220,13 @@ program eigenkernel_hip_app
   end do
   close (22)
 
+  ! eigenvector files <dir>/%08d.dat (matrix_io.f90:173-285)
+  do ir = 1, n_ranges
+    do j = ranges(1, ir), ranges(2, ir)
+      call write_eigenvector(j)
+    end do
+  end do
+
   if (n_check > 0) then
     if (generalized) then
       info = ek_hip_check(0, problem, n, n_check, 1, 1, c_loc(a_orig), c_loc(desc_a), c_loc(b_orig), &
@@ -252,9 +274,58 @@ contains
     if (ios /= 0) call die('integer expected after option', 1)
   end subroutine next_int
 
+  ! "a-b,c,d-e" -> ranges(2, n_ranges)
+  subroutine parse_ranges(spec)
+    character(len=*), intent(in) :: spec
+    integer :: p0, p1, dash, st
+    p0 = 1
+    do while (p0 <= len(spec))
+      p1 = index(spec(p0:), ',')
+      if (p1 == 0) then
+        p1 = len(spec)
+      else
+        p1 = p0 + p1 - 2
+      end if
+      if (p1 < p0) call die('-p: empty range', 1)
+      if (n_ranges >= max_ranges) call die('-p: too many ranges', 1)
+      n_ranges = n_ranges + 1
+      dash = index(spec(p0:p1), '-')
+      if (dash == 0) then
+        read (spec(p0:p1), *, iostat=st) ranges(1, n_ranges)
+        ranges(2, n_ranges) = ranges(1, n_ranges)
+      else
+        if (dash == 1 .or. p0 + dash - 1 == p1) call die('-p: invalid hyphen placement', 1)
+        read (spec(p0:p0 + dash - 2), *, iostat=st) ranges(1, n_ranges)
+        if (st == 0) read (spec(p0 + dash:p1), *, iostat=st) ranges(2, n_ranges)
+      end if
+      if (st /= 0) call die('-p: integer expected', 1)
+      p0 = p1 + 2
+    end do
+  end subroutine parse_ranges
+
+  subroutine write_eigenvector(jvec)
+    integer, intent(in) :: jvec
+    character(len=1200) :: fname
+    integer :: st, irow
+    write (fname, '(a, "/", i8.8, ".dat")') trim(vec_dir), jvec
+    if (binary_out) then
+      open (unit=24, file=trim(fname), form='unformatted', access='sequential', status='replace', iostat=st)
+      if (st /= 0) call die('print_eigenvectors: cannot open '//trim(fname), st)
+      write (24) z(1:n, jvec)
+    else
+      open (unit=24, file=trim(fname), status='replace', iostat=st)
+      if (st /= 0) call die('print_eigenvectors: cannot open '//trim(fname), st)
+      do irow = 1, n
+        write (24, "(I8, ' ', I8, ' ', E26.16e3)") irow, jvec, z(irow, jvec)
+      end do
+    end if
+    close (24)
+  end subroutine write_eigenvector
+
   subroutine usage()
     print '(a)', 'usage: eigenkernel_hip_app -s <hip|hip_select|general_hip|general_hip_select> [-n num]'
-    print '(a)', '       [-c num] [-t a,b] [-o file] [-i file] [-l file] [--block-size nb] [--dry-run] A.mtx [B.mtx]'
+    print '(a)', '       [-c num] [-t a,b] [-o file] [-i file] [-l file] [-p ranges] [-d dir] [--binary]'
+    print '(a)', '       [--block-size nb] [--dry-run] A.mtx [B.mtx]'
   end subroutine usage
 
   subroutine die(msg, code)

@@ -249,7 +249,7 @@ def test_fortran_host_end_to_end(tmp_path, golden_dir):
         flang = "/opt/rocm/lib/llvm/bin/flang"
         assert os.path.exists(flang), "flang missing: cannot build the Fortran host"
         subprocess.check_call(["make", "-C", os.path.join(root, "host")])
-    out = subprocess.run([exe, "-s", "general_hip", "-c", "-1", "-t", "1,30",
+    out = subprocess.run([exe, "-s", "general_hip", "-c", "-1", "-t", "1,30", "-p", "1-2,30", "-d", str(tmp_path),
                           os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_A.mtx"),
                           os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_B.mtx")],
                          cwd=tmp_path, capture_output=True, text=True, timeout=300)
@@ -273,6 +273,13 @@ def test_fortran_host_end_to_end(tmp_path, golden_dir):
     assert set(log) == {"setting", "events"} and log["setting"]["dimension"] == 30
     names = {e["name"] for e in log["events"]}
     assert {"reduce_generalized:pdpotrf", "eigen_solver_scalapack_all:pdsytrd", "recovery_generalized"} <= names
+    # eigenvector files (-p 1-2,30): `i j value` lines, B-normalised vectors
+    vec = np.loadtxt(tmp_path / "00000030.dat")
+    assert vec.shape == (30, 3) and np.array_equal(vec[:, 0], np.arange(1, 31)) and np.all(vec[:, 1] == 30)
+    Bd = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_B.mtx")).to_dense()
+    assert abs(vec[:, 2] @ Bd @ vec[:, 2] - 1.0) <= 1e-13
+    assert (tmp_path / "00000001.dat").exists() and (tmp_path / "00000002.dat").exists()
+    assert not (tmp_path / "00000003.dat").exists()
     # error contract: unknown solver -> "[Error] ..." on stderr, non-zero exit (processes.f90:133-138)
     bad = subprocess.run([exe, "-s", "general_elpa1", "a.mtx", "b.mtx"], cwd=tmp_path, capture_output=True, text=True)
     assert bad.returncode != 0 and bad.stderr.startswith("[Error]")

@@ -162,3 +162,21 @@ def test_multi_rank_aggregation_gloo():
     assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
     for _, _, value, t in res:
         assert t == 2.0 and abs(value - 500 / 2.0) < 1e-12
+
+
+def test_eigenvector_writer_formats(tmp_path):
+    """matrix_io.f90:173-285: `<dir>/%08d.dat`, text `i j value` lines or one Fortran
+    unformatted record (248 bytes for N = 30)."""
+    assert ek.parse_printed_vecs_ranges("1-3,7") == [(1, 3), (7, 7)]
+    with pytest.raises(ValueError):
+        ek.parse_printed_vecs_ranges("-3")
+    Z = np.arange(1, 31 * 30 + 1, dtype=np.float64).reshape(31, 30)[:30].T.copy() / 7.0
+    ek.write_eigenvectors(str(tmp_path), Z, [(2, 3)], binary=False)
+    lines = (tmp_path / "00000002.dat").read_text().splitlines()
+    assert len(lines) == 30 and lines[0][:18] == "       1        2 "
+    assert abs(float(lines[4].split()[2]) - Z[4, 1]) <= 1e-15 * abs(Z[4, 1])
+    assert (tmp_path / "00000003.dat").exists() and not (tmp_path / "00000001.dat").exists()
+    ek.write_eigenvectors(str(tmp_path), Z, [(5, 5)], binary=True)
+    raw = (tmp_path / "00000005.dat").read_bytes()
+    assert len(raw) == 248
+    assert np.array_equal(np.frombuffer(raw[4:-4], dtype=np.float64), Z[:, 4])
