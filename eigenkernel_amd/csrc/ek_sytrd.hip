@@ -32,7 +32,7 @@
 namespace ek {
 namespace {
 
-constexpr int NBP = 64;      // panel width
+constexpr int NBP = 64;      // panel width (128 measured equal: shorter SYR2K, longer column updates)
 constexpr int TS = 128;      // symv strip width / row-block height
 
 struct SytrdBufs {
@@ -375,17 +375,23 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
 
   if ((int)blockIdx.x < p.ndot) {
     // ---- reducer: totals of the raw panel products V^T x, W^T x (colupd applies the scaling)
+    constexpr int HALVES = 256 / (2 * NBP);          // thread groups that share the chunk range
     double a0 = 0.0, a1 = 0.0;
-    const int k2 = t & (2 * NBP - 1), half = t >> 7;
+    const int k2 = t & (2 * NBP - 1), half = t / (2 * NBP);
     int c = half;
-    for (; c + 2 < p.nchunks; c += 4) {
+    for (; c + HALVES < p.nchunks; c += 2 * HALVES) {
       a0 += p.b.dotpart[(size_t)c * 2 * NBP + k2];
-      a1 += p.b.dotpart[(size_t)(c + 2) * 2 * NBP + k2];
+      a1 += p.b.dotpart[(size_t)(c + HALVES) * 2 * NBP + k2];
     }
     if (c < p.nchunks) a0 += p.b.dotpart[(size_t)c * 2 * NBP + k2];
     s_dot[half][k2] = a0 + a1;
     __syncthreads();
-    if (t < 2 * NBP) p.b.dottot[t] = ((t & (NBP - 1)) < p.i) ? s_dot[0][t] + s_dot[1][t] : 0.0;
+    if (t < 2 * NBP) {
+      double tot = 0.0;
+#pragma unroll
+      for (int h = 0; h < HALVES; ++h) tot += s_dot[h][t];
+      p.b.dottot[t] = ((t & (NBP - 1)) < p.i) ? tot : 0.0;
+    }
     return;
   }
 
