@@ -591,7 +591,10 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
       sv.j = j; sv.i = i; sv.S0 = (j + 1) / TS;
       const int T = NRB - sv.S0;
       sv.ntiles = T * (T + 1) / 2;
-      sv.q = ceil_div(sv.ntiles, wg_target);
+      // ~2 resident workgroups per CU for large trailing matrices; one per CU once the matrix is
+      // small enough that per-workgroup fixed costs dominate (measured: T <= 40 strips)
+      const int target = (knobs().wgs > 0) ? wg_target : (T <= 40 ? 256 : wg_target);
+      sv.q = ceil_div(sv.ntiles, target);
       if (knobs().G > 0 && sv.q < knobs().G) sv.q = knobs().G;
       sv.nwg = ceil_div(sv.ntiles, sv.q);
       sv.ndot = (i > 0) ? 1 : 0;
