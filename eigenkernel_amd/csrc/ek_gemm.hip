@@ -22,6 +22,8 @@
 //       17-double row stride keeps both the writes and the fragment reads conflict-free.
 #include "ek_common.h"
 
+#include <cstdlib>
+
 namespace ek {
 namespace {
 
@@ -145,6 +147,106 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const double alpha = p.alpha, beta = p.beta;
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = m0 + wm + mi * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + ni * 16 + l4 + 4 * r;
+        if (m < p.M && n < p.N) {
+          double *c = C + (size_t)m + (size_t)n * p.ldc;
+          double v = alpha * acc[ni][mi][r];
+          if (beta != 0.0) v += beta * *c;
+          *c = v;
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 8-wave variant of the 128x128 tile: 512 threads, each wave a 64x32 slice (4x2 MFMA tiles,
+// 64 accumulator VGPRs), so two workgroups = 4 waves per SIMD are resident.
+template <bool KCONTIG>
+__device__ __forceinline__ void load_slab8(double (&r)[4], const double *__restrict__ P, int ld,
+                                           int x0, int X, int k0, int K, int t) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 512 * i;
+    int x, k;
+    if (KCONTIG) { k = idx & 15; x = idx >> 4; }
+    else         { x = idx & 127; k = idx >> 7; }
+    const int gx = x0 + x, gk = k0 + k;
+    double v = 0.0;
+    if (gx < X && gk < K)
+      v = KCONTIG ? P[(size_t)gk + (size_t)gx * ld] : P[(size_t)gx + (size_t)gk * ld];
+    r[i] = v;
+  }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void store_slab8(const double (&r)[4], double *s, int t) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 512 * i;
+    if (KCONTIG) { const int k = idx & 15, x = idx >> 4; s[x * KC_LD + k] = r[i]; }
+    else         { const int x = idx & 127, k = idx >> 7; s[k * MC_LD + x] = r[i]; }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 4) void gemm_kernel_w8(GemmArgs p) {
+  __shared__ double smem[2 * TILE_DOUBLES];
+  double *sA = smem, *sB = smem + TILE_DOUBLES;
+  const int tile = blockIdx.x;
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (p.lower_only && n0 > m0 + BM - 1) return;
+  if (p.dims) {
+    p.M = p.dims[3 * blockIdx.y]; p.N = p.dims[3 * blockIdx.y + 1]; p.K = p.dims[3 * blockIdx.y + 2];
+    if (m0 >= p.M || n0 >= p.N) return;
+  }
+  const double *__restrict__ A = p.A + (size_t)blockIdx.y * p.sA;
+  const double *__restrict__ B = p.B + (size_t)blockIdx.y * p.sB;
+  double *__restrict__ C = p.C + (size_t)blockIdx.y * p.sC;
+  if (p.offs) {
+    A += p.offs[3 * blockIdx.y]; B += p.offs[3 * blockIdx.y + 1]; C += p.offs[3 * blockIdx.y + 2];
+  }
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double4_t acc[2][4];   // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double ra0[4], rb0[4];
+  load_slab8<TA>(ra0, A, p.lda, m0, p.M, 0, p.K, t);
+  load_slab8<!TB>(rb0, B, p.ldb, n0, p.N, 0, p.K, t);
+  for (int k0 = 0; k0 < p.K; k0 += BK) {
+    __syncthreads();
+    store_slab8<TA>(ra0, sA, t);
+    store_slab8<!TB>(rb0, sB, t);
+    __syncthreads();
+    if (k0 + BK < p.K) {
+      load_slab8<TA>(ra0, A, p.lda, m0, p.M, k0 + BK, p.K, t);
+      load_slab8<!TB>(rb0, B, p.ldb, n0, p.N, k0 + BK, p.K, t);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag<TA>(sA, wm + i * 16 + l15, kk + l4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fb[i] = frag<!TB>(sB, wn + i * 16 + l15, kk + l4);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+  }
+  const double alpha = p.alpha, beta = p.beta;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int m = m0 + wm + mi * 16 + l15;
@@ -299,6 +401,21 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   }
   p.tiles_m = ceil_div(g.M, BM); p.tiles_n = ceil_div(g.N, BN);
   dim3 grid(p.tiles_m * p.tiles_n, g.batch), block(256);
+  // Rank-k updates (short K, C read-modify-write) run on the 8-wave variant: twice the resident
+  // waves hide the operand and C latency that the 4-wave kernel exposes when there are only a few
+  // k-steps per tile (measured: SYR2K of the tridiagonalisation -25 %); long-K products stay on
+  // the 4-wave kernel (measured 3 % faster there).  EK_GEMM_W8=0/1 forces one of them.
+  static int w8 = -2;
+  if (w8 == -2) { const char *e = getenv("EK_GEMM_W8"); w8 = e ? atoi(e) : -1; }
+  const bool use_w8 = (w8 >= 0) ? (w8 != 0) : (g.K <= 512 && g.beta != 0.0);
+  if (use_w8) {
+    dim3 b8(512);
+    if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel_w8<false, false>), grid, b8, 0, s, p);
+    else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel_w8<false, true>), grid, b8, 0, s, p);
+    else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel_w8<true, false>), grid, b8, 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel_w8<true, true>), grid, b8, 0, s, p);
+    return;
+  }
   if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, p);
   else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, p);
   else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, s, p);
