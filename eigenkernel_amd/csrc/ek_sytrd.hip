@@ -127,15 +127,16 @@ struct ColupdArgs {
   int i_new;              // finished panel columns once this launch is done (dots needed for them)
 };
 
-constexpr int CR = 64;    // rows per colupd workgroup (x 4 slices = 256 threads)
+constexpr int CR = 32;    // rows per colupd workgroup
+constexpr int NSL = 256 / CR;   // slices per row (threads sharing one row's sums)
 
 __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
   __shared__ double s_pvw[2 * NBP];          // [0,NBP): V^T v totals, [NBP,2NBP): W^T v totals
   __shared__ double s_Vj[NBP], s_Wj[NBP];
   __shared__ double s_red[8];
-  __shared__ double s_acc[3][4][CR];
+  __shared__ double s_acc[3][NSL][CR];
   __shared__ double s_x[CR], s_vn[CR], s_wn[CR];   // new column x, newest panel column (v, w)
-  const int t = threadIdx.x, lane = t & 63, q = t >> 6;
+  const int t = threadIdx.x, lane = t % CR, q = t / CR;
   const int r = p.r0 + blockIdx.x * CR + lane;
   const int ldp = p.npad;
   double *__restrict__ Pv = p.b.P;                          // V block
@@ -200,38 +201,32 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
         double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
         int S = p.S0p + q;
         const double *yp = p.b.ypart + r;
-        const size_t st4 = (size_t)4 * p.npad;
-        for (; S + 28 <= rb; S += 32) {          // 8 loads in flight per thread
+        const size_t stn = (size_t)NSL * p.npad;
+        for (; S + 3 * NSL <= rb; S += 4 * NSL) {   // 4 loads in flight per thread
           const double *b0 = yp + (size_t)S * p.npad;
-          const double u0 = b0[0], u1 = b0[st4], u2 = b0[2 * st4], u3 = b0[3 * st4];
-          const double u4 = b0[4 * st4], u5 = b0[5 * st4], u6 = b0[6 * st4], u7 = b0[7 * st4];
-          y0 += u0; y1 += u1; y2 += u2; y3 += u3; y0 += u4; y1 += u5; y2 += u6; y3 += u7;
-        }
-        for (; S + 12 <= rb; S += 16) {
-          const double *b0 = yp + (size_t)S * p.npad;
-          const double u0 = b0[0], u1 = b0[st4], u2 = b0[2 * st4], u3 = b0[3 * st4];
+          const double u0 = b0[0], u1 = b0[stn], u2 = b0[2 * stn], u3 = b0[3 * stn];
           y0 += u0; y1 += u1; y2 += u2; y3 += u3;
         }
-        for (; S <= rb; S += 4) y0 += yp[(size_t)S * p.npad];
+        for (; S <= rb; S += NSL) y0 += yp[(size_t)S * p.npad];
         const int np = num_pieces(rb - p.S0p, T, p.qp);
-        for (int pc = q; pc < np; pc += 4) y1 += p.b.tpart[((size_t)rb * p.NRB + pc) * TS + (r % TS)];
+        for (int pc = q; pc < np; pc += NSL) y1 += p.b.tpart[((size_t)rb * p.NRB + pc) * TS + (r % TS)];
         y = (y0 + y1) + (y2 + y3);
       }
       {
         double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
         int k = q;
         const double *pvr = Pv + r, *pwr = Pw + r;
-        for (; k + 12 < ip; k += 16) {           // 8 loads in flight per thread
+        for (; k + 3 * NSL < ip; k += 4 * NSL) {     // 8 loads in flight per thread
           const double v0 = pvr[(size_t)k * ldp], w0 = pwr[(size_t)k * ldp];
-          const double v1 = pvr[(size_t)(k + 4) * ldp], w1 = pwr[(size_t)(k + 4) * ldp];
-          const double v2 = pvr[(size_t)(k + 8) * ldp], w2 = pwr[(size_t)(k + 8) * ldp];
-          const double v3 = pvr[(size_t)(k + 12) * ldp], w3 = pwr[(size_t)(k + 12) * ldp];
-          a0 += v0 * s_pw[k] + w0 * s_pv[k];             b0 += v0 * s_Wj[k] + w0 * s_Vj[k];
-          a1 += v1 * s_pw[k + 4] + w1 * s_pv[k + 4];     b1 += v1 * s_Wj[k + 4] + w1 * s_Vj[k + 4];
-          a0 += v2 * s_pw[k + 8] + w2 * s_pv[k + 8];     b0 += v2 * s_Wj[k + 8] + w2 * s_Vj[k + 8];
-          a1 += v3 * s_pw[k + 12] + w3 * s_pv[k + 12];   b1 += v3 * s_Wj[k + 12] + w3 * s_Vj[k + 12];
+          const double v1 = pvr[(size_t)(k + NSL) * ldp], w1 = pwr[(size_t)(k + NSL) * ldp];
+          const double v2 = pvr[(size_t)(k + 2 * NSL) * ldp], w2 = pwr[(size_t)(k + 2 * NSL) * ldp];
+          const double v3 = pvr[(size_t)(k + 3 * NSL) * ldp], w3 = pwr[(size_t)(k + 3 * NSL) * ldp];
+          a0 += v0 * s_pw[k] + w0 * s_pv[k];                         b0 += v0 * s_Wj[k] + w0 * s_Vj[k];
+          a1 += v1 * s_pw[k + NSL] + w1 * s_pv[k + NSL];             b1 += v1 * s_Wj[k + NSL] + w1 * s_Vj[k + NSL];
+          a0 += v2 * s_pw[k + 2 * NSL] + w2 * s_pv[k + 2 * NSL];     b0 += v2 * s_Wj[k + 2 * NSL] + w2 * s_Vj[k + 2 * NSL];
+          a1 += v3 * s_pw[k + 3 * NSL] + w3 * s_pv[k + 3 * NSL];     b1 += v3 * s_Wj[k + 3 * NSL] + w3 * s_Vj[k + 3 * NSL];
         }
-        for (; k < ip; k += 4) {
+        for (; k < ip; k += NSL) {
           const double v0 = pvr[(size_t)k * ldp], w0 = pwr[(size_t)k * ldp];
           a0 += v0 * s_pw[k] + w0 * s_pv[k]; b0 += v0 * s_Wj[k] + w0 * s_Vj[k];
         }
@@ -242,9 +237,9 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
     __syncthreads();
     if (q == 0) {
       if (r >= j && r < p.npad) {
-        y = (s_acc[0][0][lane] + s_acc[0][1][lane]) + (s_acc[0][2][lane] + s_acc[0][3][lane]);
-        accA = (s_acc[1][0][lane] + s_acc[1][1][lane]) + (s_acc[1][2][lane] + s_acc[1][3][lane]);
-        accB = (s_acc[2][0][lane] + s_acc[2][1][lane]) + (s_acc[2][2][lane] + s_acc[2][3][lane]);
+        y = 0.0; accA = 0.0; accB = 0.0;
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) { y += s_acc[0][u][lane]; accA += s_acc[1][u][lane]; accB += s_acc[2][u][lane]; }
         double v_r = (r == j) ? 1.0 : p.b.xbuf[r] * rf.scale;
         if (r >= p.n) v_r = 0.0;
         const double y_r = rf.scale * y + corr * a_old;

@@ -19,7 +19,7 @@ import numpy as np
 from . import descriptor as _d
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libek_hip.so")
+LIB_PATH = os.environ.get("EK_HIP_LIB") or os.path.join(_HERE, "csrc", "libek_hip.so")   # env: A/B builds
 
 N_STAGES = 8
 SOLVERS = ("hip", "hip_select", "general_hip", "general_hip_select")
