@@ -514,6 +514,24 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   }
   EK_HIP_CHECK(hipMemsetAsync(wV, 0, (size_t)ld * ld * 8, s));
   EK_HIP_CHECK(hipMemsetAsync(dd, 0, 4 * al((size_t)ld * 8), s));
+  // Scale A into the safe range when its entries are extreme (as DSYEV / PDSYEV do before
+  // DSYTRD): the Householder norms are plain sums of squares.  Eigenvalues scale back linearly.
+  double sigma = 1.0;
+  {
+    double *d_part = (double *)work;   // stage scratch, free until the reduction starts
+    maxabs_lower(s, n, wA, ld, d_part);
+    double part[256];
+    EK_HIP_CHECK(hipMemcpyAsync(part, d_part, sizeof(part), hipMemcpyDeviceToHost, s));
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    double anrm = 0.0;
+    for (double v : part) if (v > anrm) anrm = v;
+    if (!(anrm <= 1.7e308)) { tm.destroy(); return -4; }   // NaN / Inf in A: illegal value, as XERBLA
+    // the tridiagonalisation forms x^T A x of the unscaled column (|A|^3 n^2): keep cubes in range
+    const double rmin = 1e-90, rmax = 1e90;
+    if (anrm > 0.0 && anrm < rmin) sigma = rmin / anrm;
+    else if (anrm > rmax) sigma = rmax / anrm;
+    if (sigma != 1.0) scale_lower(s, n, sigma, wA, ld);
+  }
   mark();                                                              // 1
   if (problem == 1) potrf_lower(s, n, wB, ld, dInv, g_ctx.d_info, twork);
   mark();                                                              // 2
@@ -529,6 +547,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   mark();                                                              // 7
   // stage-out: eigenvalues, eigenvectors, and the in-place results the reference leaves
   // behind (L in B, reflectors in A)
+  if (sigma != 1.0) scale_vector(s, n, 1.0 / sigma, dwv);
   EK_HIP_CHECK(hipMemcpyAsync(dw, dwv, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
   copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
   copy_matrix(s, n, n, wA, ld, dA, lda);

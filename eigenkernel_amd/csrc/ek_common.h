@@ -57,6 +57,10 @@ void symmetrize_lower(hipStream_t s, int n, double *A, int lda);   // upper <- l
 void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, const int *perm,
                     double *dst, int ldd);                         // dst(:,j) = src(:,perm[j])
 
+void maxabs_lower(hipStream_t s, int n, const double *A, int lda, double *partial /* 256 */);
+void scale_lower(hipStream_t s, int n, double alpha, double *A, int lda);
+void scale_vector(hipStream_t s, int n, double alpha, double *x);
+
 // ---------------------------------------------------------------- Cholesky & triangular (ek_chol.hip)
 constexpr int kDiagNB = 128;   // order of the diagonal blocks factored/inverted by one workgroup
 // B = L L^T (lower). invdiag (optional, ld = kDiagNB, ceil(n/128) blocks of 128x128) receives the

@@ -152,10 +152,12 @@ __global__ void dc_sort_kernel(int mbeg, DcBufs b, const double *__restrict__ Q,
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= mg.n) return;
   const double *d = b.d + mg.off;
-  const double dt = d[t];
+  // NaN (numerical breakdown upstream) sorts as +inf so that ranks stay a permutation and
+  // every later index stays in bounds; the breakdown is reported through info at the end
+  const double dt = (d[t] == d[t]) ? d[t] : INFINITY;
   int rank = 0;
   for (int i = 0; i < mg.n; ++i) {
-    const double di = d[i];
+    const double di = (d[i] == d[i]) ? d[i] : INFINITY;
     rank += (di < dt || (di == dt && i < t)) ? 1 : 0;
   }
   const double rho_in = b.e[mg.off + mg.n1 - 1];
@@ -451,17 +453,20 @@ __global__ void dc_copy_deflated_kernel(int mbeg, DcBufs b, const double *__rest
 }
 
 // ------------------------------------------------------------------ final ordering
-__global__ void dc_final_rank_kernel(int n, DcBufs b, double *__restrict__ w, int *__restrict__ perm) {
+__global__ void dc_final_rank_kernel(int n, DcBufs b, double *__restrict__ w, int *__restrict__ perm,
+                                     int *info) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const double dt = b.d[t];
+  const double raw = b.d[t];
+  const double dt = (raw == raw) ? raw : INFINITY;
   int rank = 0;
   for (int i = 0; i < n; ++i) {
-    const double di = b.d[i];
+    const double di = (b.d[i] == b.d[i]) ? b.d[i] : INFINITY;
     rank += (di < dt || (di == dt && i < t)) ? 1 : 0;
   }
-  w[rank] = dt * b.orgnrm[0];
+  w[rank] = raw * b.orgnrm[0];
   perm[rank] = t;
+  if (!(fabs(raw) <= 1.7e308)) atomicMax(info, n + 1);   // NaN / Inf eigenvalue: breakdown
 }
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -582,7 +587,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     gemm(s, g);
     hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldz, Q, ldq);
   }
-  hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, b, w, fperm);
+  hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, b, w, fperm, d_info);
   gather_columns(s, n, n, Q, ldq, fperm, Z, ldz);
 }
 

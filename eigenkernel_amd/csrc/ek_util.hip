@@ -70,6 +70,33 @@ __global__ void synth_kernel(int n, unsigned long long seed, double inv, double 
   }
 }
 
+// out[0] = max |A(i,j)| over the lower triangle (one workgroup, grid-stride; tiny vs the solve)
+__global__ __launch_bounds__(1024) void maxabs_lower_kernel(int n, const double *__restrict__ A, int lda,
+                                                            double *__restrict__ partial) {
+  __shared__ double red[1024];
+  double m = 0.0;
+  for (int j = blockIdx.x; j < n; j += gridDim.x)
+    for (int i = j + threadIdx.x; i < n; i += 1024) {
+      const double v = fabs(A[(size_t)i + (size_t)j * lda]);
+      m = (v <= 1.7e308) ? fmax(m, v) : INFINITY;        // NaN and Inf both surface as Inf
+    }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void scale_lower_kernel(int n, double alpha, double *A, int lda) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int j = blockIdx.y; j < n && j <= i; j += gridDim.y) A[(size_t)i + (size_t)j * lda] *= alpha;
+}
+
+__global__ void scale_vector_kernel(int n, double alpha, double *x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= alpha;
+}
+
 inline dim3 grid2d(int m, int n) {
   return dim3(ceil_div(m, 256), n < 4096 ? (n > 0 ? n : 1) : 4096);
 }
@@ -99,6 +126,19 @@ void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, con
 void synth_matrix(hipStream_t s, int n, unsigned long long seed, double *M, int ldm) {
   if (n <= 0) return;
   hipLaunchKernelGGL(synth_kernel, grid2d(n, n), dim3(256), 0, s, n, seed, 1.0 / sqrt((double)n), M, ldm);
+}
+
+// partial: >= 256 doubles (device); the caller reduces the 256 partial maxima on the host
+void maxabs_lower(hipStream_t s, int n, const double *A, int lda, double *partial) {
+  hipLaunchKernelGGL(maxabs_lower_kernel, dim3(256), dim3(1024), 0, s, n, A, lda, partial);
+}
+void scale_lower(hipStream_t s, int n, double alpha, double *A, int lda) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scale_lower_kernel, grid2d(n, n), dim3(256), 0, s, n, alpha, A, lda);
+}
+void scale_vector(hipStream_t s, int n, double alpha, double *x) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scale_vector_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, alpha, x);
 }
 
 }  // namespace ek

@@ -20,6 +20,8 @@
  *     >0 = numerical failure of the stage (the reference aborts on info != 0 after
  *     pdpotrf/pdsygst/pdtrtrs: generalized_to_standard.f90:25-30,38-41,105-108),
  *     <= -1000 = HIP runtime error (-1000 - hipError_t);
+ *     ek_hip_solve*: -4 also when A contains NaN/Inf; 100000 + k = the tridiagonal eigensolver
+ *     failed (k <= n: QL iteration of the leaf containing row k; k = n+1: non-finite eigenvalue);
  *   - SPMD: called once, collectively, by the single main thread of every rank
  *     (main.f90:100-104).  This round implements the 1x1 grid (one GPU); a call with
  *     nprow*npcol != 1 returns the negative index of the offending argument.

@@ -381,3 +381,45 @@ def test_ill_conditioned_B(hip, oracle):
     assert np.abs(ep.values - w_or).max() <= 1e-5 * np.abs(w_or).max()
     Z = ep.Vectors
     assert np.abs(Z.T @ B @ Z - np.eye(n)).max() <= 1e-6
+
+
+@pytest.mark.parametrize("scale", [1e200, 1e-200, 1e150, 1e-160])
+def test_extreme_scaling_of_A(hip, oracle, scale):
+    """Entries whose squares over/underflow: the solve rescales A like DSYEV does (the
+    reference's PDSYTRD survives through PDNRM2's scaled sum of squares)."""
+    n = 150
+    A0 = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    w0, _, _, _ = oracle.solve(A0, B)
+    ep, _ = hip.eigen_solver("general_hip", A0 * scale, B)
+    assert np.all(np.isfinite(ep.values))
+    assert np.abs(ep.values / scale - w0).max() <= 8 * n * EPS * np.abs(w0).max()
+    Z = ep.Vectors
+    assert np.abs(Z.T @ B @ Z - np.eye(n)).max() <= 256 * n * EPS
+    ep2, _ = hip.eigen_solver("hip", A0 * scale)
+    w1, _, _, _ = oracle.solve(A0)
+    assert np.abs(ep2.values / scale - w1).max() <= 8 * n * EPS * np.abs(w1).max()
+
+
+def test_non_finite_inputs_are_rejected_not_crashed(hip, oracle):
+    """NaN / Inf in A -> info = -4 (illegal value); NaN in B -> the Cholesky reports the pivot.
+    The process must survive (the reference would hand garbage to ScaLAPACK, not crash)."""
+    n = 130
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    for bad in (np.nan, np.inf, -np.inf):
+        Ab = A.copy(); Ab[70, 3] = bad; Ab[3, 70] = bad
+        with pytest.raises(hip.SolverError) as ei:
+            hip.eigen_solver("general_hip", Ab, B)
+        assert ei.value.info == -4
+        with pytest.raises(hip.SolverError) as ei:
+            hip.eigen_solver("hip", Ab)
+        assert ei.value.info == -4
+    Bb = B.copy(); Bb[40, 40] = np.nan
+    with pytest.raises(hip.SolverError) as ei:
+        hip.eigen_solver("general_hip", A, Bb)
+    assert ei.value.info == 41
+    # and the library is still healthy afterwards
+    ep, _ = hip.eigen_solver("general_hip", A, B)
+    w_or, _, _, _ = oracle.solve(A, B)
+    assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * np.abs(w_or).max()
