@@ -535,23 +535,43 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     b.ldw = ldz; b.ldq = ldq; b.lds = lds;
   }
   int *fperm = (int *)(base + L.off_int + 5 * al256((size_t)(n + 8) * 4));
-  Leaf *d_leaves = (Leaf *)(base + L.off_leaf);
+  Leaf *d_leaves = nullptr;
 
-  Plan plan;
-  plan.height(0, n);
-  std::vector<Merge> all;
-  std::vector<int> lvl_beg;
-  for (auto &lv : plan.levels) {
-    lvl_beg.push_back((int)all.size());
-    for (auto &m : lv) all.push_back(m);
+  // The recursion tree depends on n only: it is built and uploaded once per order and kept in
+  // a small persistent device buffer, so a solve never synchronises with the host here.
+  struct CachedPlan {
+    int n = -1;
+    Plan plan;
+    std::vector<Merge> all;
+    std::vector<int> lvl_beg;
+    Leaf *d_leaves = nullptr;
+    Merge *d_merges = nullptr;
+  };
+  static CachedPlan cache;
+  if (cache.n != n) {
+    (void)hipStreamSynchronize(s);   // a previous order's plan may still be in use on the stream
+    if (cache.d_leaves) (void)hipFree(cache.d_leaves);
+    if (cache.d_merges) (void)hipFree(cache.d_merges);
+    cache = CachedPlan();
+    cache.plan.height(0, n);
+    for (auto &lv : cache.plan.levels) {
+      cache.lvl_beg.push_back((int)cache.all.size());
+      for (auto &m : lv) cache.all.push_back(m);
+    }
+    cache.lvl_beg.push_back((int)cache.all.size());
+    (void)hipMalloc((void **)&cache.d_leaves, cache.plan.leaves.size() * sizeof(Leaf) + 64);
+    (void)hipMalloc((void **)&cache.d_merges, cache.all.size() * sizeof(Merge) + 64);
+    (void)hipMemcpy(cache.d_leaves, cache.plan.leaves.data(), cache.plan.leaves.size() * sizeof(Leaf),
+                    hipMemcpyHostToDevice);
+    if (!cache.all.empty())
+      (void)hipMemcpy(cache.d_merges, cache.all.data(), cache.all.size() * sizeof(Merge), hipMemcpyHostToDevice);
+    cache.n = n;
   }
-  lvl_beg.push_back((int)all.size());
-  (void)hipMemcpyAsync(d_leaves, plan.leaves.data(), plan.leaves.size() * sizeof(Leaf),
-                       hipMemcpyHostToDevice, s);
-  if (!all.empty()) {
-    (void)hipMemcpyAsync(b.merges, all.data(), all.size() * sizeof(Merge), hipMemcpyHostToDevice, s);
-  }
-  (void)hipStreamSynchronize(s);   // host vectors go out of scope; pageable copies are staged anyway
+  const Plan &plan = cache.plan;
+  const std::vector<Merge> &all = cache.all;
+  const std::vector<int> &lvl_beg = cache.lvl_beg;
+  d_leaves = cache.d_leaves;
+  b.merges = cache.d_merges;
 
   hipLaunchKernelGGL(dc_scale_kernel, dim3(1), dim3(256), 0, s, n, d, e, b);
   if (!all.empty())
