@@ -203,6 +203,74 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
   double *dout = b.d + off;
   int k = 0, ndf = 0, nrot = 0;
   const bool all_deflate = (rho * zm <= tol);
+
+  // ---- parallel fast path: when no two neighbouring surviving poles are close enough to be
+  // rotated together (the generic case) the scan has no loop-carried state, so deflation is a
+  // stream compaction: each thread owns a contiguous chunk, a block-level prefix sum places
+  // the outputs.  Any close pair sends the whole merge to the sequential DLAED2 scan below.
+  __shared__ int s_cnt[3][256], s_pre[3][256], s_last[256];
+  __shared__ int s_anyclose;
+  if (!all_deflate) {
+    const int per = (n + 255) / 256, i0 = t * per, i1 = (i0 + per < n) ? i0 + per : n;
+    int ct = 0, c1 = 0, c3 = 0, last = -1, first = -1;
+    bool close = false;
+    double dprev = 0.0, zprev = 0.0;
+    if (t == 0) s_anyclose = 0;
+    for (int i = i0; i < i1; ++i) {
+      const double zi = zs[i], di = ds[i];
+      if (rho * fabs(zi) <= tol) { ++ct; continue; }
+      if (perm[i] < mg.n1) ++c1; else ++c3;
+      if (last >= 0) close = close || (fabs((di - dprev) * zi * zprev) <= tol * (zi * zi + zprev * zprev));
+      else first = i;
+      last = i; dprev = di; zprev = zi;
+    }
+    s_cnt[0][t] = ct; s_cnt[1][t] = c1; s_cnt[2][t] = c3; s_last[t] = last;
+    __syncthreads();
+    if (first >= 0) {
+      int u = t - 1;
+      while (u >= 0 && s_last[u] < 0) --u;
+      if (u >= 0) {
+        const int pidx = s_last[u];
+        const double zi = zs[first], zp = zs[pidx];
+        close = close || (fabs((ds[first] - ds[pidx]) * zi * zp) <= tol * (zi * zi + zp * zp));
+      }
+    }
+    if (close) s_anyclose = 1;
+    __syncthreads();
+    if (!s_anyclose) {
+      if (t == 0) {
+        int a0 = 0, a1 = 0, a3 = 0;
+        for (int u = 0; u < 256; ++u) {
+          s_pre[0][u] = a0; s_pre[1][u] = a1; s_pre[2][u] = a3;
+          a0 += s_cnt[0][u]; a1 += s_cnt[1][u]; a3 += s_cnt[2][u];
+        }
+        s_cnt[0][0] = a0; s_cnt[1][0] = a1; s_cnt[2][0] = a3;   // totals
+      }
+      __syncthreads();
+      const int ntiny = s_cnt[0][0], k1f = s_cnt[1][0], k3f = s_cnt[2][0];
+      const int kf = n - ntiny;
+      int tt = s_pre[0][t], j1 = s_pre[1][t], j3 = s_pre[2][t];
+      int a = ((i0 < n) ? i0 : n) - tt;
+      for (int i = i0; i < i1; ++i) {
+        const double zi = zs[i], di = ds[i];
+        if (rho * fabs(zi) <= tol) { wcol[i] = n - 1 - tt; dout[n - 1 - tt] = di; ++tt; continue; }
+        const int g = (perm[i] < mg.n1) ? j1++ : k1f + j3++;
+        dl[a] = di; zl[a] = zi; spos[a] = i; grp[a] = g; wcol[i] = g; ++a;
+      }
+      if (t == 0) {
+        const long long o = off;
+        long long *go = b.goffs + 6 * (size_t)mi;
+        int *gd = b.gdims + 6 * (size_t)mi;
+        go[0] = o + o * b.ldw;                       go[1] = o + o * b.lds;        go[2] = o + o * b.ldq;
+        go[3] = o + mg.n1 + (o + k1f) * b.ldw;       go[4] = o + k1f + o * b.lds;  go[5] = o + mg.n1 + o * b.ldq;
+        gd[0] = mg.n1;        gd[1] = kf; gd[2] = k1f;
+        gd[3] = n - mg.n1;    gd[4] = kf; gd[5] = k3f;
+        b.k[mi] = kf; b.nrot[mi] = 0; b.rho[mi] = rho;
+      }
+      return;
+    }
+  }
+
   int pj = -1, tpj = 0;
   double dpj = 0.0, zpj = 0.0;
   for (int c0 = 0; c0 < n; c0 += CHUNK) {
