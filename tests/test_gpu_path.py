@@ -423,3 +423,21 @@ def test_non_finite_inputs_are_rejected_not_crashed(hip, oracle):
     ep, _ = hip.eigen_solver("general_hip", A, B)
     w_or, _, _, _ = oracle.solve(A, B)
     assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * np.abs(w_or).max()
+
+
+def test_descriptor_block_size_is_layout_only_on_1x1_grid(hip, golden_dir):
+    """BNZ30 on the reference's 2x2 grid runs with NB = 15 (block-shrink rule,
+    distribute_matrix.f90:114-120); on the 1x1 grid any NB describes the same column-major
+    array, so the result must not depend on it (`--block-size`, solver_main.f90:44-46)."""
+    A = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_A.mtx"))
+    B = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_B.mtx"))
+    ev = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ev.txt"))[:, 1]
+    ref = None
+    for nb in (None, 15, 1, 7, 64):
+        ep, _ = hip.eigen_solver("general_hip", A, B, block_size=nb)
+        assert np.abs(ep.values - ev).max() <= 1e-14
+        assert ep.desc[4] == (min(nb or 64, 30))
+        if ref is None:
+            ref = ep.Vectors.copy()
+        else:
+            assert np.array_equal(ep.Vectors, ref)     # bit-identical: NB never reaches a kernel
