@@ -441,3 +441,13 @@ def test_descriptor_block_size_is_layout_only_on_1x1_grid(hip, golden_dir):
             ref = ep.Vectors.copy()
         else:
             assert np.array_equal(ep.Vectors, ref)     # bit-identical: NB never reaches a kernel
+
+
+def test_bitwise_reproducible(hip, oracle):
+    """No atomics, fixed reduction orders: two solves of the same input give identical bits."""
+    n = 700
+    A = oracle.synth_matrix(n, 1); B = oracle.synth_matrix(n, 2)
+    ep1, _ = hip.eigen_solver("general_hip", A, B)
+    ep2, _ = hip.eigen_solver("general_hip", A, B)
+    assert np.array_equal(ep1.values, ep2.values)
+    assert np.array_equal(ep1.Vectors, ep2.Vectors)
