@@ -10,9 +10,12 @@ timed region, because the solve overwrites A and B as the reference does).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--order 16384] [--problem gep|sep]
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; this round every
-rank solves its own problem (replicas; the 2-D block-cyclic multi-GPU decomposition is the
-next row of SURVEY.md 8(e)) -- no data-path collective, "scaling": "weak".
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; by default every
+rank solves its own problem (replicas: independent problems sharded over ranks, no data-path
+collective, "scaling": "weak").  `--distribution columns` instead solves ONE problem on a
+1 x N process grid in replicated-input mode (reduction replicated on every rank, eigenvector
+columns sharded; still no collective; "scaling": "strong").  Distributing the reduction
+itself over the grid with RCCL is the remaining part of SURVEY.md 8(e), see DESIGN.md.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline"     : the dominant kernel (symv of the tridiagonalisation, HBM-bound), timed
@@ -21,6 +24,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                    same generator, rank 0 at N=1 only.
 """
 import argparse
+import numpy as np
 import ctypes
 import json
 import os
@@ -112,6 +116,14 @@ def main():
                     help="order of the CPU-oracle sample (scalar C port, 1 core)")
     ap.add_argument("--scalapack-sample-n", type=int, default=4096,
                     help="order of the ScaLAPACK-path sample (all physical cores)")
+    ap.add_argument("--distribution", choices=["replicas", "columns"], default="replicas",
+                    help="N>1 GPUs: 'replicas' = one independent problem per rank (weak scaling, default); "
+                         "'columns' = ONE problem on a 1 x N process grid in replicated-input mode "
+                         "(ek_hip_solve_device_grid: reduction replicated, eigenvector columns sharded; strong scaling)")
+    ap.add_argument("--virtual-grid", type=int, default=0,
+                    help="with --distribution columns on ONE GPU: play rank --virtual-rank of a 1 x P grid "
+                         "(the mode has no collective, so a rank's time does not depend on the others)")
+    ap.add_argument("--virtual-rank", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-symv-events", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
@@ -147,7 +159,16 @@ def main():
     K = args.steps
     dAs = [torch.empty((n, n), dtype=torch.float64, device=dev) for _ in range(K)]
     dBs = [torch.empty((n, n), dtype=torch.float64, device=dev) for _ in range(K)] if problem == 1 else None
-    dZ = torch.empty((n, n), dtype=torch.float64, device=dev)
+    columns = args.distribution == "columns"
+    NB = 64                                        # g_block_size (global_variables.f90:5)
+    if columns:
+        from eigenkernel_amd import descriptor as dsc
+        npcol, mycol = (args.virtual_grid, args.virtual_rank) if (world == 1 and args.virtual_grid > 0) else (world, rank)
+        my_cols = dsc.local_indices(n_vec, NB, mycol, npcol)
+        nc_loc = len(my_cols)
+    else:
+        npcol, mycol, nc_loc = 1, 0, n_vec
+    dZ = torch.empty((max(nc_loc, 1), n) if columns else (n, n), dtype=torch.float64, device=dev)  # column-major n x nc
     dw = torch.empty((n,), dtype=torch.float64, device=dev)
     stage = (ctypes.c_double * 8)()
     stage_sum = [0.0] * 8
@@ -158,9 +179,14 @@ def main():
             assert lib.ek_hip_synth_matrix_device(n, 2, dBs[i].data_ptr(), n) == 0
 
     def step(i, collect):
-        info = lib.ek_hip_solve_device(problem, n, n_vec, dAs[i].data_ptr(), n,
-                                       dBs[i].data_ptr() if problem == 1 else None, n,
-                                       dw.data_ptr(), dZ.data_ptr(), n, stage, 8)
+        if columns:
+            info = lib.ek_hip_solve_device_grid(problem, n, n_vec, dAs[i].data_ptr(), n,
+                                                dBs[i].data_ptr() if problem == 1 else None, n,
+                                                dw.data_ptr(), dZ.data_ptr(), n, NB, 1, npcol, 0, mycol, stage, 8)
+        else:
+            info = lib.ek_hip_solve_device(problem, n, n_vec, dAs[i].data_ptr(), n,
+                                           dBs[i].data_ptr() if problem == 1 else None, n,
+                                           dw.data_ptr(), dZ.data_ptr(), n, stage, 8)
         if info != 0:
             raise RuntimeError("ek_hip_solve_device info=%d" % info)
         if collect:
@@ -203,14 +229,17 @@ def main():
     w = dw.cpu().numpy()
     assert (w[1:n_vec] >= w[:n_vec - 1]).all() and abs(w[:n_vec]).max() < 1e6
     parity = None
-    if not args.no_parity_check:
+    if not args.no_parity_check and nc_loc > 0:
         regenerate(0)
         an, ave, mx, orth = (ctypes.c_double(0) for _ in range(4))
-        rc = lib.ek_hip_residual_device(problem, n, n_vec, dAs[0].data_ptr(), n,
-                                        dBs[0].data_ptr() if problem == 1 else None, n, dw.data_ptr(),
+        dwc = dw
+        if columns:      # this rank's eigenpairs: its block-cyclic columns and their eigenvalues
+            dwc = torch.from_numpy(np.ascontiguousarray(w[my_cols])).to(dev)
+        rc = lib.ek_hip_residual_device(problem, n, nc_loc, dAs[0].data_ptr(), n,
+                                        dBs[0].data_ptr() if problem == 1 else None, n, dwc.data_ptr(),
                                         dZ.data_ptr(), n, ctypes.byref(an), ctypes.byref(ave), ctypes.byref(mx))
         assert rc == 0, rc
-        rc = lib.ek_hip_orthogonality_device(problem, n, 1, n_vec, dBs[0].data_ptr() if problem == 1 else None, n,
+        rc = lib.ek_hip_orthogonality_device(problem, n, 1, nc_loc, dBs[0].data_ptr() if problem == 1 else None, n,
                                              dZ.data_ptr(), n, ctypes.byref(orth))
         assert rc == 0, rc
         parity = {"A_norm": an.value, "residual_norm_average": ave.value, "residual_norm_max": mx.value,
@@ -220,21 +249,24 @@ def main():
         assert orth.value <= parity["bounds"]["orthogonality"], parity
 
     if rank == 0:
-        value = world * n_vec * K / total
+        value = (1 if columns else world) * n_vec * K / total
         out = {
             "metric": ("eigenpairs/s (full spectrum) + achieved fp64 TFLOP/s vs roofline, N=16384 GEP"
                        if (n == 16384 and problem == 1 and n_vec == n) else
                        ("eigenpairs/s (full spectrum)" if n_vec == n else "eigenpairs/s (lowest n_vec)")),
             "value": value, "unit": "eigenpairs/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": 1e3 * total / K, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * total / K, "higher_is_better": True,
+            "scaling": "strong" if columns else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic dense SPD pair (SURVEY 8(d), seeds 1,2) N=%d %s, "
                                    "full spectrum, 1 problem per GPU" % (n, "generalized EVP (Cholesky+reduce+SEP)"
                                                                          if problem == 1 else "standard EVP"),
                        "n": n, "problem": args.problem, "n_vec": n_vec,
-                       "parallelism": "replicas x%d" % world if world > 1 else "1 GPU"},
-            "tflops_equiv": world * flops(problem, n, n_vec) * K / total / 1e12,
+                       "parallelism": ("1 x %d process grid, replicated inputs, eigenvector columns sharded "
+                                       "(rank %d%s)" % (npcol, mycol, ", played on one GPU" if world == 1 else "")
+                                       if columns else "replicas x%d" % world if world > 1 else "1 GPU")},
+            "tflops_equiv": (1 if columns else world) * flops(problem, n, n_vec) * K / total / 1e12,
             "fp64_mfma_peak_tflops": FP64_MFMA_PEAK_TFLOPS,
             "stage_seconds_per_step": {lib.ek_hip_stage_name(i).decode(): stage_sum[i] / K for i in range(8)},
             "parity": parity,

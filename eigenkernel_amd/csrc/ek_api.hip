@@ -7,6 +7,7 @@
 #include "ek_common.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -68,7 +69,8 @@ inline size_t al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
 // descriptor checks for the 1x1 grid this round implements; returns 0 or the LAPACK-style
 // 100*argpos + field code ScaLAPACK uses (-(argpos*100 + field)).
-int check_desc(const int *desc, int argpos, int m, int n) {
+int check_desc(const int *desc, int argpos, int m, int n, int lld_rows = -1) {
+  if (lld_rows < 0) lld_rows = m;
   if (!desc) return -argpos;
   if (desc[0] != 1) return -(argpos * 100 + 1);
   if (desc[2] != m) return -(argpos * 100 + 3);
@@ -76,11 +78,28 @@ int check_desc(const int *desc, int argpos, int m, int n) {
   if (desc[4] < 1 || desc[4] != desc[5]) return -(argpos * 100 + 5);
   if (desc[6] != 0) return -(argpos * 100 + 7);
   if (desc[7] != 0) return -(argpos * 100 + 8);
-  if (desc[8] < (m > 1 ? m : 1)) return -(argpos * 100 + 9);
+  if (desc[8] < (lld_rows > 1 ? lld_rows : 1)) return -(argpos * 100 + 9);
   return 0;
 }
 
-inline int pad_ld(int n) { return round_up(n > 0 ? n : 1, 128); }
+// NUMROC with source process 0: rows/columns of an n-long dimension (blocks nb) owned by `me` of `np`
+int numroc0(int n, int nb, int me, int np) {
+  const int nblocks = n / nb;
+  int num = (nblocks / np) * nb;
+  const int extra = nblocks % np;
+  if (me < extra) num += nb;
+  else if (me == extra) num += n % nb;
+  return num;
+}
+
+// Owner cell of a process grid for the replicated-input mode (ek_hip_solve_replicated)
+struct GridCell { int nb, nprow, npcol, myrow, mycol; };
+
+inline int pad_ld(int n) {
+  static int extra = -1;
+  if (extra < 0) { const char *e = getenv("EK_HIP_LDPAD"); extra = e ? atoi(e) : 0; }
+  return round_up(n > 0 ? n : 1, 128) + extra;
+}
 
 int h2d_matrix(int m, int n, const double *h, int ldh, double *d, int ldd, hipStream_t s) {
   EK_HIP_CHECK(hipMemcpy2DAsync(d, (size_t)ldd * sizeof(double), h, (size_t)ldh * sizeof(double),
@@ -470,12 +489,20 @@ struct StageTimer {
 
 // Runs the path on user device arrays dA, dB, dZ (column-major, any ld >= n) by way of padded
 // internal work arrays (ld multiple of 128, zero padding), so the kernels see aligned tiles.
+//
+// cell == nullptr: dZ receives the first n_vec eigenvectors (n x n_vec).  Otherwise the reduction
+// and the tridiagonal eigenproblem are computed as usual (replicated on every rank) and only the
+// eigenvector columns this grid cell owns are back-transformed; dZ receives the local
+// block-cyclic piece numroc(n, nb, myrow, nprow) x numroc(n_vec, nb, mycol, npcol).
 int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
-                        double *dw, double *dZ, int ldz, double *stage_seconds, int n_stages) {
+                        double *dw, double *dZ, int ldz, double *stage_seconds, int n_stages,
+                        const GridCell *cell = nullptr) {
   hipStream_t s = g_ctx.stream;
   const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
+  const int nc_loc = cell ? numroc0(n_vec, cell->nb, cell->mycol, cell->npcol) : n_vec;
+  const int nr_loc = cell ? numroc0(n, cell->nb, cell->myrow, cell->nprow) : n;
   const size_t wb_sytrd = sytrd_work_bytes(n), wb_stedc = stedc_work_bytes(n),
-               wb_ormtr = ormtr_work_bytes(n, n_vec);
+               wb_ormtr = ormtr_work_bytes(n, nc_loc);
   const size_t mat = al((size_t)ld * ld * 8);
   size_t scratch = wb_sytrd;
   if (wb_stedc > scratch) scratch = wb_stedc;
@@ -483,8 +510,10 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   const size_t trsm_work = al((size_t)128 * ld * 8);
   void *ws;
   const size_t sygst_scr = (problem == 1) ? al(sygst_scratch_doubles(n) * 8) : 0;
-  int rc = workspace(4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
-                     4 * al((size_t)ld * 8) + sygst_scr, &ws);
+  int rc = 0;
+  const size_t sel = cell ? al((size_t)ld * (nc_loc > 0 ? nc_loc : 1) * 8) : 0;
+  rc = workspace(4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
+                     4 * al((size_t)ld * 8) + sygst_scr + sel, &ws);
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
   double *wA = a.get<double>((size_t)ld * ld);
@@ -496,6 +525,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   char *work = a.get<char>(scratch);
   double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
   double *sscr = (problem == 1) ? a.get<double>(sygst_scratch_doubles(n)) : nullptr;
+  double *wS = cell ? a.get<double>((size_t)ld * (nc_loc > 0 ? nc_loc : 1)) : nullptr;
 
   StageTimer tm;
   const bool timing = stage_seconds && n_stages > 0;
@@ -541,15 +571,23 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   mark();                                                              // 4
   stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1);
   mark();                                                              // 5
-  ormtr_lower(s, n, n_vec, wV, ld, dt, wZ, ld, work);
+  // eigenvector columns to back-transform: the first n_vec, or this grid cell's share of them
+  // (columns of Z are independent in both remaining stages)
+  double *zc = wZ;
+  if (cell) {
+    gather_block_cyclic(s, n, nc_loc, wZ, ld, cell->nb, 1, 0, cell->npcol, cell->mycol, wS, ld);
+    zc = wS;
+  }
+  ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work);
   mark();                                                              // 6
-  if (problem == 1) trsm_llt(s, n, n_vec, wB, ld, dInv, wZ, ld, twork);
+  if (problem == 1) trsm_llt(s, n, nc_loc, wB, ld, dInv, zc, ld, twork);
   mark();                                                              // 7
   // stage-out: eigenvalues, eigenvectors, and the in-place results the reference leaves
   // behind (L in B, reflectors in A)
   if (sigma != 1.0) scale_vector(s, n, 1.0 / sigma, dwv);
   EK_HIP_CHECK(hipMemcpyAsync(dw, dwv, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-  copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
+  if (cell) gather_block_cyclic(s, nr_loc, nc_loc, zc, ld, cell->nb, cell->nprow, cell->myrow, 1, 0, dZ, ldz);
+  else copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
   copy_matrix(s, n, n, wA, ld, dA, lda);
   if (problem == 1) copy_matrix(s, n, n, wB, ld, dB, ldb);
   mark();                                                              // 8
@@ -594,6 +632,91 @@ int ek_hip_solve_device(int problem, int n, int n_vec, double *dA, int lda, doub
   if (n == 0) return 0;
   std::lock_guard<std::mutex> lk(g_mu);
   return solve_device_locked(problem, n, n_vec, dA, lda, dB, ldb, dw, dZ, ldz, stage_seconds, n_stages);
+}
+
+int ek_hip_solve_device_grid(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
+                             double *dw, double *dZ_loc, int ldz_loc, int nb, int nprow, int npcol,
+                             int myrow, int mycol, double *stage_seconds, int n_stages) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_vec < 0 || n_vec > n) return -3;
+  if (n > 0 && !dA) return -4;
+  if (lda < (n > 1 ? n : 1)) return -5;
+  if (problem == 1 && n > 0 && !dB) return -6;
+  if (problem == 1 && ldb < (n > 1 ? n : 1)) return -7;
+  if (n > 0 && !dw) return -8;
+  if (n > 0 && !dZ_loc) return -9;
+  if (nb < 1) return -11;
+  if (nprow < 1) return -12;
+  if (npcol < 1) return -13;
+  if (myrow < 0 || myrow >= nprow) return -14;
+  if (mycol < 0 || mycol >= npcol) return -15;
+  const int nr_loc = numroc0(n, nb, myrow, nprow);
+  if (ldz_loc < (nr_loc > 1 ? nr_loc : 1)) return -10;
+  int rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const GridCell cell{nb, nprow, npcol, myrow, mycol};
+  return solve_device_locked(problem, n, n_vec, dA, lda, dB, ldb, dw, dZ_loc, ldz_loc, stage_seconds,
+                             n_stages, &cell);
+}
+
+int ek_hip_solve_replicated(int problem, int n, int n_vec, double *A, int lda, double *B, int ldb,
+                            double *w, double *Z_loc, const int desc_Z[9], int nprow, int npcol,
+                            int myrow, int mycol, double *stage_seconds, int n_stages) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_vec < 0 || n_vec > n) return -3;
+  if (n > 0 && !A) return -4;
+  if (lda < (n > 1 ? n : 1)) return -5;
+  if (problem == 1 && n > 0 && !B) return -6;
+  if (problem == 1 && ldb < (n > 1 ? n : 1)) return -7;
+  if (n > 0 && !w) return -8;
+  if (n > 0 && !Z_loc) return -9;
+  if (nprow < 1) return -11;
+  if (npcol < 1) return -12;
+  if (myrow < 0 || myrow >= nprow) return -13;
+  if (mycol < 0 || mycol >= npcol) return -14;
+  if (!desc_Z) return -10;
+  if (desc_Z[4] < 1) return -(10 * 100 + 5);
+  const int nb = desc_Z[4];
+  const int nr_loc = numroc0(n, nb, myrow, nprow), nc_loc = numroc0(n_vec, nb, mycol, npcol);
+  int rc = check_desc(desc_Z, 10, n, n, nr_loc); if (rc) return rc;
+  rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
+  const size_t nn = (size_t)n * n * 8;
+  const int ldzl = nr_loc > 1 ? nr_loc : 1;
+  auto t0 = std::chrono::steady_clock::now();
+  EK_HIP_CHECK(hipMalloc((void **)&uA, nn));
+  EK_HIP_CHECK(hipMalloc((void **)&uZ, (size_t)ldzl * (nc_loc > 0 ? nc_loc : 1) * 8));
+  EK_HIP_CHECK(hipMalloc((void **)&uw, (size_t)n * 8));
+  if (problem == 1) EK_HIP_CHECK(hipMalloc((void **)&uB, nn));
+  rc = h2d_matrix(n, n, A, lda, uA, n, s);
+  if (!rc && problem == 1) rc = h2d_matrix(n, n, B, ldb, uB, n, s);
+  if (!rc) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc = -1000 - (int)e; }
+  auto t1 = std::chrono::steady_clock::now();
+  int info = rc;
+  const GridCell cell{nb, nprow, npcol, myrow, mycol};
+  if (!rc) info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, ldzl, stage_seconds, n_stages, &cell);
+  auto t2 = std::chrono::steady_clock::now();
+  if (info > -1000) {
+    int rc2 = 0;
+    if (nr_loc > 0 && nc_loc > 0) rc2 = d2h_matrix(nr_loc, nc_loc, uZ, ldzl, Z_loc, desc_Z[8], s);
+    if (!rc2) rc2 = d2h_matrix(n, n, uA, n, A, lda, s);
+    if (!rc2 && problem == 1) rc2 = d2h_matrix(n, n, uB, n, B, ldb, s);
+    if (!rc2) { hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (rc2 && info == 0) info = rc2;
+  }
+  auto t3 = std::chrono::steady_clock::now();
+  (void)hipFree(uA); (void)hipFree(uZ); (void)hipFree(uw); if (uB) (void)hipFree(uB);
+  if (stage_seconds && n_stages > EK_STAGE_COPY)
+    stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() +
+                                    std::chrono::duration<double>(t3 - t2).count();
+  return info;
 }
 
 int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[9], double *B_loc,

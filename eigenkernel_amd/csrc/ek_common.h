@@ -57,6 +57,10 @@ void symmetrize_lower(hipStream_t s, int n, double *A, int lda);   // upper <- l
 void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, const int *perm,
                     double *dst, int ldd);                         // dst(:,j) = src(:,perm[j])
 
+// local piece of a block-cyclic matrix: dst (mr x nc local) <- src (global), owner (me_r, me_c)
+void gather_block_cyclic(hipStream_t s, int mr, int nc, const double *src, int lds, int nb, int pr,
+                         int me_r, int pc, int me_c, double *dst, int ldd);
+
 void maxabs_lower(hipStream_t s, int n, const double *A, int lda, double *partial /* 256 */);
 void scale_lower(hipStream_t s, int n, double alpha, double *A, int lda);
 void scale_vector(hipStream_t s, int n, double alpha, double *x);

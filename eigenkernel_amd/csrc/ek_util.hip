@@ -48,6 +48,21 @@ __global__ void gather_columns_kernel(int m, int n, const double *__restrict__ s
     dst[(size_t)i + (size_t)j * ldd] = src[(size_t)i + (size_t)perm[j] * lds];
 }
 
+// dst(lr, lc) = src(global row of local row lr, global column of local column lc) for the
+// block-cyclic owner (me_r, me_c) of a pr x pc grid, square blocks nb, source process (0,0)
+// (the map of distribute_matrix.f90:128-138 / ScaLAPACK INDXL2G).
+__global__ void bc_gather_kernel(int mr, int nc, const double *__restrict__ src, int lds, int nb,
+                                 int pr, int me_r, int pc, int me_c, double *__restrict__ dst,
+                                 int ldd) {
+  const int lr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lr >= mr) return;
+  const size_t gr = (size_t)((lr / nb) * pr + me_r) * nb + lr % nb;
+  for (int lc = blockIdx.y; lc < nc; lc += gridDim.y) {
+    const size_t gc = (size_t)((lc / nb) * pc + me_c) * nb + lc % nb;
+    dst[(size_t)lr + (size_t)lc * ldd] = src[gr + gc * lds];
+  }
+}
+
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ULL;
   unsigned long long z = x;
@@ -121,6 +136,13 @@ void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, con
   if (m <= 0 || n <= 0) return;
   hipLaunchKernelGGL(gather_columns_kernel, grid2d(m, n), dim3(256), 0, s, m, n, src, lds, perm,
                      dst, ldd);
+}
+
+void gather_block_cyclic(hipStream_t s, int mr, int nc, const double *src, int lds, int nb, int pr,
+                         int me_r, int pc, int me_c, double *dst, int ldd) {
+  if (mr <= 0 || nc <= 0) return;
+  hipLaunchKernelGGL(bc_gather_kernel, grid2d(mr, nc), dim3(256), 0, s, mr, nc, src, lds, nb, pr, me_r,
+                     pc, me_c, dst, ldd);
 }
 
 void synth_matrix(hipStream_t s, int n, unsigned long long seed, double *M, int ldm) {

@@ -58,3 +58,34 @@ def setup_distributed_matrix(rows, cols, nprow=1, npcol=1, myrow=0, mycol=0, blo
     desc = descinit(rows, cols, nb, nb, 0, 0, ctxt, local_rows)
     mat = np.zeros((local_rows, local_cols), dtype=np.float64, order="F")
     return desc, mat
+
+
+def local_to_global(l, nb, iproc, nprocs):
+    """0-based INDXL2G with source process 0: global index of local index l on process iproc."""
+    l = np.asarray(l)
+    return ((l // nb) * nprocs + iproc) * nb + l % nb
+
+
+def local_indices(n, nb, iproc, nprocs):
+    """Global indices (ascending) owned by process iproc along one block-cyclic dimension."""
+    return local_to_global(np.arange(numroc(n, nb, iproc, 0, nprocs)), nb, iproc, nprocs)
+
+
+def make_process_grid(rank, n_procs, nprow=None, npcol=None):
+    """processes.f90:17-36: row-major rank -> (myrow, mycol) on the layout_procs grid (or a given one)."""
+    if nprow is None or npcol is None:
+        nprow, npcol = layout_procs(n_procs)
+    if nprow * npcol != n_procs:
+        raise ValueError("grid %dx%d does not hold %d processes" % (nprow, npcol, n_procs))
+    return nprow, npcol, rank // npcol, rank % npcol
+
+
+def assemble_global(pieces, n_rows, n_cols, nb, nprow, npcol):
+    """Global matrix from the local block-cyclic pieces {(myrow, mycol): array} (test helper)."""
+    G = np.zeros((n_rows, n_cols), order="F")
+    for (pr, pc), loc in pieces.items():
+        ri = local_indices(n_rows, nb, pr, nprow)
+        ci = local_indices(n_cols, nb, pc, npcol)
+        if len(ri) and len(ci):
+            G[np.ix_(ri, ci)] = loc[:len(ri), :len(ci)]
+    return G

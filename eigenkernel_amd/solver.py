@@ -59,6 +59,10 @@ def load_library(path=None):
                                  c_int, c_int, c_int, c_int, _dp, c_int]),
         "ek_hip_solve_device": (c_int, [c_int, c_int, c_int, vp, c_int, vp, c_int, vp, vp, c_int,
                                         _dp, c_int]),
+        "ek_hip_solve_replicated": (c_int, [c_int, c_int, c_int, _dp, c_int, _dp, c_int, _dp, _dp, _ip,
+                                            c_int, c_int, c_int, c_int, _dp, c_int]),
+        "ek_hip_solve_device_grid": (c_int, [c_int, c_int, c_int, vp, c_int, vp, c_int, vp, vp, c_int,
+                                             c_int, c_int, c_int, c_int, c_int, _dp, c_int]),
         "ek_hip_potrf": (c_int, [c_int, _dp, _ip]),
         "ek_hip_sygst": (c_int, [c_int, _dp, _ip, _dp, _ip, _dp]),
         "ek_hip_sytrd": (c_int, [c_int, _dp, _ip, _dp, _dp, _dp]),
@@ -97,7 +101,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = (
     "ek_hip_version", "ek_hip_init", "ek_hip_finalize", "ek_hip_stage_name", "ek_hip_solve",
-    "ek_hip_solve_device", "ek_hip_potrf", "ek_hip_sygst", "ek_hip_sytrd", "ek_hip_stedc",
+    "ek_hip_solve_device", "ek_hip_solve_replicated", "ek_hip_solve_device_grid", "ek_hip_potrf", "ek_hip_sygst", "ek_hip_sytrd", "ek_hip_stedc",
     "ek_hip_ormtr", "ek_hip_trtrs", "ek_hip_dgemm", "ek_hip_malloc", "ek_hip_free",
     "ek_hip_memcpy_h2d", "ek_hip_memcpy_d2h", "ek_hip_synchronize", "ek_hip_synth_matrix_device",
     "ek_hip_profile_symv", "ek_hip_profile_symv_get", "ek_hip_debug_sytrd",
@@ -278,6 +282,9 @@ def eigen_solver(solver_type, matrix_A, matrix_B=None, n_vec=None, block_size=No
 
     matrix_A / matrix_B: SparseMat (replicated triplets, as the reference passes) or dense
     symmetric ndarrays.  Returns (eigenpairs: EigenpairsBlacs, proc: Process).
+    With a process grid larger than 1x1 (proc.n_procs_row x proc.n_procs_col, one rank per GPU)
+    every rank passes the same replicated matrices (main.f90:84-86) and receives its
+    block-cyclic piece of the eigenvectors (ek_hip_solve_replicated): no collective is issued.
     Raises SolverError where the reference terminates (info != 0 from the Cholesky,
     reduction or recovery stage), ValueError for an unknown solver
     ('eigen_solver: Unknown solver', solver_main.f90:98).
@@ -290,8 +297,7 @@ def eigen_solver(solver_type, matrix_A, matrix_B=None, n_vec=None, block_size=No
         raise ValueError("eigen_solver: matrix_B is required for %s" % solver_type)
     lib = load_library()
     proc = proc or Process()
-    if proc.n_procs_row * proc.n_procs_col != 1:
-        raise NotImplementedError("this round implements the 1x1 process grid")
+    gridded = proc.n_procs_row * proc.n_procs_col != 1
 
     def dense(m):
         return m.to_dense() if hasattr(m, "to_dense") else np.array(_farr(m), order="F", copy=True)
@@ -302,6 +308,23 @@ def eigen_solver(solver_type, matrix_A, matrix_B=None, n_vec=None, block_size=No
         if n_vec is not None and n_vec != n and not select:
             raise ValueError("-n is only legal for *_select solvers (command_argument.f90:186-200)")
         n_vec = n if not select or n_vec is None else n_vec
+    if gridded:
+        B = dense(matrix_B) if generalized else None
+        desc_Z, Z_loc = _d.setup_distributed_matrix(
+            n, n, proc.n_procs_row, proc.n_procs_col, proc.my_proc_row, proc.my_proc_col,
+            block_size=block_size, ctxt=proc.context)
+        w = np.zeros(n)
+        stage = np.zeros(N_STAGES)
+        info = lib.ek_hip_solve_replicated(
+            1 if generalized else 0, n, n_vec, _P(A), max(1, n), _P(B) if generalized else None,
+            max(1, n), _P(w), _P(Z_loc), _I(desc_Z), proc.n_procs_row, proc.n_procs_col,
+            proc.my_proc_row, proc.my_proc_col, _P(stage), N_STAGES)
+        if info != 0:
+            raise SolverError("eigen_solver(%s): libek_hip failed" % solver_type, info)
+        ep = EigenpairsBlacs(values=w, desc=desc_Z, Vectors=Z_loc, info=info)
+        ep.stage_seconds = {lib.ek_hip_stage_name(i).decode(): float(stage[i]) for i in range(N_STAGES)}
+        ep.n_vec = n_vec
+        return ep, proc
     # setup_distributed_matrix (distribute_matrix.f90:92-148) on the 1x1 grid
     desc_A, A_loc = _d.setup_distributed_matrix(n, n, block_size=block_size)
     A_loc[:, :] = A

@@ -81,6 +81,38 @@ int ek_hip_solve_device(int problem, int n, int n_vec,
                         double *dw, double *dZ, int ldz,
                         double *stage_seconds, int n_stages);
 
+/* Process grids larger than 1x1 (one rank per GPU): replicated-input mode.
+ * The reference broadcasts the global sparse matrices to every rank before the solver runs
+ * (main.f90:84-86, bcast_sparse_matrix), so every rank can build the full dense A (and B)
+ * locally, with no communication.  Each rank then computes the reduction and the
+ * tridiagonal eigenproblem redundantly (bitwise identical on every rank: fixed reduction
+ * orders, no atomics) and back-transforms / recovers only the eigenvector columns its grid
+ * cell owns -- the columns of Z are independent in PDORMTR and PDTRTRS.
+ * No data-path collective is needed; a 1 x P grid shards the last two stages P ways.
+ *   A, B    : host, full n x n (lda, ldb >= n), same in/out meaning as in ek_hip_solve,
+ *             every rank receives the reflectors / the factor L
+ *   w       : out: n doubles on every rank (eigenpairs%blacs%values is replicated)
+ *   Z_loc   : out: this rank's block-cyclic piece of the N x N eigenvector matrix,
+ *             numroc(n, NB, myrow, 0, nprow) x numroc(n_vec, NB, mycol, 0, npcol) entries valid,
+ *             layout of setup_distributed_matrix('Eigenvectors', ...) (distribute_matrix.f90:92-148,
+ *             solver_scalapack_all.f90:80-81); NB = desc_Z[4] = desc_Z[5]
+ *   grid    : nprow x npcol, this rank at (myrow, mycol), row-major ranks (processes.f90:23)
+ * info as ek_hip_solve (argument numbering of this prototype). */
+int ek_hip_solve_replicated(int problem, int n, int n_vec,
+                            double *A, int lda, double *B, int ldb,
+                            double *w,
+                            double *Z_loc, const int desc_Z[9],
+                            int nprow, int npcol, int myrow, int mycol,
+                            double *stage_seconds, int n_stages);
+
+/* The same with A, B resident in this rank's HBM; dZ_loc (ldz_loc >= local rows) receives the
+ * local block-cyclic piece for square blocks nb. */
+int ek_hip_solve_device_grid(int problem, int n, int n_vec,
+                             double *dA, int lda, double *dB, int ldb,
+                             double *dw, double *dZ_loc, int ldz_loc,
+                             int nb, int nprow, int npcol, int myrow, int mycol,
+                             double *stage_seconds, int n_stages);
+
 /* Stage-level entry points: one per ScaLAPACK call of the reference, host arrays,
  * 1x1 grid descriptors.  They exist so the path can be replaced (and tested) call by call. */
 /* PDPOTRF('L', n, B, 1, 1, desc_B, info)        generalized_to_standard.f90:24 */

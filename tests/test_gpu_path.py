@@ -451,3 +451,59 @@ def test_bitwise_reproducible(hip, oracle):
     ep2, _ = hip.eigen_solver("general_hip", A, B)
     assert np.array_equal(ep1.values, ep2.values)
     assert np.array_equal(ep1.Vectors, ep2.Vectors)
+
+
+# ----------------------------------------------------------------------------- process grids
+# One GPU plays every rank of the grid in turn ("virtual ranks"): each call is exactly what
+# rank (myrow, mycol) would issue on its own GPU.  The pieces must assemble to the 1x1 result.
+@pytest.mark.parametrize("n,grid,nb,gep,n_vec", [
+    (300, (1, 4), 64, True, None),       # block-column cyclic, ragged last block
+    (256, (2, 2), 64, True, None),       # layout_procs(4)
+    (515, (2, 4), 64, False, None),      # layout_procs(8), standard problem, odd order
+    (200, (1, 3), 200, True, None),      # NB larger than n/P: shrink rule of setup_distributed_matrix
+    (640, (1, 8), 32, True, 100),        # *_select: only columns < n_vec, some ranks own few
+    (30, (2, 2), 64, True, None),        # config 1 of the reference: N=30 on 4 ranks -> NB=15
+])
+def test_process_grid_replicated_mode(hip, oracle, n, grid, nb, gep, n_vec):
+    from eigenkernel_amd import descriptor as d
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2) if gep else None
+    name = ("general_hip" if gep else "hip") + ("_select" if n_vec else "")
+    ref, _ = hip.eigen_solver(name, A, B, n_vec=n_vec)
+    k = n_vec or n
+    nprow, npcol = grid
+    pieces, nb_used = {}, None
+    for rank in range(nprow * npcol):
+        _, _, myrow, mycol = d.make_process_grid(rank, nprow * npcol, nprow, npcol)
+        proc = hip.Process(my_rank=rank, n_procs=nprow * npcol, n_procs_row=nprow, n_procs_col=npcol,
+                           my_proc_row=myrow, my_proc_col=mycol)
+        ep, _ = hip.eigen_solver(name, A, B, n_vec=n_vec, block_size=nb, proc=proc)
+        assert np.array_equal(ep.values, ref.values)           # replicated, bitwise
+        nb_used = int(ep.desc[d.BLOCK_ROW_])
+        assert ep.desc[d.LOCAL_ROWS_] == max(1, d.numroc(n, nb_used, myrow, 0, nprow))
+        pieces[(myrow, mycol)] = ep.Vectors
+    assert nb_used == min(nb, max(min(n // nprow, n // npcol), 1))   # distribute_matrix.f90:114-120
+    Zg = d.assemble_global(pieces, n, n, nb_used, nprow, npcol)
+    # every rank back-transforms its own columns with the same K order: identical bits expected;
+    # the tolerance is only the fallback statement of parity
+    if not np.array_equal(Zg[:, :k], ref.Vectors[:, :k]):
+        assert np.abs(Zg[:, :k] - ref.Vectors[:, :k]).max() <= 1e-13
+    _check_pairs(A, B, ref.values, Zg, k)
+
+
+def test_process_grid_argument_errors(hip, oracle):
+    from eigenkernel_amd import descriptor as d
+    lib = hip.load_library()
+    n = 64
+    A = oracle.synth_matrix(n, 1)
+    w = np.zeros(n)
+    desc, Z = d.setup_distributed_matrix(n, n, 1, 2, 0, 1)
+    P, I = hip._P, hip._I
+    call = lambda *g: lib.ek_hip_solve_replicated(0, n, n, P(A.copy(order="F")), n, None, n, P(w), P(Z), I(desc), *g, None, 0)
+    assert call(0, 2, 0, 0) == -11
+    assert call(1, 0, 0, 0) == -12
+    assert call(1, 2, 1, 0) == -13
+    assert call(1, 2, 0, 2) == -14
+    bad = desc.copy(); bad[d.LOCAL_ROWS_] = n - 1
+    assert lib.ek_hip_solve_replicated(0, n, n, P(A.copy(order="F")), n, None, n, P(w), P(Z), I(bad), 1, 2, 0, 1, None, 0) == -1009
+    assert lib.ek_hip_solve_replicated(0, n, n, P(A.copy(order="F")), n - 1, None, n, P(w), P(Z), I(desc), 1, 2, 0, 1, None, 0) == -5

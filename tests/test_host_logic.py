@@ -124,6 +124,22 @@ def test_argument_validation_without_gpu():
     assert lib.ek_hip_solve(1, 4, 5, dp, ip, dp, ip, dp, dp, ip, 1, 1, 0, 0, None, 0) == -3
     assert lib.ek_hip_solve(1, 4, 4, dp, ip, dp, ip, dp, dp, ip, 2, 1, 0, 0, None, 0) == -11
     assert lib.ek_hip_dgemm(0, 0, 4, 4, -1, 1.0, dp, 4, dp, 4, 0.0, dp, 4, 0) == -5
+    # replicated-input mode for larger grids: full A (lda), Z by descriptor, grid cell checked
+    dz = dsc.descinit(4, 4, 2, 2, 0, 0, 0, 2)
+    iz = dz.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    rep = lib.ek_hip_solve_replicated
+    assert rep(0, 4, 4, dp, 3, None, 4, dp, dp, iz, 2, 2, 0, 0, None, 0) == -5
+    assert rep(1, 4, 4, dp, 4, None, 4, dp, dp, iz, 2, 2, 0, 0, None, 0) == -6
+    assert rep(0, 4, 4, dp, 4, None, 4, dp, dp, iz, 0, 2, 0, 0, None, 0) == -11
+    assert rep(0, 4, 4, dp, 4, None, 4, dp, dp, iz, 2, 2, 2, 0, None, 0) == -13
+    assert rep(0, 4, 4, dp, 4, None, 4, dp, dp, iz, 2, 2, 0, -1, None, 0) == -14
+    dz1 = dz.copy(); dz1[8] = 1                   # lld below the local row count of cell (0,*)
+    assert rep(0, 4, 4, dp, 4, None, 4, dp, dp, dz1.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+               2, 2, 0, 0, None, 0) == -1009
+    grid = lib.ek_hip_solve_device_grid
+    assert grid(0, 4, 4, None, 4, None, 4, None, None, 4, 2, 1, 2, 0, 0, None, 0) == -4
+    assert grid(0, 4, 4, 1, 4, None, 4, 1, 1, 4, 0, 1, 2, 0, 0, None, 0) == -11
+    assert grid(0, 4, 4, 1, 4, None, 4, 1, 1, 1, 2, 1, 2, 0, 0, None, 0) == -10
 
 
 def test_solver_dispatch_rejects_unknown_and_missing_library(tmp_path):
@@ -162,6 +178,67 @@ def test_multi_rank_aggregation_gloo():
     assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
     for _, _, value, t in res:
         assert t == 2.0 and abs(value - 500 / 2.0) < 1e-12
+
+
+def test_block_cyclic_maps_partition_and_assemble():
+    """Ownership rule of distribute_matrix.f90:128-138: global (i, j) lives on
+    ((i / NB) mod P_r, (j / NB) mod P_c); local pieces tile the global matrix exactly once."""
+    rng = np.random.default_rng(3)
+    for n, nb, (pr, pc) in [(30, 15, (2, 2)), (100, 64, (1, 4)), (257, 32, (2, 4)), (7, 3, (3, 2))]:
+        G = rng.standard_normal((n, n))
+        seen = np.zeros(n, dtype=int)
+        for p in range(pc):
+            idx = dsc.local_indices(n, nb, p, pc)
+            assert len(idx) == dsc.numroc(n, nb, p, 0, pc)
+            assert all((g // nb) % pc == p for g in idx)
+            seen[idx] += 1
+        assert (seen == 1).all()
+        pieces = {}
+        for rank in range(pr * pc):
+            _, _, myrow, mycol = dsc.make_process_grid(rank, pr * pc, pr, pc)
+            assert rank == myrow * pc + mycol                    # row-major (processes.f90:23)
+            ri = dsc.local_indices(n, nb, myrow, pr); ci = dsc.local_indices(n, nb, mycol, pc)
+            pieces[(myrow, mycol)] = G[np.ix_(ri, ci)]
+        assert np.array_equal(dsc.assemble_global(pieces, n, n, nb, pr, pc), G)
+    assert dsc.make_process_grid(5, 8)[:2] == dsc.layout_procs(8) == (2, 4)
+    with pytest.raises(ValueError):
+        dsc.make_process_grid(0, 6, 4, 2)
+
+
+def _grid_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from eigenkernel_amd.parallel import grid_cell, owned_eigenvector_columns
+    n, n_vec, nb = 100, 37, 8
+    nprow, npcol, myrow, mycol = grid_cell(rank, world, columns_only=True)
+    cols = owned_eigenvector_columns(n_vec, nb, mycol, npcol)
+    out = [None] * world
+    dist.all_gather_object(out, (nprow, npcol, myrow, mycol, cols.tolist()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_column_sharding_of_eigenvectors_gloo():
+    """Replicated-input mode on a 1 x P grid: the ranks' eigenvector columns partition
+    [0, n_vec) with no overlap (world_size 2, gloo)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_grid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]
+    cells = res[0][1]
+    assert [(c[0], c[1], c[2], c[3]) for c in cells] == [(1, 2, 0, 0), (1, 2, 0, 1)]
+    allcols = sorted(cells[0][4] + cells[1][4])
+    assert allcols == list(range(37))
 
 
 def test_eigenvector_writer_formats(tmp_path):
