@@ -95,6 +95,70 @@ int numroc0(int n, int nb, int me, int np) {
 // Owner cell of a process grid for the replicated-input mode (ek_hip_solve_replicated)
 struct GridCell { int nb, nprow, npcol, myrow, mycol; };
 
+// Exchange hook for block-cyclically distributed inputs (ek_hip_set_allgatherv)
+ek_hip_allgatherv_fn g_allgatherv = nullptr;
+void *g_allgatherv_user = nullptr;
+
+// local piece (nr x nc, lld) <-> its place in the full matrix; blocks of nb rows are contiguous
+template <typename F>
+void for_each_local_block(int m, int n, int nb, int pr, int nprow, int pc, int npcol, F f) {
+  const int nr = numroc0(m, nb, pr, nprow), nc = numroc0(n, nb, pc, npcol);
+  for (int lc = 0; lc < nc; ++lc) {
+    const size_t gc = (size_t)((lc / nb) * npcol + pc) * nb + lc % nb;
+    for (int lr0 = 0; lr0 < nr; lr0 += nb) {
+      const size_t gr0 = (size_t)((lr0 / nb) * nprow + pr) * nb;
+      f(lr0, lc, gr0, gc, (nr - lr0 < nb) ? nr - lr0 : nb, nr);
+    }
+  }
+}
+
+// M_full (m x n, ldf) <- all ranks' pieces of a block-cyclic matrix, through the host hook.
+int gather_full(int m, int n, const double *M_loc, const int *desc, const GridCell &g, double *M_full,
+                int ldf) {
+  if (!g_allgatherv) return -998;
+  const int nb = desc[4], P = g.nprow * g.npcol;
+  std::vector<long long> counts(P), displs(P);
+  long long tot = 0;
+  for (int r = 0; r < P; ++r) {            // ranks in row-major grid order (processes.f90:23, 'R')
+    counts[r] = (long long)numroc0(m, nb, r / g.npcol, g.nprow) * numroc0(n, nb, r % g.npcol, g.npcol);
+    displs[r] = tot; tot += counts[r];
+  }
+  const int me = g.myrow * g.npcol + g.mycol;
+  double *send = (double *)malloc((size_t)(counts[me] > 0 ? counts[me] : 1) * 8);
+  double *recv = (double *)malloc((size_t)(tot > 0 ? tot : 1) * 8);
+  if (!send || !recv) { free(send); free(recv); return -1000 - (int)hipErrorOutOfMemory; }
+  const int lld = desc[8];
+  for_each_local_block(m, n, nb, g.myrow, g.nprow, g.mycol, g.npcol,
+                       [&](int lr0, int lc, size_t, size_t, int len, int nr) {
+                         memcpy(send + (size_t)lr0 + (size_t)lc * nr, M_loc + (size_t)lr0 + (size_t)lc * lld,
+                                (size_t)len * 8);
+                       });
+  const int rc = g_allgatherv(send, counts[me], recv, counts.data(), displs.data(), g_allgatherv_user);
+  if (rc == 0) {
+    for (int r = 0; r < P; ++r) {
+      const double *piece = recv + displs[r];
+      for_each_local_block(m, n, nb, r / g.npcol, g.nprow, r % g.npcol, g.npcol,
+                           [&](int lr0, int lc, size_t gr0, size_t gc, int len, int nr) {
+                             memcpy(M_full + gr0 + gc * (size_t)ldf, piece + (size_t)lr0 + (size_t)lc * nr,
+                                    (size_t)len * 8);
+                           });
+    }
+  }
+  free(send); free(recv);
+  return rc == 0 ? 0 : -999;
+}
+
+// M_loc <- this cell's piece of M_full
+void extract_local(int m, int n, const double *M_full, int ldf, const int *desc, const GridCell &g,
+                   double *M_loc) {
+  const int lld = desc[8];
+  for_each_local_block(m, n, desc[4], g.myrow, g.nprow, g.mycol, g.npcol,
+                       [&](int lr0, int lc, size_t gr0, size_t gc, int len, int) {
+                         memcpy(M_loc + (size_t)lr0 + (size_t)lc * lld, M_full + gr0 + gc * (size_t)ldf,
+                                (size_t)len * 8);
+                       });
+}
+
 inline int pad_ld(int n) {
   static int extra = -1;
   if (extra < 0) { const char *e = getenv("EK_HIP_LDPAD"); extra = e ? atoi(e) : 0; }
@@ -612,6 +676,45 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   return 0;
 }
 
+// Replicated host inputs (full A, B on every rank) -> this cell's block-cyclic piece of Z.
+int replicated_host_locked(int problem, int n, int n_vec, double *A, int lda, double *B, int ldb, double *w,
+                           double *Z_loc, int lldz, const GridCell &cell, double *stage_seconds,
+                           int n_stages) {
+  hipStream_t s = g_ctx.stream;
+  const int nr_loc = numroc0(n, cell.nb, cell.myrow, cell.nprow);
+  const int nc_loc = numroc0(n_vec, cell.nb, cell.mycol, cell.npcol);
+  double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
+  const size_t nn = (size_t)n * n * 8;
+  const int ldzl = nr_loc > 1 ? nr_loc : 1;
+  auto t0 = std::chrono::steady_clock::now();
+  EK_HIP_CHECK(hipMalloc((void **)&uA, nn));
+  EK_HIP_CHECK(hipMalloc((void **)&uZ, (size_t)ldzl * (nc_loc > 0 ? nc_loc : 1) * 8));
+  EK_HIP_CHECK(hipMalloc((void **)&uw, (size_t)n * 8));
+  if (problem == 1) EK_HIP_CHECK(hipMalloc((void **)&uB, nn));
+  int rc = h2d_matrix(n, n, A, lda, uA, n, s);
+  if (!rc && problem == 1) rc = h2d_matrix(n, n, B, ldb, uB, n, s);
+  if (!rc) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc = -1000 - (int)e; }
+  auto t1 = std::chrono::steady_clock::now();
+  int info = rc;
+  if (!rc) info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, ldzl, stage_seconds, n_stages, &cell);
+  auto t2 = std::chrono::steady_clock::now();
+  if (info > -1000) {
+    int rc2 = 0;
+    if (nr_loc > 0 && nc_loc > 0) rc2 = d2h_matrix(nr_loc, nc_loc, uZ, ldzl, Z_loc, lldz, s);
+    if (!rc2) rc2 = d2h_matrix(n, n, uA, n, A, lda, s);
+    if (!rc2 && problem == 1) rc2 = d2h_matrix(n, n, uB, n, B, ldb, s);
+    if (!rc2) { hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (rc2 && info == 0) info = rc2;
+  }
+  auto t3 = std::chrono::steady_clock::now();
+  (void)hipFree(uA); (void)hipFree(uZ); (void)hipFree(uw); if (uB) (void)hipFree(uB);
+  if (stage_seconds && n_stages > EK_STAGE_COPY)
+    stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() +
+                                    std::chrono::duration<double>(t3 - t2).count();
+  return info;
+}
+
 }  // namespace
 
 extern "C" {
@@ -632,6 +735,34 @@ int ek_hip_solve_device(int problem, int n, int n_vec, double *dA, int lda, doub
   if (n == 0) return 0;
   std::lock_guard<std::mutex> lk(g_mu);
   return solve_device_locked(problem, n, n_vec, dA, lda, dB, ldb, dw, dZ, ldz, stage_seconds, n_stages);
+}
+
+int ek_hip_set_allgatherv(ek_hip_allgatherv_fn fn, void *user) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_allgatherv = fn; g_allgatherv_user = user;
+  return 0;
+}
+
+// Pure host code (no GPU needed): the exchange step of ek_hip_solve for distributed inputs.
+int ek_hip_gather_matrix(int m, int n, const double *M_loc, const int desc[9], int nprow, int npcol,
+                         int myrow, int mycol, double *M_full, int ldf) {
+  if (m < 0) return -1;
+  if (n < 0) return -2;
+  if (m > 0 && n > 0 && !M_loc) return -3;
+  if (nprow < 1) return -5;
+  if (npcol < 1) return -6;
+  if (myrow < 0 || myrow >= nprow) return -7;
+  if (mycol < 0 || mycol >= npcol) return -8;
+  if (!desc) return -4;
+  if (desc[4] < 1) return -405;
+  int rc = check_desc(desc, 4, m, n, numroc0(m, desc[4], myrow, nprow)); if (rc) return rc;
+  if (m > 0 && n > 0 && !M_full) return -9;
+  if (ldf < (m > 1 ? m : 1)) return -10;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_allgatherv) return -998;
+  if (m == 0 || n == 0) return 0;
+  const GridCell cell{desc[4], nprow, npcol, myrow, mycol};
+  return gather_full(m, n, M_loc, desc, cell, M_full, ldf);
 }
 
 int ek_hip_solve_device_grid(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
@@ -679,44 +810,13 @@ int ek_hip_solve_replicated(int problem, int n, int n_vec, double *A, int lda, d
   if (mycol < 0 || mycol >= npcol) return -14;
   if (!desc_Z) return -10;
   if (desc_Z[4] < 1) return -(10 * 100 + 5);
-  const int nb = desc_Z[4];
-  const int nr_loc = numroc0(n, nb, myrow, nprow), nc_loc = numroc0(n_vec, nb, mycol, npcol);
-  int rc = check_desc(desc_Z, 10, n, n, nr_loc); if (rc) return rc;
+  int rc = check_desc(desc_Z, 10, n, n, numroc0(n, desc_Z[4], myrow, nprow)); if (rc) return rc;
   rc = ensure_init(); if (rc) return rc;
   if (n == 0) return 0;
   std::lock_guard<std::mutex> lk(g_mu);
-  hipStream_t s = g_ctx.stream;
-  double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
-  const size_t nn = (size_t)n * n * 8;
-  const int ldzl = nr_loc > 1 ? nr_loc : 1;
-  auto t0 = std::chrono::steady_clock::now();
-  EK_HIP_CHECK(hipMalloc((void **)&uA, nn));
-  EK_HIP_CHECK(hipMalloc((void **)&uZ, (size_t)ldzl * (nc_loc > 0 ? nc_loc : 1) * 8));
-  EK_HIP_CHECK(hipMalloc((void **)&uw, (size_t)n * 8));
-  if (problem == 1) EK_HIP_CHECK(hipMalloc((void **)&uB, nn));
-  rc = h2d_matrix(n, n, A, lda, uA, n, s);
-  if (!rc && problem == 1) rc = h2d_matrix(n, n, B, ldb, uB, n, s);
-  if (!rc) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc = -1000 - (int)e; }
-  auto t1 = std::chrono::steady_clock::now();
-  int info = rc;
-  const GridCell cell{nb, nprow, npcol, myrow, mycol};
-  if (!rc) info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, ldzl, stage_seconds, n_stages, &cell);
-  auto t2 = std::chrono::steady_clock::now();
-  if (info > -1000) {
-    int rc2 = 0;
-    if (nr_loc > 0 && nc_loc > 0) rc2 = d2h_matrix(nr_loc, nc_loc, uZ, ldzl, Z_loc, desc_Z[8], s);
-    if (!rc2) rc2 = d2h_matrix(n, n, uA, n, A, lda, s);
-    if (!rc2 && problem == 1) rc2 = d2h_matrix(n, n, uB, n, B, ldb, s);
-    if (!rc2) { hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
-    if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
-    if (rc2 && info == 0) info = rc2;
-  }
-  auto t3 = std::chrono::steady_clock::now();
-  (void)hipFree(uA); (void)hipFree(uZ); (void)hipFree(uw); if (uB) (void)hipFree(uB);
-  if (stage_seconds && n_stages > EK_STAGE_COPY)
-    stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() +
-                                    std::chrono::duration<double>(t3 - t2).count();
-  return info;
+  const GridCell cell{desc_Z[4], nprow, npcol, myrow, mycol};
+  return replicated_host_locked(problem, n, n_vec, A, lda, B, ldb, w, Z_loc, desc_Z[8], cell, stage_seconds,
+                                n_stages);
 }
 
 int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[9], double *B_loc,
@@ -726,21 +826,50 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
   if (n < 0) return -2;
   if (n_vec < 0 || n_vec > n) return -3;
   if (n > 0 && !A_loc) return -4;
-  int rc = check_desc(desc_A, 5, n, n); if (rc) return rc;
+  const bool cell_ok = nprow >= 1 && npcol >= 1 && myrow >= 0 && myrow < nprow;
+  auto rows_of = [&](const int *d) {   // local row count the descriptor's lld must cover
+    return (d && d[4] >= 1 && cell_ok) ? numroc0(n, d[4], myrow, nprow) : n;
+  };
+  int rc = check_desc(desc_A, 5, n, n, rows_of(desc_A)); if (rc) return rc;
   if (problem == 1) {
     if (n > 0 && !B_loc) return -6;
-    rc = check_desc(desc_B, 7, n, n); if (rc) return rc;
+    rc = check_desc(desc_B, 7, n, n, rows_of(desc_B)); if (rc) return rc;
   }
   if (n > 0 && !w) return -8;
   if (n > 0 && !Z_loc) return -9;
-  rc = check_desc(desc_Z, 10, n, n); if (rc) return rc;
-  if (nprow != 1) return -11;     // 1x1 grid this round
-  if (npcol != 1) return -12;
-  if (myrow != 0) return -13;
-  if (mycol != 0) return -14;
+  rc = check_desc(desc_Z, 10, n, n, rows_of(desc_Z)); if (rc) return rc;
+  // grids other than 1x1 need the host's exchange hook (ek_hip_set_allgatherv)
+  if (nprow != 1 && !(nprow > 1 && g_allgatherv)) return -11;
+  if (npcol != 1 && !(npcol > 1 && g_allgatherv)) return -12;
+  if (myrow < 0 || myrow >= nprow) return -13;
+  if (mycol < 0 || mycol >= npcol) return -14;
   rc = ensure_init(); if (rc) return rc;
   if (n == 0) return 0;
   std::lock_guard<std::mutex> lk(g_mu);
+  if (nprow * npcol > 1) {
+    // distributed inputs: assemble the full matrices on every rank through the hook, then
+    // proceed as in the replicated-input mode; A_loc / B_loc receive their pieces of the
+    // reflectors / of L, as every rank of the reference ends up with
+    const GridCell cell{desc_Z[4], nprow, npcol, myrow, mycol};
+    double *Af = (double *)malloc((size_t)n * n * 8);
+    double *Bf = problem == 1 ? (double *)malloc((size_t)n * n * 8) : nullptr;
+    int info = (!Af || (problem == 1 && !Bf)) ? -1000 - (int)hipErrorOutOfMemory : 0;
+    auto t0 = std::chrono::steady_clock::now();
+    if (!info) info = gather_full(n, n, A_loc, desc_A, cell, Af, n);
+    if (!info && problem == 1) info = gather_full(n, n, B_loc, desc_B, cell, Bf, n);
+    const double tg = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!info) {
+      info = replicated_host_locked(problem, n, n_vec, Af, n, Bf, n, w, Z_loc, desc_Z[8], cell,
+                                    stage_seconds, n_stages);
+      if (info > -1000) {
+        extract_local(n, n, Af, n, desc_A, cell, A_loc);
+        if (problem == 1) extract_local(n, n, Bf, n, desc_B, cell, B_loc);
+      }
+      if (stage_seconds && n_stages > EK_STAGE_GATHER) stage_seconds[EK_STAGE_GATHER] += tg;
+    }
+    free(Af); free(Bf);
+    return info;
+  }
   hipStream_t s = g_ctx.stream;
   // user-side device images (exact n x n); freed before returning: the library keeps nothing
   double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;

@@ -35,6 +35,10 @@ class LibraryMissing(RuntimeError):
 _lib = None
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
+_llp = ctypes.POINTER(ctypes.c_longlong)
+# ek_hip_allgatherv_fn (include/ek_hip.h)
+ALLGATHERV_FN = ctypes.CFUNCTYPE(ctypes.c_int, _dp, ctypes.c_longlong, _dp, _llp, _llp, ctypes.c_void_p)
+_hook_keepalive = None
 
 
 def load_library(path=None):
@@ -63,6 +67,8 @@ def load_library(path=None):
                                             c_int, c_int, c_int, c_int, _dp, c_int]),
         "ek_hip_solve_device_grid": (c_int, [c_int, c_int, c_int, vp, c_int, vp, c_int, vp, vp, c_int,
                                              c_int, c_int, c_int, c_int, c_int, _dp, c_int]),
+        "ek_hip_set_allgatherv": (c_int, [ALLGATHERV_FN, vp]),
+        "ek_hip_gather_matrix": (c_int, [c_int, c_int, _dp, _ip, c_int, c_int, c_int, c_int, _dp, c_int]),
         "ek_hip_potrf": (c_int, [c_int, _dp, _ip]),
         "ek_hip_sygst": (c_int, [c_int, _dp, _ip, _dp, _ip, _dp]),
         "ek_hip_sytrd": (c_int, [c_int, _dp, _ip, _dp, _dp, _dp]),
@@ -101,7 +107,8 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = (
     "ek_hip_version", "ek_hip_init", "ek_hip_finalize", "ek_hip_stage_name", "ek_hip_solve",
-    "ek_hip_solve_device", "ek_hip_solve_replicated", "ek_hip_solve_device_grid", "ek_hip_potrf", "ek_hip_sygst", "ek_hip_sytrd", "ek_hip_stedc",
+    "ek_hip_solve_device", "ek_hip_solve_replicated", "ek_hip_solve_device_grid",
+    "ek_hip_set_allgatherv", "ek_hip_gather_matrix", "ek_hip_potrf", "ek_hip_sygst", "ek_hip_sytrd", "ek_hip_stedc",
     "ek_hip_ormtr", "ek_hip_trtrs", "ek_hip_dgemm", "ek_hip_malloc", "ek_hip_free",
     "ek_hip_memcpy_h2d", "ek_hip_memcpy_d2h", "ek_hip_synchronize", "ek_hip_synth_matrix_device",
     "ek_hip_profile_symv", "ek_hip_profile_symv_get", "ek_hip_debug_sytrd",
@@ -167,6 +174,79 @@ def _desc_for(a, nb=None):
     m, n = a.shape
     nb = min(_d.g_block_size if nb is None else nb, max(min(m, n), 1))
     return _d.descinit(m, n, nb, nb, 0, 0, 0, max(1, a.strides[1] // 8 if n > 1 else m))
+
+
+# ----------------------------------------------------------------------------- exchange hook
+def set_allgatherv(fn):
+    """Registers the host exchange hook ek_hip_solve needs on grids larger than 1x1.
+
+    fn(send: ndarray[count], counts: list[int], displs: list[int]) -> ndarray[sum(counts)]
+    with MPI_Allgatherv semantics over the grid's ranks in row-major order; None removes it.
+    """
+    global _hook_keepalive
+    lib = load_library()
+    if fn is None:
+        lib.ek_hip_set_allgatherv(ctypes.cast(None, ALLGATHERV_FN), None)
+        _hook_keepalive = None
+        return
+
+    n_ranks = getattr(fn, "n_ranks", None)
+    if n_ranks is None:
+        raise ValueError("the hook must carry .n_ranks (number of ranks of the grid)")
+
+    def thunk(send, count, recv, counts, displs, _user):
+        try:
+            cs = [int(counts[r]) for r in range(n_ranks)]
+            ds = [int(displs[r]) for r in range(n_ranks)]
+            count = int(count)
+            sv = np.ctypeslib.as_array(send, shape=(max(count, 1),))[:count]
+            out = np.asarray(fn(sv, cs, ds), dtype=np.float64)
+            total = ds[-1] + cs[-1]
+            if out.shape != (total,):
+                return 2
+            np.ctypeslib.as_array(recv, shape=(max(total, 1),))[:total] = out
+            return 0
+        except Exception:                     # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    cb = ALLGATHERV_FN(thunk)
+    _hook_keepalive = (cb, thunk, fn)
+    lib.ek_hip_set_allgatherv(cb, None)
+
+
+def torch_allgatherv(dist, group=None):
+    """Exchange hook on torch.distributed host tensors (gloo in the CPU tests; with the nccl
+    backend pass a gloo side group): pads every piece to the largest and all-gathers."""
+    import torch
+    world = dist.get_world_size(group)
+
+    def fn(send, counts, displs):
+        mx = max(max(counts), 1)
+        mine = torch.zeros(mx, dtype=torch.float64)
+        mine[:send.shape[0]] = torch.from_numpy(np.ascontiguousarray(send))
+        parts = [torch.empty(mx, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        out = np.empty(displs[-1] + counts[-1])
+        for r in range(world):
+            out[displs[r]:displs[r] + counts[r]] = parts[r][:counts[r]].numpy()
+        return out
+
+    fn.n_ranks = world
+    return fn
+
+
+def gather_matrix(M_loc, desc, proc):
+    """ek_hip_gather_matrix: the full matrix from every rank's block-cyclic piece (host only)."""
+    lib = load_library()
+    m, n = int(desc[_d.ROWS_]), int(desc[_d.COLS_])
+    full = np.zeros((m, n), order="F")
+    info = lib.ek_hip_gather_matrix(m, n, _P(M_loc), _I(desc), proc.n_procs_row, proc.n_procs_col,
+                                    proc.my_proc_row, proc.my_proc_col, _P(full), max(1, m))
+    if info != 0:
+        raise SolverError("ek_hip_gather_matrix failed", info)
+    return full
 
 
 # ----------------------------------------------------------------------------- types
@@ -277,7 +357,8 @@ def dgemm(transa, transb, alpha, A, B, beta, C, lower_only=False):
 
 
 # ----------------------------------------------------------------------------- the dispatch
-def eigen_solver(solver_type, matrix_A, matrix_B=None, n_vec=None, block_size=None, proc=None):
+def eigen_solver(solver_type, matrix_A, matrix_B=None, n_vec=None, block_size=None, proc=None,
+                 inputs="replicated"):
     """eigen_solver (solver_main.f90:22-100) for the hip arms.
 
     matrix_A / matrix_B: SparseMat (replicated triplets, as the reference passes) or dense
@@ -285,6 +366,9 @@ def eigen_solver(solver_type, matrix_A, matrix_B=None, n_vec=None, block_size=No
     With a process grid larger than 1x1 (proc.n_procs_row x proc.n_procs_col, one rank per GPU)
     every rank passes the same replicated matrices (main.f90:84-86) and receives its
     block-cyclic piece of the eigenvectors (ek_hip_solve_replicated): no collective is issued.
+    inputs="distributed" reproduces the reference's own data flow instead: A and B are cut into
+    block-cyclic pieces (setup_distributed_matrix + distribute_global_sparse_matrix) and handed
+    to ek_hip_solve, which reassembles them through the hook of set_allgatherv().
     Raises SolverError where the reference terminates (info != 0 from the Cholesky,
     reduction or recovery stage), ValueError for an unknown solver
     ('eigen_solver: Unknown solver', solver_main.f90:98).
@@ -308,6 +392,34 @@ def eigen_solver(solver_type, matrix_A, matrix_B=None, n_vec=None, block_size=No
         if n_vec is not None and n_vec != n and not select:
             raise ValueError("-n is only legal for *_select solvers (command_argument.f90:186-200)")
         n_vec = n if not select or n_vec is None else n_vec
+    if gridded and inputs == "distributed":
+        g = (proc.n_procs_row, proc.n_procs_col, proc.my_proc_row, proc.my_proc_col)
+
+        def piece(M):
+            desc, loc = _d.setup_distributed_matrix(n, n, *g, block_size=block_size, ctxt=proc.context)
+            nb = int(desc[_d.BLOCK_ROW_])
+            ri = _d.local_indices(n, nb, g[2], g[0]); ci = _d.local_indices(n, nb, g[3], g[1])
+            if len(ri) and len(ci):
+                loc[:len(ri), :len(ci)] = M[np.ix_(ri, ci)]
+            return desc, loc
+
+        desc_A, A_loc = piece(A)
+        desc_B, B_loc = piece(dense(matrix_B)) if generalized else (None, None)
+        desc_Z, Z_loc = _d.setup_distributed_matrix(n, n, *g, block_size=int(desc_A[_d.BLOCK_ROW_]),
+                                                    ctxt=proc.context)
+        w = np.zeros(n)
+        stage = np.zeros(N_STAGES)
+        info = lib.ek_hip_solve(1 if generalized else 0, n, n_vec, _P(A_loc), _I(desc_A),
+                                _P(B_loc) if generalized else None,
+                                _I(desc_B) if generalized else None, _P(w), _P(Z_loc), _I(desc_Z),
+                                *g, _P(stage), N_STAGES)
+        if info != 0:
+            raise SolverError("eigen_solver(%s): libek_hip failed" % solver_type, info)
+        ep = EigenpairsBlacs(values=w, desc=desc_Z, Vectors=Z_loc, info=info)
+        ep.stage_seconds = {lib.ek_hip_stage_name(i).decode(): float(stage[i]) for i in range(N_STAGES)}
+        ep.n_vec = n_vec
+        ep.A_loc, ep.B_loc = A_loc, B_loc
+        return ep, proc
     if gridded:
         B = dense(matrix_B) if generalized else None
         desc_Z, Z_loc = _d.setup_distributed_matrix(

@@ -105,6 +105,27 @@ int ek_hip_solve_replicated(int problem, int n, int n_vec,
                             int nprow, int npcol, int myrow, int mycol,
                             double *stage_seconds, int n_stages);
 
+/* Distributed INPUTS on grids larger than 1x1 (the reference's own contract: A_loc, B_loc are
+ * the block-cyclic pieces setup_distributed_matrix / distribute_global_sparse_matrix produce,
+ * distribute_matrix.f90:92-148, 401-422).  The library has no communication layer of its own;
+ * the MPI host lends it one: a hook with the semantics of MPI_Allgatherv on doubles over the
+ * grid's ranks in row-major order (rank = myrow * npcol + mycol, processes.f90:23).  With the
+ * hook registered, ek_hip_solve accepts any nprow x npcol grid: it assembles the full A (and B)
+ * on every rank through the hook, continues as ek_hip_solve_replicated, and returns each
+ * rank's pieces of Z, of the reflectors (A_loc) and of L (B_loc); the exchange time is
+ * reported in stage_seconds[EK_STAGE_GATHER].  Without a hook such grids are refused
+ * (info = -11 / -12).  Hook return value: 0 on success (anything else -> info = -999).
+ * INTEGRATION.md shows the Fortran bind(C) wrapper around MPI_Allgatherv. */
+typedef int (*ek_hip_allgatherv_fn)(const double *send, long long count, double *recv,
+                                    const long long *counts, const long long *displs, void *user);
+int ek_hip_set_allgatherv(ek_hip_allgatherv_fn fn, void *user);   /* fn = NULL removes the hook */
+
+/* The exchange step alone (pure host code, no GPU involved): M_full (m x n, ldf) <- all ranks'
+ * block-cyclic pieces.  info = -998 when no hook is registered. */
+int ek_hip_gather_matrix(int m, int n, const double *M_loc, const int desc[9],
+                         int nprow, int npcol, int myrow, int mycol,
+                         double *M_full, int ldf);
+
 /* The same with A, B resident in this rank's HBM; dZ_loc (ldz_loc >= local rows) receives the
  * local block-cyclic piece for square blocks nb. */
 int ek_hip_solve_device_grid(int problem, int n, int n_vec,

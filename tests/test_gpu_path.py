@@ -507,3 +507,88 @@ def test_process_grid_argument_errors(hip, oracle):
     bad = desc.copy(); bad[d.LOCAL_ROWS_] = n - 1
     assert lib.ek_hip_solve_replicated(0, n, n, P(A.copy(order="F")), n, None, n, P(w), P(Z), I(bad), 1, 2, 0, 1, None, 0) == -1009
     assert lib.ek_hip_solve_replicated(0, n, n, P(A.copy(order="F")), n - 1, None, n, P(w), P(Z), I(desc), 1, 2, 0, 1, None, 0) == -5
+
+
+@pytest.mark.parametrize("n,grid,nb,gep,n_vec", [
+    (30, (2, 2), 64, True, None),        # config 1: N=30, np=4 -> NB=15, the reference's own CPU case
+    (300, (2, 4), 64, True, None),
+    (257, (1, 2), 32, False, None),
+    (256, (2, 2), 64, True, 40),
+])
+def test_process_grid_distributed_inputs(hip, oracle, n, grid, nb, gep, n_vec):
+    """ek_hip_solve with the reference's own data contract on an nprow x npcol grid: block-cyclic
+    pieces of A, B in, pieces of Z / reflectors / L out; the exchange goes through the host hook."""
+    from eigenkernel_amd import descriptor as d
+    from test_host_logic import virtual_allgatherv
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2) if gep else None
+    name = ("general_hip" if gep else "hip") + ("_select" if n_vec else "")
+    ref, _ = hip.eigen_solver(name, A, B, n_vec=n_vec)
+    # what the 1x1 call leaves in A (reflectors) and B (L): run it through the C-ABI once more
+    lib = hip.load_library()
+    desc1, A1 = d.setup_distributed_matrix(n, n); A1[:, :] = A
+    B1 = None
+    if gep:
+        _, B1 = d.setup_distributed_matrix(n, n); B1[:, :] = B
+    _, Z1 = d.setup_distributed_matrix(n, n)
+    w1 = np.zeros(n)
+    k = n_vec or n
+    assert lib.ek_hip_solve(1 if gep else 0, n, k, hip._P(A1), hip._I(desc1), hip._P(B1) if gep else None,
+                            hip._I(desc1) if gep else None, hip._P(w1), hip._P(Z1), hip._I(desc1),
+                            1, 1, 0, 0, None, 0) == 0
+    nprow, npcol = grid
+    nbu = int(d.setup_distributed_matrix(n, n, nprow, npcol, 0, 0, block_size=nb)[0][d.BLOCK_ROW_])
+    hook = virtual_allgatherv([A, B] if gep else [A], nbu, nprow, npcol)
+    hip.set_allgatherv(hook)
+    try:
+        Zp, Ap, Bp = {}, {}, {}
+        for rank in range(nprow * npcol):
+            hook.state["rank"] = rank
+            _, _, myrow, mycol = d.make_process_grid(rank, nprow * npcol, nprow, npcol)
+            proc = hip.Process(rank, nprow * npcol, 0, nprow, npcol, myrow, mycol)
+            ep, _ = hip.eigen_solver(name, A, B, n_vec=n_vec, block_size=nb, proc=proc, inputs="distributed")
+            assert np.array_equal(ep.values, ref.values)
+            assert ep.stage_seconds["eigen_solver_scalapack_all:gather1"] > 0.0
+            Zp[(myrow, mycol)] = ep.Vectors; Ap[(myrow, mycol)] = ep.A_loc
+            if gep:
+                Bp[(myrow, mycol)] = ep.B_loc
+        Zg = d.assemble_global(Zp, n, n, nbu, nprow, npcol)
+        if not np.array_equal(Zg[:, :k], ref.Vectors[:, :k]):
+            assert np.abs(Zg[:, :k] - ref.Vectors[:, :k]).max() <= 1e-13
+        _check_pairs(A, B, ref.values, Zg, k)
+        assert np.array_equal(d.assemble_global(Ap, n, n, nbu, nprow, npcol), A1)     # reflectors, d, e
+        if gep:
+            assert np.array_equal(np.tril(d.assemble_global(Bp, n, n, nbu, nprow, npcol)), np.tril(B1))  # L
+    finally:
+        hip.set_allgatherv(None)
+
+
+@pytest.mark.parametrize("inputs", ["replicated", "distributed"])
+def test_golden_bnz30_on_the_reference_grid(hip, golden_dir, inputs):
+    """config C1 as the reference runs it: `mpirun -np 4 ... -s general_scalapack` -> 2x2 grid,
+    NB shrunk to 15 (distribute_matrix.f90:114-120); every rank's call is played on the one GPU."""
+    from eigenkernel_amd import descriptor as d
+    from test_host_logic import virtual_allgatherv
+    A = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_A.mtx"))
+    B = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_B.mtx"))
+    ev = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ev.txt"))[:, 1]
+    ipr = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_ipr.txt"))[:, 1]
+    nprow, npcol = d.layout_procs(4)
+    assert (nprow, npcol) == (2, 2)
+    hook = virtual_allgatherv([A.to_dense(), B.to_dense()], 15, nprow, npcol)
+    hip.set_allgatherv(hook if inputs == "distributed" else None)
+    try:
+        pieces = {}
+        for rank in range(4):
+            hook.state["rank"] = rank
+            _, _, myrow, mycol = d.make_process_grid(rank, 4)
+            ep, _ = hip.eigen_solver("general_hip", A, B, proc=hip.Process(rank, 4, 0, nprow, npcol, myrow, mycol),
+                                     inputs=inputs)
+            assert int(ep.desc[d.BLOCK_ROW_]) == 15 and ep.Vectors.shape == (15, 15)
+            assert np.abs(ep.values - ev).max() <= 1e-14
+            pieces[(myrow, mycol)] = ep.Vectors
+        Z = d.assemble_global(pieces, 30, 30, 15, nprow, npcol)
+        _check_pairs(A.to_dense(), B.to_dense(), ev, Z)
+        assert np.abs(get_ipratios(Z, B.to_dense()) - ipr).max() <= 1e-6
+    finally:
+        hip.set_allgatherv(None)

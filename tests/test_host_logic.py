@@ -257,3 +257,111 @@ def test_eigenvector_writer_formats(tmp_path):
     raw = (tmp_path / "00000005.dat").read_bytes()
     assert len(raw) == 248
     assert np.array_equal(np.frombuffer(raw[4:-4], dtype=np.float64), Z[:, 4])
+
+
+# ----------------------------------------------------------------------------- exchange hook
+def _packed_pieces(G, nb, nprow, npcol):
+    """Every rank's block-cyclic piece of G, column-major, in row-major rank order."""
+    out = []
+    for rank in range(nprow * npcol):
+        pr, pc = rank // npcol, rank % npcol
+        ri = dsc.local_indices(G.shape[0], nb, pr, nprow); ci = dsc.local_indices(G.shape[1], nb, pc, npcol)
+        out.append(G[np.ix_(ri, ci)].flatten(order="F"))
+    return out
+
+
+def virtual_allgatherv(mats, nb, nprow, npcol):
+    """Exchange hook for ONE process that plays every rank in turn: call k serves the pieces of
+    mats[k % len(mats)] and checks that the caller sent exactly its own piece."""
+    state = {"k": 0, "rank": 0}
+
+    def fn(send, counts, displs):
+        pieces = _packed_pieces(mats[state["k"] % len(mats)], nb, nprow, npcol)
+        state["k"] += 1
+        assert [len(p) for p in pieces] == counts
+        assert displs == [int(x) for x in np.cumsum([0] + counts[:-1])]
+        assert np.array_equal(send, pieces[state["rank"]])
+        return np.concatenate(pieces) if pieces else np.zeros(0)
+
+    fn.n_ranks = nprow * npcol
+    fn.state = state
+    return fn
+
+
+def test_gather_matrix_through_hook_single_process():
+    """ek_hip_gather_matrix is pure host code: block-cyclic pieces -> full matrix on every rank."""
+    rng = np.random.default_rng(11)
+    lib = solver.load_library()
+    try:
+        for m, nb, (pr, pc) in [(30, 15, (2, 2)), (37, 8, (1, 2)), (100, 64, (2, 4)), (9, 2, (3, 1)), (5, 7, (1, 1))]:
+            G = np.asfortranarray(rng.standard_normal((m, m)))
+            nb = int(dsc.setup_distributed_matrix(m, m, pr, pc, 0, 0, block_size=nb)[0][dsc.BLOCK_ROW_])
+            hook = virtual_allgatherv([G], nb, pr, pc)
+            solver.set_allgatherv(hook)
+            for rank in range(pr * pc):
+                hook.state["rank"] = rank
+                myrow, mycol = rank // pc, rank % pc
+                desc, loc = dsc.setup_distributed_matrix(m, m, pr, pc, myrow, mycol, block_size=nb)
+                assert int(desc[dsc.BLOCK_ROW_]) == nb
+                ri = dsc.local_indices(m, nb, myrow, pr); ci = dsc.local_indices(m, nb, mycol, pc)
+                loc[:len(ri), :len(ci)] = G[np.ix_(ri, ci)]
+                proc = solver.Process(rank, pr * pc, 0, pr, pc, myrow, mycol)
+                assert np.array_equal(solver.gather_matrix(loc, desc, proc), G)
+        # a hook that fails, and no hook at all
+        bad = lambda send, counts, displs: np.zeros(1)
+        bad.n_ranks = 4
+        solver.set_allgatherv(bad)
+        desc, loc = dsc.setup_distributed_matrix(8, 8, 2, 2, 0, 0, block_size=2)
+        with pytest.raises(solver.SolverError) as e:
+            solver.gather_matrix(loc, desc, solver.Process(0, 4, 0, 2, 2, 0, 0))
+        assert e.value.info == -999
+        solver.set_allgatherv(None)
+        with pytest.raises(solver.SolverError) as e:
+            solver.gather_matrix(loc, desc, solver.Process(0, 4, 0, 2, 2, 0, 0))
+        assert e.value.info == -998
+        # without a hook ek_hip_solve refuses grids other than 1x1 by argument index
+        ip = desc.ctypes.data_as(ctypes.POINTER(ctypes.c_int)); dp = loc.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        assert lib.ek_hip_solve(0, 8, 8, dp, ip, None, None, dp, dp, ip, 2, 2, 0, 0, None, 0) == -11
+        assert lib.ek_hip_solve(0, 8, 8, dp, ip, None, None, dp, dp, ip, 1, 2, 0, 0, None, 0) == -509  # lld of a 2x2 piece
+        d12, l12 = dsc.setup_distributed_matrix(8, 8, 1, 2, 0, 0, block_size=2)
+        ip = d12.ctypes.data_as(ctypes.POINTER(ctypes.c_int)); dp = l12.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        assert lib.ek_hip_solve(0, 8, 8, dp, ip, None, None, dp, dp, ip, 1, 2, 0, 0, None, 0) == -12
+    finally:
+        solver.set_allgatherv(None)
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from eigenkernel_amd import solver as sv, descriptor as d
+    sv.set_allgatherv(sv.torch_allgatherv(dist))
+    ok = True
+    for (m, nb, pr, pc) in [(37, 8, 1, 2), (64, 16, 2, 1), (5, 1, 1, 2)]:
+        G = np.asfortranarray(np.random.default_rng(5).standard_normal((m, m)))
+        _, _, myrow, mycol = d.make_process_grid(rank, world, pr, pc)
+        desc, loc = d.setup_distributed_matrix(m, m, pr, pc, myrow, mycol, block_size=nb)
+        nbu = int(desc[d.BLOCK_ROW_])
+        ri = d.local_indices(m, nbu, myrow, pr); ci = d.local_indices(m, nbu, mycol, pc)
+        loc[:len(ri), :len(ci)] = G[np.ix_(ri, ci)]
+        full = sv.gather_matrix(loc, desc, sv.Process(rank, world, 0, pr, pc, myrow, mycol))
+        ok = ok and np.array_equal(full, G)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_matrix_gloo_world2():
+    """The exchange step of ek_hip_solve for distributed inputs, two real ranks over gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
