@@ -67,6 +67,17 @@ struct Arena {
 };
 inline size_t al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
+// device buffers of one host-array call: released on every exit path
+struct DevMem {
+  std::vector<void *> ptrs;
+  ~DevMem() { for (void *p : ptrs) (void)hipFree(p); }
+  int alloc(double **p, size_t bytes) {
+    EK_HIP_CHECK(hipMalloc((void **)p, bytes > 0 ? bytes : 8));
+    ptrs.push_back(*p);
+    return 0;
+  }
+};
+
 // descriptor checks for the 1x1 grid this round implements; returns 0 or the LAPACK-style
 // 100*argpos + field code ScaLAPACK uses (-(argpos*100 + field)).
 int check_desc(const int *desc, int argpos, int m, int n, int lld_rows = -1) {
@@ -575,9 +586,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   void *ws;
   const size_t sygst_scr = (problem == 1) ? al(sygst_scratch_doubles(n) * 8) : 0;
   int rc = 0;
-  const size_t sel = cell ? al((size_t)ld * (nc_loc > 0 ? nc_loc : 1) * 8) : 0;
   rc = workspace(4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
-                     4 * al((size_t)ld * 8) + sygst_scr + sel, &ws);
+                     4 * al((size_t)ld * 8) + sygst_scr, &ws);
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
   double *wA = a.get<double>((size_t)ld * ld);
@@ -589,7 +599,6 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   char *work = a.get<char>(scratch);
   double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
   double *sscr = (problem == 1) ? a.get<double>(sygst_scratch_doubles(n)) : nullptr;
-  double *wS = cell ? a.get<double>((size_t)ld * (nc_loc > 0 ? nc_loc : 1)) : nullptr;
 
   StageTimer tm;
   const bool timing = stage_seconds && n_stages > 0;
@@ -633,15 +642,13 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   mark();                                                              // 3
   sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, work);
   mark();                                                              // 4
-  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1);
+  // eigenvector columns wanted: the first n_vec, or this grid cell's share of them; the D&C
+  // forms only those (columns 0..nc_loc-1 of wZ) and the two remaining stages treat the
+  // columns of Z independently
+  const StedcSelect pick{nc_loc, cell ? cell->nb : (n > 0 ? n : 1), cell ? cell->npcol : 1, cell ? cell->mycol : 0};
+  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick);
   mark();                                                              // 5
-  // eigenvector columns to back-transform: the first n_vec, or this grid cell's share of them
-  // (columns of Z are independent in both remaining stages)
   double *zc = wZ;
-  if (cell) {
-    gather_block_cyclic(s, n, nc_loc, wZ, ld, cell->nb, 1, 0, cell->npcol, cell->mycol, wS, ld);
-    zc = wS;
-  }
   ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work);
   mark();                                                              // 6
   if (problem == 1) trsm_llt(s, n, nc_loc, wB, ld, dInv, zc, ld, twork);
@@ -687,11 +694,13 @@ int replicated_host_locked(int problem, int n, int n_vec, double *A, int lda, do
   const size_t nn = (size_t)n * n * 8;
   const int ldzl = nr_loc > 1 ? nr_loc : 1;
   auto t0 = std::chrono::steady_clock::now();
-  EK_HIP_CHECK(hipMalloc((void **)&uA, nn));
-  EK_HIP_CHECK(hipMalloc((void **)&uZ, (size_t)ldzl * (nc_loc > 0 ? nc_loc : 1) * 8));
-  EK_HIP_CHECK(hipMalloc((void **)&uw, (size_t)n * 8));
-  if (problem == 1) EK_HIP_CHECK(hipMalloc((void **)&uB, nn));
-  int rc = h2d_matrix(n, n, A, lda, uA, n, s);
+  DevMem mem;
+  int rc = mem.alloc(&uA, nn);
+  if (!rc) rc = mem.alloc(&uZ, (size_t)ldzl * (nc_loc > 0 ? nc_loc : 1) * 8);
+  if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
+  if (!rc && problem == 1) rc = mem.alloc(&uB, nn);
+  if (rc) return rc;
+  rc = h2d_matrix(n, n, A, lda, uA, n, s);
   if (!rc && problem == 1) rc = h2d_matrix(n, n, B, ldb, uB, n, s);
   if (!rc) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc = -1000 - (int)e; }
   auto t1 = std::chrono::steady_clock::now();
@@ -708,7 +717,6 @@ int replicated_host_locked(int problem, int n, int n_vec, double *A, int lda, do
     if (rc2 && info == 0) info = rc2;
   }
   auto t3 = std::chrono::steady_clock::now();
-  (void)hipFree(uA); (void)hipFree(uZ); (void)hipFree(uw); if (uB) (void)hipFree(uB);
   if (stage_seconds && n_stages > EK_STAGE_COPY)
     stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() +
                                     std::chrono::duration<double>(t3 - t2).count();
@@ -875,10 +883,12 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
   double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
   const size_t nn = (size_t)n * n * 8;
   auto t0 = std::chrono::steady_clock::now();
-  EK_HIP_CHECK(hipMalloc((void **)&uA, nn));
-  EK_HIP_CHECK(hipMalloc((void **)&uZ, nn));
-  EK_HIP_CHECK(hipMalloc((void **)&uw, (size_t)n * 8));
-  if (problem == 1) EK_HIP_CHECK(hipMalloc((void **)&uB, nn));
+  DevMem mem;
+  rc = mem.alloc(&uA, nn);
+  if (!rc) rc = mem.alloc(&uZ, nn);
+  if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
+  if (!rc && problem == 1) rc = mem.alloc(&uB, nn);
+  if (rc) return rc;
   rc = h2d_matrix(n, n, A_loc, desc_A[8], uA, n, s);
   if (!rc && problem == 1) rc = h2d_matrix(n, n, B_loc, desc_B[8], uB, n, s);
   if (!rc) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc = -1000 - (int)e; }
@@ -896,7 +906,6 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
     if (rc2 && info == 0) info = rc2;
   }
   auto t3 = std::chrono::steady_clock::now();
-  (void)hipFree(uA); (void)hipFree(uZ); (void)hipFree(uw); if (uB) (void)hipFree(uB);
   if (stage_seconds && n_stages > EK_STAGE_COPY)
     stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() +
                                     std::chrono::duration<double>(t3 - t2).count();
@@ -995,19 +1004,20 @@ int ek_hip_check(int what, int problem, int n, int n_cols, int index1, int index
   if (n == 0) return 0;
   double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
   const size_t nn = (size_t)n * n * 8;
+  DevMem mem;
   {
     std::lock_guard<std::mutex> lk(g_mu);
     hipStream_t s = g_ctx.stream;
-    EK_HIP_CHECK(hipMalloc((void **)&uZ, nn));
+    rc = mem.alloc(&uZ, nn); if (rc) return rc;
     rc = h2d_matrix(n, n, Z_loc, desc_Z[8], uZ, n, s); if (rc) return rc;
     if (what == 0) {
-      EK_HIP_CHECK(hipMalloc((void **)&uA, nn));
-      EK_HIP_CHECK(hipMalloc((void **)&uw, (size_t)n * 8));
+      rc = mem.alloc(&uA, nn); if (rc) return rc;
+      rc = mem.alloc(&uw, (size_t)n * 8); if (rc) return rc;
       rc = h2d_matrix(n, n, A_loc, desc_A[8], uA, n, s); if (rc) return rc;
       EK_HIP_CHECK(hipMemcpyAsync(uw, w, (size_t)n * 8, hipMemcpyHostToDevice, s));
     }
     if (problem == 1) {
-      EK_HIP_CHECK(hipMalloc((void **)&uB, nn));
+      rc = mem.alloc(&uB, nn); if (rc) return rc;
       rc = h2d_matrix(n, n, B_loc, desc_B[8], uB, n, s); if (rc) return rc;
     }
     EK_HIP_CHECK(hipStreamSynchronize(s));
@@ -1015,7 +1025,6 @@ int ek_hip_check(int what, int problem, int n, int n_cols, int index1, int index
   if (what == 0) rc = ek_hip_residual_device(problem, n, n_cols, uA, n, uB, n, uw, uZ, n, &out[0], &out[1], &out[2]);
   else if (what == 1) rc = ek_hip_orthogonality_device(problem, n, index1, index2, uB, n, uZ, n, &out[0]);
   else rc = ek_hip_ipratios_device(problem, n, n_cols, uB, n, uZ, n, out);
-  (void)hipFree(uZ); if (uA) (void)hipFree(uA); if (uB) (void)hipFree(uB); if (uw) (void)hipFree(uw);
   return rc;
 }
 

@@ -106,8 +106,13 @@ void symv_profile_collect(double *seconds, long long *launches, double *bytes);
 // ---------------------------------------------------------------- tridiagonal D&C (ek_stedc.hip)
 size_t stedc_work_bytes(int n);
 // d(n), e(n-1) -> eigenvalues ascending in w(n), eigenvectors in Z (n x n, ldz).
+// With a selection only the eigenvectors of ranks r(l) = ((l / nb) * npcol + mycol) * nb + l % nb,
+// l = 0..nsel-1, are formed (the block-cyclic share of a process column; nb >= n, npcol = 1 gives
+// the lowest nsel) and returned in columns 0..nsel-1 of Z: the top-level merge, two thirds of the
+// D&C flops, then multiplies only those columns.  All n eigenvalues are always returned.
+struct StedcSelect { int nsel, nb, npcol, mycol; };
 void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z,
-           int ldz, void *work, int *d_info);
+           int ldz, void *work, int *d_info, const StedcSelect *sel = nullptr);
 
 // ---------------------------------------------------------------- back-transformation (ek_ormtr.hip)
 size_t ormtr_work_bytes(int n, int ncols);

@@ -537,6 +537,64 @@ __global__ void dc_final_rank_kernel(int n, DcBufs b, double *__restrict__ w, in
   if (!(fabs(raw) <= 1.7e308)) atomicMax(info, n + 1);   // NaN / Inf eigenvalue: breakdown
 }
 
+// ------------------------------------------------------------------ selected eigenvectors only
+__device__ __forceinline__ int sel_rank(const StedcSelect &q, int l) {
+  return ((l / q.nb) * q.npcol + q.mycol) * q.nb + l % q.nb;
+}
+
+// selcol[l] = basis column (root / deflated column of the top merge) that carries rank r(l);
+// thread 0 also narrows the top merge's two GEMMs to nsel output columns.
+__global__ void dc_select_kernel(StedcSelect q, const int *__restrict__ fperm, int *__restrict__ selcol,
+                                 int *gd) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < q.nsel) selcol[l] = fperm[sel_rank(q, l)];
+  if (l == 0 && gd) { gd[1] = q.nsel; gd[4] = q.nsel; }
+}
+
+// Top merge, selected columns: column l of S = the rank-one eigenvector of root selcol[l]
+// (as dc_vectors_kernel), or zero when selcol[l] is a deflated column (copied afterwards).
+__global__ __launch_bounds__(256) void dc_vectors_sel_kernel(int mi, DcBufs b, const int *__restrict__ selcol,
+                                                             double *__restrict__ S, int lds) {
+  __shared__ double red[4];
+  const Merge mg = b.merges[mi];
+  const int l = blockIdx.x, t = threadIdx.x;
+  const int k = b.k[mi];
+  const int c = selcol[l];
+  double *col = S + (size_t)mg.off + (size_t)(mg.off + l) * lds;
+  if (c >= k) {
+    for (int j = t; j < k; j += 256) col[j] = 0.0;
+    return;
+  }
+  const double *dl = b.dl + mg.off, *zh = b.zhat + mg.off;
+  const int *grp = b.grp + mg.off;
+  const double dK = dl[b.korig[mg.off + c]], tau = b.tauv[mg.off + c];
+  double ss = 0.0;
+  for (int j = t; j < k; j += 256) {
+    const double u = zh[j] / ((dl[j] - dK) - tau);
+    ss += u * u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+  if ((t & 63) == 0) red[t >> 6] = ss;
+  __syncthreads();
+  const double inv = 1.0 / sqrt((red[0] + red[1]) + (red[2] + red[3]));
+  for (int j = t; j < k; j += 256) col[grp[j]] = zh[j] / ((dl[j] - dK) - tau) * inv;
+}
+
+// selected deflated eigenpairs of the top merge: Q(:, l) = W(:, selcol[l]) where selcol[l] >= k
+__global__ void dc_copy_deflated_sel_kernel(int mi, DcBufs b, int nsel, const int *__restrict__ selcol,
+                                            const double *__restrict__ W, int ldw, double *__restrict__ Q,
+                                            int ldq) {
+  const Merge mg = b.merges[mi];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= mg.n) return;
+  const int k = b.k[mi];
+  for (int l = blockIdx.y; l < nsel; l += gridDim.y) {
+    const int c = selcol[l];
+    if (c >= k) Q[(size_t)r + (size_t)l * ldq] = W[(size_t)r + (size_t)c * ldw];
+  }
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Plan {
@@ -576,7 +634,7 @@ struct WorkLayout {
 size_t stedc_work_bytes(int n) { return WorkLayout(n > 0 ? n : 1).total; }
 
 void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z, int ldz,
-           void *work, int *d_info) {
+           void *work, int *d_info, const StedcSelect *sel) {
   if (n <= 0) return;
   const WorkLayout L(n);
   char *base = (char *)work;
@@ -650,6 +708,8 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
                      d_info);
 
   double *W = Z;   // the output array doubles as the permuted-basis scratch until the end
+  const bool selecting = sel && sel->nsel < n;
+  bool sel_done = false;
   for (size_t lv = 0; lv < plan.levels.size(); ++lv) {
     const int mbeg = lvl_beg[lv], cnt = lvl_beg[lv + 1] - mbeg;
     int maxn = 0;
@@ -662,6 +722,30 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     hipLaunchKernelGGL(dc_rotate_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, W, ldz);
     hipLaunchKernelGGL(dc_secular_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
     hipLaunchKernelGGL(dc_zhat_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b);
+    if (selecting && lv + 1 == plan.levels.size()) {
+      // Top merge (off = 0, order n): every eigenvalue is known now, so the final order can be
+      // fixed before the eigenvector product and only the selected columns are multiplied,
+      // straight into their final positions.
+      int *selcol = b.rotp;               // the rotation list is spent once dc_rotate has run
+      hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, b, w, fperm, d_info);
+      sel_done = true;
+      if (sel->nsel <= 0) break;
+      hipLaunchKernelGGL(dc_select_kernel, dim3(ceil_div(sel->nsel, 256)), dim3(256), 0, s, *sel, fperm, selcol,
+                         b.gdims + 6 * (size_t)mbeg);
+      hipLaunchKernelGGL(dc_vectors_sel_kernel, dim3(sel->nsel), dim3(256), 0, s, mbeg, b, selcol, S, lds);
+      GemmDesc g{};
+      g.M = (maxn + 1) / 2; g.N = sel->nsel; g.K = maxn; g.transA = false; g.transB = false;
+      g.alpha = 1.0; g.beta = 0.0;
+      g.A = W; g.lda = ldz; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
+      g.C = Q; g.ldc = ldq; g.strideC = 0; g.batch = 2; g.lower_only = false;
+      g.d_offs = b.goffs + 6 * (size_t)mbeg; g.d_dims = b.gdims + 6 * (size_t)mbeg;
+      gemm(s, g);
+      const int gys = std::min(sel->nsel, std::max(1, 4096 / gx));
+      hipLaunchKernelGGL(dc_copy_deflated_sel_kernel, dim3(gx, gys), dim3(256), 0, s, mbeg, b, sel->nsel, selcol,
+                         W, ldz, Q, ldq);
+      copy_matrix(s, n, sel->nsel, Q, ldq, Z, ldz);
+      break;
+    }
     hipLaunchKernelGGL(dc_vectors_kernel, dim3(maxn, cnt), dim3(256), 0, s, mbeg, b, S, lds);
     // two GEMMs per merge (top rows x [top-only|dense] columns, bottom rows x [dense|bottom-only]
     // columns), all merges of this height in one launch; sizes and offsets come from the
@@ -675,7 +759,17 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     gemm(s, g);
     hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldz, Q, ldq);
   }
+  if (sel_done) return;
   hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, b, w, fperm, d_info);
+  if (selecting) {
+    // no merge at all (a single leaf): pick the selected columns out of the leaf's eigenvectors
+    if (sel->nsel <= 0) return;
+    int *selcol = b.rotp;
+    hipLaunchKernelGGL(dc_select_kernel, dim3(ceil_div(sel->nsel, 256)), dim3(256), 0, s, *sel, fperm, selcol,
+                       (int *)nullptr);
+    gather_columns(s, n, sel->nsel, Q, ldq, selcol, Z, ldz);
+    return;
+  }
   gather_columns(s, n, n, Q, ldq, fperm, Z, ldz);
 }
 
