@@ -488,7 +488,7 @@ int ek_hip_profile_symv(int enable) {
   int rc = ensure_init(); if (rc) return rc;
   std::lock_guard<std::mutex> lk(g_mu);
   EK_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
-  symv_profile_enable(enable != 0);
+  symv_profile_enable(enable > 0 ? enable : 0);
   return 0;
 }
 

@@ -100,7 +100,7 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
                  double *V, int ldv, void *work);
 
 // instrumentation: HIP events around every symv launch (bench.py roofline line)
-void symv_profile_enable(bool on);
+void symv_profile_enable(int stride);   // 0 = off, k = time every k-th column's launch
 void symv_profile_collect(double *seconds, long long *launches, double *bytes);
 
 // ---------------------------------------------------------------- tridiagonal D&C (ek_stedc.hip)

@@ -498,10 +498,12 @@ __global__ void put_diag_kernel(int n, double *A, int lda, const double *__restr
 
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// Optional instrumentation for bench.py's roofline line: HIP events around every symv launch
-// on the launch stream.  Off by default (events cost host time).
+// Optional instrumentation for bench.py's roofline line: HIP events around every stride-th symv
+// launch (by column index, so the sample is uniform over the trailing orders) on the launch
+// stream.  Off by default: a pair of event records costs ~5 us of host time per launch.
 struct SymvProfile {
   bool enabled = false;
+  int stride = 1;
   std::vector<hipEvent_t> ev;
   size_t used = 0;
   double bytes = 0.0;
@@ -595,7 +597,8 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
       sv.ndot = (i > 0) ? 1 : 0;
       sv.nchunks = nchunks_cur;
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (g_prof.enabled) {
+      const bool timed = g_prof.enabled && (j % g_prof.stride == 0);
+      if (timed) {
         if (g_prof.used + 2 > g_prof.ev.size()) {
           const size_t old = g_prof.ev.size();
           g_prof.ev.resize(old + 4096);
@@ -605,7 +608,7 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
         (void)hipEventRecord(e0, s);
       }
       hipLaunchKernelGGL(symv_kernel, dim3(sv.nwg + sv.ndot), dim3(256), 0, s, sv);
-      if (g_prof.enabled) {
+      if (timed) {
         (void)hipEventRecord(e1, s);
         const double m = (double)(n - j - 1);
         g_prof.bytes += 8.0 * m * (m + 1.0) * 0.5;   // lower triangle of the active matrix, once
@@ -637,8 +640,9 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
   hipLaunchKernelGGL(put_diag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, A, lda, d);
 }
 
-void symv_profile_enable(bool on) {
-  g_prof.enabled = on;
+void symv_profile_enable(int stride) {
+  g_prof.enabled = stride > 0;
+  g_prof.stride = stride > 0 ? stride : 1;
   g_prof.used = 0; g_prof.bytes = 0.0; g_prof.launches = 0; g_prof.seconds = 0.0;
 }
 

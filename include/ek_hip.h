@@ -192,9 +192,10 @@ int ek_hip_check(int what, int problem, int n, int n_cols, int index1, int index
                  const double *A_loc, const int desc_A[9], const double *B_loc, const int desc_B[9],
                  const double *w, const double *Z_loc, const int desc_Z[9], double *out);
 
-/* Instrumentation for the roofline line of bench.py: when enabled, every launch of the
- * HBM-bound symv kernel of the tridiagonalisation is bracketed by HIP events on its own
- * stream.  _get returns the accumulated device seconds, the number of launches and the
+/* Instrumentation for the roofline line of bench.py: enable = k > 0 brackets the launch of the
+ * HBM-bound symv kernel of every k-th Householder column (k = 1: every launch; a uniform sample
+ * over the trailing orders otherwise) by HIP events on its own stream; 0 switches it off.
+ * _get returns the accumulated device seconds, the number of timed launches and their
  * algorithmic bytes (8 B x lower triangle of the active matrix per launch). */
 int ek_hip_profile_symv(int enable);
 /* Tuning hook: tridiagonalise a device-generated synthetic matrix (order n, leading dimension
