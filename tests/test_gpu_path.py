@@ -592,3 +592,29 @@ def test_golden_bnz30_on_the_reference_grid(hip, golden_dir, inputs):
         assert np.abs(get_ipratios(Z, B.to_dense()) - ipr).max() <= 1e-6
     finally:
         hip.set_allgatherv(None)
+
+
+def test_no_eigenvectors_requested(hip, oracle):
+    """n_vec = 0 (eigenvalues only) and grid cells that own no eigenvector column."""
+    from eigenkernel_amd import descriptor as d
+    lib = hip.load_library()
+    n = 300
+    A = oracle.synth_matrix(n, 1); B = oracle.synth_matrix(n, 2)
+    ref, _ = hip.eigen_solver("general_hip", A, B)
+    desc, Al = d.setup_distributed_matrix(n, n); Al[:, :] = A
+    _, Bl = d.setup_distributed_matrix(n, n); Bl[:, :] = B
+    _, Z = d.setup_distributed_matrix(n, n)
+    w = np.zeros(n)
+    assert lib.ek_hip_solve(1, n, 0, hip._P(Al), hip._I(desc), hip._P(Bl), hip._I(desc), hip._P(w), hip._P(Z),
+                            hip._I(desc), 1, 1, 0, 0, None, 0) == 0
+    assert np.array_equal(w, ref.values) and not Z.any()
+    # 1 x 8 grid, NB = 64, n_vec = 100: process columns 2..7 own nothing
+    for mycol in (1, 5):
+        proc = hip.Process(mycol, 8, 0, 1, 8, 0, mycol)
+        ep, _ = hip.eigen_solver("general_hip_select", A, B, n_vec=100, block_size=64, proc=proc)
+        assert np.array_equal(ep.values, ref.values)
+        own = d.local_indices(100, int(ep.desc[d.BLOCK_ROW_]), mycol, 8)
+        if len(own):
+            assert np.array_equal(ep.Vectors[:, :len(own)], ref.Vectors[:, own])
+        else:
+            assert not ep.Vectors.any()
