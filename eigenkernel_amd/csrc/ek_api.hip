@@ -6,6 +6,9 @@
 #include "../../include/ek_hip.h"
 #include "ek_common.h"
 
+#include <rccl/rccl.h>   // types only: the library is bound at run time (dlopen), see Rccl below
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -109,6 +112,65 @@ struct GridCell { int nb, nprow, npcol, myrow, mycol; };
 // Exchange hook for block-cyclically distributed inputs (ek_hip_set_allgatherv)
 ek_hip_allgatherv_fn g_allgatherv = nullptr;
 void *g_allgatherv_user = nullptr;
+
+// ---- RCCL, bound at run time.  The collective of the distributed tridiagonalisation (one
+// all-reduce per Householder column) has to be issued from inside the library on the library's
+// stream: a host-language collective per column costs more than the column.  dlopen keeps
+// libek_hip.so loadable where RCCL is absent and makes it share the copy the host already loaded
+// (PyTorch ships its own librccl.so.1).  Replaces the BLACS calls inside PDSYTRD.
+struct Rccl {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  int load() {
+    if (h) return 0;
+    const char *names[] = {getenv("EK_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+      if (!nm || !*nm) continue;
+      h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) { fprintf(stderr, "[ek_hip] cannot load RCCL: %s\n", dlerror()); return -997; }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+    AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+    GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
+      fprintf(stderr, "[ek_hip] RCCL symbols missing\n");
+      dlclose(h); h = nullptr; return -997;
+    }
+    return 0;
+  }
+};
+Rccl g_rccl;
+struct Comm {
+  bool on = false;
+  ncclComm_t comm = nullptr;
+  int nranks = 0, rank = 0;
+  int err = 0;          // first failing collective since the last check (ncclResult_t)
+};
+Comm g_comm;
+
+void rccl_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t count, void *) {
+  if (nmem != 1 || !g_comm.on) { if (!g_comm.err) g_comm.err = (int)ncclInvalidUsage; return; }
+  const ncclResult_t r = g_rccl.AllReduce(bufs[0], bufs[0], count, ncclDouble, ncclSum, g_comm.comm, s);
+  if (r != ncclSuccess && !g_comm.err) g_comm.err = (int)r;
+}
+
+__global__ void count_mismatch_kernel(int m, int n, const double *X, int ldx, const double *Y, int ldy,
+                                      int lower, unsigned long long *count) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)m * n) return;
+  const int r = (int)(idx % m), c = (int)(idx / m);
+  if (lower && r < c) return;
+  const unsigned long long a = __double_as_longlong(X[(size_t)r + (size_t)c * ldx]);
+  const unsigned long long b = __double_as_longlong(Y[(size_t)r + (size_t)c * ldy]);
+  if (a != b) atomicAdd(count, 1ull);
+}
 
 // local piece (nr x nc, lld) <-> its place in the full matrix; blocks of nb rows are contiguous
 template <typename F>
@@ -412,6 +474,135 @@ int ek_hip_sytrd(int n, double *A_loc, const int desc_A[9], double *d, double *e
   return 0;
 }
 
+// PDSYTRD on a 1 x P grid (column-block-cyclic, 128-wide blocks), see sytrd_lower_dist.
+//   nteam >= 1: rehearsal of a whole team of nteam members inside this process on one GPU (each
+//               member gets its own copy of A and its own workspace; exchange = a device kernel);
+//   nteam == 0: this process is one member of the attached communicator (ek_hip_comm_init).
+// A_loc/d/e/tau return the first local member's results; *mismatch (optional) the number of
+// doubles (lower triangle of A, d, e, tau) in which any other local member differs from it.
+int ek_hip_sytrd_team(int n, double *A_loc, const int desc_A[9], double *d, double *e, double *tau,
+                      int nteam, long long *mismatch) {
+  if (n < 0) return -1;
+  if (!A_loc && n > 0) return -2;
+  int rc = check_desc(desc_A, 3, n, n); if (rc) return rc;
+  if (n > 0 && !d) return -4;
+  if (n > 1 && !e) return -5;
+  if (n > 1 && !tau) return -6;
+  if (nteam < 0 || nteam > kMaxTeam) return -7;
+  rc = ensure_init(); if (rc) return rc;
+  if (mismatch) *mismatch = 0;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nteam == 0 && !g_comm.on) return -7;
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const int nmem = nteam > 0 ? nteam : 1, P = nteam > 0 ? nteam : g_comm.nranks;
+  const size_t wb = sytrd_dist_work_bytes(n, P);
+  const size_t per = al((size_t)ld * ld * 8) + al(wb) + 3 * al((size_t)ld * 8);
+  void *ws;
+  rc = workspace(per * nmem + 256, &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  unsigned long long *d_cnt = a.get<unsigned long long>(1);
+  EK_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 8, s));
+  SytrdMember mem[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    double *dA = a.get<double>((size_t)ld * ld);
+    char *work = a.get<char>(wb);
+    double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld);
+    EK_HIP_CHECK(hipMemsetAsync(dA, 0, (size_t)ld * ld * 8, s));
+    EK_HIP_CHECK(hipMemsetAsync(dd, 0, 3 * al((size_t)ld * 8), s));
+    rc = h2d_matrix(n, n, A_loc, desc_A[8], dA, ld, s); if (rc) return rc;
+    mem[m] = SytrdMember{dA, ld, dd, de, dt, nullptr, 0, work, nteam > 0 ? m : g_comm.rank};
+  }
+  SytrdExchange x{P, nteam > 0 ? sytrd_team_allreduce : rccl_allreduce, nullptr};
+  g_comm.err = 0;
+  sytrd_lower_dist(s, n, nmem, mem, x);
+  EK_HIP_CHECK(hipGetLastError());
+  for (int m = 1; m < nmem; ++m) {
+    const unsigned nb = (unsigned)(((size_t)n * n + 255) / 256);
+    hipLaunchKernelGGL(count_mismatch_kernel, dim3(nb), dim3(256), 0, s, n, n, mem[0].A, ld, mem[m].A, ld, 1, d_cnt);
+    hipLaunchKernelGGL(count_mismatch_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, 1, mem[0].d, n, mem[m].d, n, 0, d_cnt);
+    if (n > 1) {
+      hipLaunchKernelGGL(count_mismatch_kernel, dim3(ceil_div(n - 1, 256)), dim3(256), 0, s, n - 1, 1, mem[0].e, n, mem[m].e, n, 0, d_cnt);
+      hipLaunchKernelGGL(count_mismatch_kernel, dim3(ceil_div(n - 1, 256)), dim3(256), 0, s, n - 1, 1, mem[0].tau, n, mem[m].tau, n, 0, d_cnt);
+    }
+  }
+  rc = d2h_matrix(n, n, mem[0].A, ld, A_loc, desc_A[8], s); if (rc) return rc;
+  EK_HIP_CHECK(hipMemcpyAsync(d, mem[0].d, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  if (n > 1) {
+    EK_HIP_CHECK(hipMemcpyAsync(e, mem[0].e, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, s));
+    EK_HIP_CHECK(hipMemcpyAsync(tau, mem[0].tau, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, s));
+  }
+  unsigned long long cnt = 0;
+  EK_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  if (mismatch) *mismatch = (long long)cnt;
+  if (g_comm.err) { fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", g_rccl.GetErrorString((ncclResult_t)g_comm.err)); return -996; }
+  return 0;
+}
+
+// ---- communicator of the distributed path: one rank per GPU, RCCL over xGMI.  The host
+// obtains the 128-byte id on rank 0, broadcasts it with whatever it has (MPI_Bcast in the
+// Fortran host, torch.distributed in the tests) and every rank calls ek_hip_comm_init.
+int ek_hip_comm_unique_id(void *id, int bytes) {
+  if (!id) return -1;
+  if (bytes < (int)sizeof(ncclUniqueId)) return -2;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  rc = g_rccl.load(); if (rc) return rc;
+  ncclUniqueId uid;
+  const ncclResult_t r = g_rccl.GetUniqueId(&uid);
+  if (r != ncclSuccess) { fprintf(stderr, "[ek_hip] ncclGetUniqueId: %s\n", g_rccl.GetErrorString(r)); return -996; }
+  memcpy(id, &uid, sizeof(uid));
+  return 0;
+}
+
+int ek_hip_comm_init(const void *id, int bytes, int nranks, int rank) {
+  if (!id) return -1;
+  if (bytes < (int)sizeof(ncclUniqueId)) return -2;
+  if (nranks < 1 || nranks > kMaxTeam) return -3;
+  if (rank < 0 || rank >= nranks) return -4;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  rc = g_rccl.load(); if (rc) return rc;
+  if (g_comm.on) { (void)g_rccl.CommDestroy(g_comm.comm); g_comm = Comm{}; }
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  const ncclResult_t r = g_rccl.CommInitRank(&g_comm.comm, nranks, uid, rank);
+  if (r != ncclSuccess) { fprintf(stderr, "[ek_hip] ncclCommInitRank: %s\n", g_rccl.GetErrorString(r)); return -996; }
+  g_comm.on = true; g_comm.nranks = nranks; g_comm.rank = rank; g_comm.err = 0;
+  return 0;
+}
+
+int ek_hip_comm_size(void) { return g_comm.on ? g_comm.nranks : 0; }
+int ek_hip_comm_rank(void) { return g_comm.on ? g_comm.rank : -1; }
+
+int ek_hip_comm_destroy(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_comm.on) {
+    if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+    (void)g_rccl.CommDestroy(g_comm.comm);
+  }
+  g_comm = Comm{};
+  return 0;
+}
+
+// sum over the ranks of the attached communicator of a device vector, in place (binding check;
+// the same call the tridiagonalisation issues once per column)
+int ek_hip_comm_allreduce_device(double *dbuf, long long count) {
+  if (count < 0) return -2;
+  if (count > 0 && !dbuf) return -1;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_comm.on) return -995;
+  g_comm.err = 0;
+  double *bufs[1] = {dbuf};
+  if (count > 0) rccl_allreduce(g_ctx.stream, 1, bufs, (size_t)count, nullptr);
+  EK_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  return g_comm.err ? -996 : 0;
+}
+
 
 int ek_hip_stedc(int n, double *d, double *e, double *Z_loc, const int desc_Z[9]) {
   if (n < 0) return -1;
@@ -576,8 +767,13 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
   const int nc_loc = cell ? numroc0(n_vec, cell->nb, cell->mycol, cell->npcol) : n_vec;
   const int nr_loc = cell ? numroc0(n, cell->nb, cell->myrow, cell->nprow) : n;
-  const size_t wb_sytrd = sytrd_work_bytes(n), wb_stedc = stedc_work_bytes(n),
-               wb_ormtr = ormtr_work_bytes(n, nc_loc);
+  // A communicator attached by the host (ek_hip_comm_init) whose size is the grid's: the
+  // tridiagonalisation is distributed over the ranks (one RCCL all-reduce per column); the other
+  // stages are as in the replicated-input mode.
+  const bool dist = cell && g_comm.on && g_comm.nranks == cell->nprow * cell->npcol;
+  if (dist && g_comm.rank != cell->myrow * cell->npcol + cell->mycol) return -994;
+  const size_t wb_sytrd = dist ? sytrd_dist_work_bytes(n, g_comm.nranks) : sytrd_work_bytes(n),
+               wb_stedc = stedc_work_bytes(n), wb_ormtr = ormtr_work_bytes(n, nc_loc);
   const size_t mat = al((size_t)ld * ld * 8);
   size_t scratch = wb_sytrd;
   if (wb_stedc > scratch) scratch = wb_stedc;
@@ -640,7 +836,14 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   mark();                                                              // 2
   if (problem == 1) sygst_lower(s, n, wA, ld, wB, ld, dInv, twork, sscr);
   mark();                                                              // 3
-  sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, work);
+  if (dist) {
+    const SytrdMember me{wA, ld, dd, de, dt, wV, ld, work, g_comm.rank};
+    const SytrdExchange x{g_comm.nranks, rccl_allreduce, nullptr};
+    g_comm.err = 0;
+    sytrd_lower_dist(s, n, 1, &me, x);
+  } else {
+    sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, work);
+  }
   mark();                                                              // 4
   // eigenvector columns wanted: the first n_vec, or this grid cell's share of them; the D&C
   // forms only those (columns 0..nc_loc-1 of wZ) and the two remaining stages treat the
@@ -677,6 +880,10 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     st[EK_STAGE_TRTRS] = ms[6] * 1e-3;
     for (int i = 0; i < n_stages && i < EK_HIP_N_STAGES; ++i) stage_seconds[i] = st[i];
     tm.destroy();
+  }
+  if (dist && g_comm.err) {
+    fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", g_rccl.GetErrorString((ncclResult_t)g_comm.err));
+    return -996;
   }
   if (info[0] != 0) return info[0];          // Cholesky: leading minor not positive definite
   if (info[1] != 0) return 100000 + info[1];  // tridiagonal eigensolver did not converge

@@ -99,6 +99,33 @@ size_t sytrd_work_bytes(int n);
 void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e, double *tau,
                  double *V, int ldv, void *work);
 
+// Distributed form (PDSYTRD on a 1 x P grid with 128-wide column blocks): member
+// `rank` of a team of `nranks` owns the strips rank, rank+P, ... of the trailing matrix.  Every
+// member passes a full-size A (identical on entry; only the owned strips are kept current by the
+// trailing updates), streams only its own strips in symv, and the team all-reduces one window of
+// at most 2*npad+1 doubles per column.  d, e, tau, V and the reflector columns of A come out
+// complete and bit-identical on every member.  A process holds `nmem` members: 1 in production
+// (exchange = ncclAllReduce over RCCL), the whole team in the single-GPU rehearsal
+// (exchange = sytrd_team_allreduce).
+constexpr int kMaxTeam = 16;
+struct SytrdMember {
+  double *A; int lda;
+  double *d, *e, *tau;
+  double *V; int ldv;
+  void *work;          // >= sytrd_dist_work_bytes(n, nranks)
+  int rank;
+};
+struct SytrdExchange {
+  int nranks;
+  // in-place sum over ALL ranks of the team of `count` doubles; bufs = the windows of the nmem
+  // members held by this process; stream-ordered
+  void (*allreduce)(hipStream_t s, int nmem, double *const *bufs, size_t count, void *user);
+  void *user;
+};
+size_t sytrd_dist_work_bytes(int n, int nranks);
+void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, const SytrdExchange &x);
+void sytrd_team_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t count, void *user);
+
 // instrumentation: HIP events around every symv launch (bench.py roofline line)
 void symv_profile_enable(int stride);   // 0 = off, k = time every k-th column's launch
 void symv_profile_collect(double *seconds, long long *launches, double *bytes);

@@ -93,19 +93,24 @@ __device__ __forceinline__ Refl reflector(double ssq, double alpha0) {
 // strip) owns the 128x128 tiles rb = s .. T-1.  Tiles are numbered strip-major and dealt to
 // the workgroups in equal contiguous runs of q tiles, so every workgroup streams the same
 // number of bytes; a strip therefore reaches colupd as one partial per workgroup ("piece").
-__device__ __host__ __forceinline__ int tile_start(int s, int T) { return s * T - (s * (s - 1)) / 2; }
-__device__ __forceinline__ int strip_of_tile(int L, int T) {
-  const double b = 2.0 * T + 1.0;
-  int s = (int)((b - sqrt(b * b - 8.0 * (double)L)) * 0.5);
+// With P > 1 (distributed run, one member of a 1 x P column-block-cyclic layout with 128-wide
+// blocks) a member owns every P-th strip: its k-th active strip has T - k*P tiles, T being the
+// length of its first active strip, and the same formulas hold with the stride P.
+__device__ __host__ __forceinline__ int tile_start(int s, int T, int P = 1) { return s * T - P * ((s * (s - 1)) / 2); }
+__device__ __forceinline__ int strip_of_tile(int L, int T, int P = 1) {
+  const double b = 2.0 * T + (double)P;
+  const double disc = b * b - 8.0 * (double)P * (double)L;
+  int s = (int)((b - sqrt(disc > 0.0 ? disc : 0.0)) / (2.0 * P));
+  const int smax = (T + P - 1) / P - 1;
   if (s < 0) s = 0;
-  if (s > T - 1) s = T - 1;
-  while (s + 1 < T && tile_start(s + 1, T) <= L) ++s;
-  while (s > 0 && tile_start(s, T) > L) --s;
+  if (s > smax) s = smax;
+  while (s + 1 <= smax && tile_start(s + 1, T, P) <= L) ++s;
+  while (s > 0 && tile_start(s, T, P) > L) --s;
   return s;
 }
-__device__ __forceinline__ int first_piece(int s, int T, int q) { return tile_start(s, T) / q; }
-__device__ __forceinline__ int num_pieces(int s, int T, int q) {
-  return (tile_start(s + 1, T) - 1) / q - tile_start(s, T) / q + 1;
+__device__ __forceinline__ int first_piece(int s, int T, int q, int P = 1) { return tile_start(s, T, P) / q; }
+__device__ __forceinline__ int num_pieces(int s, int T, int q, int P = 1) {
+  return (tile_start(s + 1, T, P) - 1) / q - tile_start(s, T, P) / q + 1;
 }
 
 struct ColupdArgs {
@@ -125,11 +130,18 @@ struct ColupdArgs {
   int update;             // 0/1
   int j;                  // global index of the column to update
   int i_new;              // finished panel columns once this launch is done (dots needed for them)
+  // distributed run: the all-reduced exchange window of this column (rows r0 .. npad-1):
+  // [0, xcnt) raw entries of column j, [xcnt, 2 xcnt) y = A22 x, [2 xcnt] x^T A x
+  const double *xch;
+  int xcnt;
 };
 
 constexpr int CR = 32;    // rows per colupd workgroup
 constexpr int NSL = 256 / CR;   // slices per row (threads sharing one row's sums)
 
+// DIST: the symv partial sums and the raw column come from the exchange window (every member of
+// the team runs this kernel redundantly on identical data), not from this member's own buffers.
+template <bool DIST>
 __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
   __shared__ double s_pvw[2 * NBP];          // [0,NBP): V^T v totals, [NBP,2NBP): W^T v totals
   __shared__ double s_Vj[NBP], s_Wj[NBP];
@@ -156,8 +168,10 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
     double red3[3] = {0.0, 0.0, 0.0};   // ssq, x^T A x, (A x)_j
     const double *normp = p.b.normpart + (size_t)(jp & 1) * p.b.nch;
     for (int c = t; c < p.nchunks_p; c += 256) red3[0] += normp[c];
-    for (int u = t; u < p.nwg_p; u += 256) red3[1] += p.b.vavpart[u];
-    {
+    if (DIST) {
+      if (t == 0) { red3[1] = p.xch[2 * (size_t)p.xcnt]; red3[2] = p.xch[(size_t)p.xcnt + (j - p.r0)]; }
+    } else {
+      for (int u = t; u < p.nwg_p; u += 256) red3[1] += p.b.vavpart[u];
       const int nS = rbj - p.S0p + 1;
       for (int idx = t; idx < nS; idx += 256) red3[2] += p.b.ypart[(size_t)(p.S0p + idx) * p.npad + j];
       const int np = num_pieces(rbj - p.S0p, T, p.qp);
@@ -171,9 +185,9 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
       dtot = p.b.dottot[t];
     }
     const double alpha0 = p.b.scal[jp & 1];
-    const double ajj = p.A[(size_t)j + (size_t)j * p.lda];   // still the panel-start value: A(:,j)
-                                                             // is not written until column j is finalized
-    if (r >= j && r < p.n) a_old = p.A[(size_t)r + (size_t)j * p.lda];
+    // still the panel-start value: A(:,j) is not written until column j is finalized
+    const double ajj = DIST ? p.xch[j - p.r0] : p.A[(size_t)j + (size_t)j * p.lda];
+    if (r >= j && r < p.n) a_old = DIST ? p.xch[r - p.r0] : p.A[(size_t)r + (size_t)j * p.lda];
     block_sum_n<3>(red3, s_red);
     const Refl rf = reflector(red3[0], alpha0);
     const double corr = 1.0 - rf.scale * alpha0;
@@ -197,7 +211,9 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
     double y = 0.0, accA = 0.0, aB = 0.0;
     if (r >= j && r < p.npad) {
       const int rb = r / TS;
-      {
+      if (DIST) {
+        if (q == 0) y = p.xch[(size_t)p.xcnt + (r - p.r0)];
+      } else {
         double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
         int S = p.S0p + q;
         const double *yp = p.b.ypart + r;
@@ -267,7 +283,7 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
   const int j = p.j;
   double sq = 0.0, xr = 0.0;
   if (q == 0 && r >= j && r < p.n) {
-    if (!p.finalize) a_old = p.A[(size_t)r + (size_t)j * p.lda];
+    if (!p.finalize) a_old = DIST ? p.xch[r - p.r0] : p.A[(size_t)r + (size_t)j * p.lda];
     const double a = a_old - accB;   // the updated column lives in xbuf / d only
     if (r == j) { p.d[j] = a; p.b.xbuf[r] = 0.0; }
     else {
@@ -319,7 +335,8 @@ struct SymvArgs {
   SytrdBufs b;
   int j;            // column whose reflector is applied; active rows/cols > j
   int i;            // in-panel index (number of finished panel columns)
-  int S0, NRB;      // first active strip, total row blocks
+  int S0, NRB;      // first active strip (of this member), total row blocks
+  int P;            // strip stride: 1, or the team size of a distributed run (strips S0, S0+P, ...)
   int q, nwg;       // tiles per workgroup, symv workgroups
   int ntiles;
   int ndot;         // 1 if a reducer workgroup (blockIdx 0) totals the panel products, else 0
@@ -359,6 +376,7 @@ __device__ __forceinline__ void part_fma(const d2_t (&a)[QC], int h, int rloc0, 
   }
 }
 
+template <bool DIST>
 __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
   __shared__ double s_vc[TS];            // v on the strip's columns
   __shared__ double s_y[2][4][TS];       // per-wave row-part partials, double buffered
@@ -393,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
   // ---- symv workgroup: a run of q tiles in strip-major order, software-pipelined by halves
   const int w = blockIdx.x - p.ndot;
   const int T = p.NRB - p.S0;
+  const int P = DIST ? p.P : 1;
   const int L0 = w * p.q;
   int L1 = L0 + p.q; if (L1 > p.ntiles) L1 = p.ntiles;
   double vav = 0.0;
@@ -400,21 +419,21 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
     if (t == 0) p.b.vavpart[w] = 0.0;
     return;
   }
-  int s = strip_of_tile(L0, T);
-  int rbrel = s + (L0 - tile_start(s, T));
+  int s = strip_of_tile(L0, T, P);
+  int S = p.S0 + s * P;                          // absolute strip, absolute row block
+  int rb = S + (L0 - tile_start(s, T, P));
   const size_t lda = (size_t)p.lda;
-  auto tile_ptr = [&](int ss, int rr) {
-    return p.A + (size_t)((p.S0 + rr) * TS + 2 * lane) + (size_t)((p.S0 + ss) * TS + wave * 32) * lda;
+  auto tile_ptr = [&](int SS, int RB) {
+    return p.A + (size_t)(RB * TS + 2 * lane) + (size_t)(SS * TS + wave * 32) * lda;
   };
   d2_t bufA[QC], bufB[QC];
-  const double *cur = tile_ptr(s, rbrel);
+  const double *cur = tile_ptr(S, rb);
   part_load(bufA, cur, p.lda);
   double tc[32];
   int buf = 0;
   bool new_strip = true;
   const double *svc = s_vc + wave * 32;
   for (int L = L0; L < L1; ++L) {
-    const int S = p.S0 + s, rb = p.S0 + rbrel;
     part_load(bufB, cur + QC * lda, p.lda);
     if (new_strip) {
       if (t < TS) s_vc[t] = xbuf[S * TS + t];   // x is 0 outside the active range j1 .. n-1
@@ -437,10 +456,10 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
     if (diag) part_fma<true>(bufA, 2, 2 * lane, wave * 32, svc, vr0, vr1, y0, y1, tc);
     else part_fma<false>(bufA, 2, 0, 0, svc, vr0, vr1, y0, y1, tc);
     // next tile (possibly in the next strip): issue its first part before finishing this one
-    int s2 = s, rb2 = rbrel + 1;
-    if (rb2 == T) { ++s2; rb2 = s2; }
-    const bool strip_ends = (rb2 == s2 && s2 != s) || (L + 1 == L1);
-    if (L + 1 < L1) { cur = tile_ptr(s2, rb2); part_load(bufA, cur, p.lda); }
+    int s2 = s, S2 = S, rb2 = rb + 1;
+    if (rb2 == p.NRB) { ++s2; S2 += P; rb2 = S2; }
+    const bool strip_ends = (s2 != s) || (L + 1 == L1);
+    if (L + 1 < L1) { cur = tile_ptr(S2, rb2); part_load(bufA, cur, p.lda); }
     if (diag) part_fma<true>(bufB, 3, 2 * lane, wave * 32, svc, vr0, vr1, y0, y1, tc);
     else part_fma<false>(bufB, 3, 0, 0, svc, vr0, vr1, y0, y1, tc);
     *reinterpret_cast<double2 *>(&s_y[buf][wave][2 * lane]) = make_double2(y0, y1);
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
     if (strip_ends) {
       // flush the strip's column part: transpose through LDS (16 columns per round), then
       // lanes 0..15 each add up one column's 64 lane-partials in a fixed order
-      const int piece = w - first_piece(s, T, p.q);
+      const int piece = w - first_piece(s, T, p.q, P);
       double *tp = p.b.tpart + ((size_t)S * p.NRB + piece) * TS + wave * 32;
       double *st = s_t[wave];
 #pragma unroll
@@ -484,10 +503,115 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
       new_strip = true;
       __syncthreads();   // s_vc is about to be rewritten
     }
-    s = s2; rbrel = rb2;
+    s = s2; S = S2; rb = rb2;
   }
   const double tot = block_sum(vav, s_red);
   if (t == 0) p.b.vavpart[w] = tot;
+}
+
+// ------------------------------------------------------------------------------ distributed run
+// One member of a team of P ranks (1 x P process grid, column-block-cyclic with 128-wide blocks:
+// member r owns the strips S = r, r+P, ...).  Every member holds a full-size A of which only its
+// own strips are kept current by the trailing updates, runs symv over its own strips, and the team
+// all-reduces one small window per column:
+//   [0, cnt)      raw entries of the next column (contributed by its owner, zeros elsewhere),
+//   [cnt, 2 cnt)  this member's part of y = A22 x,
+//   [2 cnt]       its part of x^T A x,
+// cnt = npad - r0 rows from the colupd row base r0 of the next column.  colupd<true> then runs
+// redundantly on identical data on every member, so the panel, d, e, tau and the reflector
+// columns stay bit-identical across the team with no further exchange.
+struct YredArgs {
+  int n, npad, lda, NRB;
+  const double *A;
+  SytrdBufs b;
+  int r0, cnt;
+  int jn;            // column whose raw entries travel (the next one to be updated), -1: none
+  int own_next;      // this member owns the strip of column jn
+  int with_y;        // 0 at a panel start: only the column part is filled
+  int S0, P, T, q, nwg;   // the member's symv geometry of this column (nwg = 0: it had no tiles)
+  double *xch;
+};
+
+constexpr int YR = 64;   // rows per yreduce workgroup (4 slices per row)
+
+__global__ __launch_bounds__(256) void yreduce_kernel(YredArgs p) {
+  __shared__ double s_acc[4][YR];
+  __shared__ double s_red[8];
+  const int t = threadIdx.x, lane = t & (YR - 1), q4 = t / YR;
+  const int r = p.r0 + blockIdx.x * YR + lane;
+  if (q4 == 0 && r < p.npad) {
+    double a = 0.0;
+    if (p.jn >= 0 && p.own_next && r >= p.jn && r < p.n) a = p.A[(size_t)r + (size_t)p.jn * p.lda];
+    p.xch[r - p.r0] = a;
+  }
+  if (!p.with_y) return;
+  double y = 0.0;
+  if (p.nwg > 0 && r < p.npad && r >= p.jn) {
+    const int rb = r / TS;
+    if (rb >= p.S0) {
+      const int kmax = (rb - p.S0) / p.P;
+      double y0 = 0.0, y1 = 0.0;
+      int k = q4;
+      for (; k + 4 <= kmax; k += 8) {
+        y0 += p.b.ypart[(size_t)(p.S0 + k * p.P) * p.npad + r];
+        y1 += p.b.ypart[(size_t)(p.S0 + (k + 4) * p.P) * p.npad + r];
+      }
+      if (k <= kmax) y0 += p.b.ypart[(size_t)(p.S0 + k * p.P) * p.npad + r];
+      if ((rb - p.S0) % p.P == 0) {
+        const int np = num_pieces(kmax, p.T, p.q, p.P);
+        for (int pc = q4; pc < np; pc += 4) y1 += p.b.tpart[((size_t)rb * p.NRB + pc) * TS + (r % TS)];
+      }
+      y = y0 + y1;
+    }
+  }
+  s_acc[q4][lane] = y;
+  __syncthreads();
+  if (q4 == 0 && r < p.npad)
+    p.xch[(size_t)p.cnt + (r - p.r0)] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+  if (blockIdx.x == 0) {
+    double v = 0.0;
+    for (int u = t; u < p.nwg; u += 256) v += p.b.vavpart[u];
+    const double tot = block_sum(v, s_red);
+    if (t == 0) p.xch[2 * (size_t)p.cnt] = tot;
+  }
+}
+
+// Rehearsal exchange for a team held by ONE process on one GPU: sum of the members' windows in
+// member order, written back to all of them (what ncclAllReduce does across processes).
+struct TeamBufs { double *buf[kMaxTeam]; int nmem; };
+__global__ void team_allreduce_kernel(TeamBufs tb, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double v = 0.0;
+  for (int m = 0; m < tb.nmem; ++m) v += tb.buf[m][i];
+  for (int m = 0; m < tb.nmem; ++m) tb.buf[m][i] = v;
+}
+
+// Operand table of the trailing update of one member: per panel, one GEMM per owned strip that
+// still has active columns (A22(:, strip) -= [V|W] [W|V](strip rows)^T, lower part).
+// Entry (panel, k): offsets {A, B, C} and dims {M, N, K} for the batched GEMM.
+__global__ void syr2k_table_kernel(int n, int npad, int lda, int P, int rank, int maxb,
+                                   long long *offs, int *dims) {
+  const int panel = blockIdx.x, k = threadIdx.x;
+  if (k >= maxb) return;
+  const int j0 = panel * NBP;
+  const int pw = (n - 1 - j0 < NBP) ? n - 1 - j0 : NBP;
+  const int r2 = j0 + pw;
+  const int Sf = r2 / TS;
+  const int Sfl = Sf + ((rank - Sf) % P + P) % P;
+  const int S = Sfl + k * P;
+  long long c0 = (long long)S * TS;
+  if (c0 < r2) c0 = r2;
+  int M = 0, N = 0;
+  if (c0 < n) {
+    M = n - (int)c0;
+    long long cend = (long long)(S + 1) * TS;
+    if (cend > n) cend = n;
+    N = (int)(cend - c0);
+  }
+  const size_t e = (size_t)panel * maxb + k;
+  offs[3 * e] = c0; offs[3 * e + 1] = c0; offs[3 * e + 2] = c0 * ((long long)lda + 1);
+  dims[3 * e] = M; dims[3 * e + 1] = N; dims[3 * e + 2] = (pw == NBP) ? 2 * NBP : pw;
 }
 
 // PDSYTRD leaves d on the diagonal and e on the sub-diagonal of A
@@ -565,12 +689,12 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
   c.n = n; c.npad = npad; c.lda = lda; c.ldv = ldv; c.A = A; c.V = V; c.d = d; c.e = e; c.tau = tau;
   c.b = b; c.NRB = NRB;
   SymvArgs sv{};
-  sv.n = n; sv.npad = npad; sv.lda = lda; sv.A = A; sv.b = b; sv.NRB = NRB;
+  sv.n = n; sv.npad = npad; sv.lda = lda; sv.A = A; sv.b = b; sv.NRB = NRB; sv.P = 1;
 
   auto launch_colupd = [&](int row_from) {
     c.r0 = (row_from / CR) * CR;
     const int nblk = ceil_div(npad - c.r0, CR);
-    hipLaunchKernelGGL(colupd_kernel, dim3(nblk), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(colupd_kernel<false>, dim3(nblk), dim3(256), 0, s, c);
     return nblk;
   };
   const int wg_target = knobs().wgs > 0 ? knobs().wgs : 512;   // 2 resident workgroups per CU
@@ -607,7 +731,7 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
         e0 = g_prof.ev[g_prof.used++]; e1 = g_prof.ev[g_prof.used++];
         (void)hipEventRecord(e0, s);
       }
-      hipLaunchKernelGGL(symv_kernel, dim3(sv.nwg + sv.ndot), dim3(256), 0, s, sv);
+      hipLaunchKernelGGL(symv_kernel<false>, dim3(sv.nwg + sv.ndot), dim3(256), 0, s, sv);
       if (timed) {
         (void)hipEventRecord(e1, s);
         const double m = (double)(n - j - 1);
@@ -638,6 +762,178 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
   c.finalize = 0; c.update = 1; c.j = n - 1; c.i_new = 0;
   launch_colupd(n - 1);
   hipLaunchKernelGGL(put_diag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, A, lda, d);
+}
+
+// ------------------------------------------------------------------------------ distributed host side
+namespace {
+struct DistLayout {
+  Layout base;
+  int maxb, npanels;
+  size_t off_xch, off_offs, off_dims, total;
+  DistLayout(int n, int P) : base(n) {
+    maxb = ceil_div(base.NRB, P) + 1;
+    npanels = ceil_div(n > 1 ? n - 1 : 1, NBP);
+    size_t o = base.total;
+    off_xch = o; o += al256((size_t)(2 * base.npad + 8) * 8);
+    off_offs = o; o += al256((size_t)npanels * maxb * 3 * sizeof(long long));
+    off_dims = o; o += al256((size_t)npanels * maxb * 3 * sizeof(int));
+    total = o;
+  }
+};
+}  // namespace
+
+size_t sytrd_dist_work_bytes(int n, int nranks) { return DistLayout(n, nranks > 0 ? nranks : 1).total; }
+
+void sytrd_team_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t count, void *) {
+  if (nmem <= 1 || count == 0) return;
+  TeamBufs tb{};
+  tb.nmem = nmem;
+  for (int m = 0; m < nmem; ++m) tb.buf[m] = bufs[m];
+  hipLaunchKernelGGL(team_allreduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, tb, count);
+}
+
+// Same column loop as sytrd_lower; every phase is issued for each member held by this process
+// (one in production, the whole team in the single-GPU rehearsal), with one exchange per column.
+void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, const SytrdExchange &x) {
+  if (n <= 0 || nmem <= 0 || nmem > kMaxTeam) return;
+  const int P = x.nranks;
+  const DistLayout L(n, P);
+  const int npad = L.base.npad, NRB = L.base.NRB;
+
+  struct MemberState {
+    SytrdBufs b; double *xch; long long *offs; int *dims;
+    ColupdArgs c; SymvArgs sv; YredArgs yr;
+  };
+  std::vector<MemberState> st(nmem);
+  double *xbufs[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    char *w = (char *)mem[m].work;
+    MemberState &M = st[m];
+    SytrdBufs &b = M.b;
+    b.xbuf = (double *)(w + L.base.off_x); b.P = (double *)(w + L.base.off_P);
+    b.ypart = (double *)(w + L.base.off_y); b.tpart = (double *)(w + L.base.off_t);
+    b.vavpart = (double *)(w + L.base.off_vav); b.normpart = (double *)(w + L.base.off_norm); b.nch = L.base.nch;
+    b.dotpart = (double *)(w + L.base.off_dot); b.dottot = (double *)(w + L.base.off_dtot);
+    b.scal = (double *)(w + L.base.off_scal);
+    M.xch = (double *)(w + L.off_xch); M.offs = (long long *)(w + L.off_offs); M.dims = (int *)(w + L.off_dims);
+    xbufs[m] = M.xch;
+    (void)hipMemsetAsync(w, 0, L.total, s);
+    hipLaunchKernelGGL(syr2k_table_kernel, dim3(L.npanels), dim3(round_up(L.maxb, 64)), 0, s, n, npad,
+                       mem[m].lda, P, mem[m].rank, L.maxb, M.offs, M.dims);
+    ColupdArgs &c = M.c; c = ColupdArgs{};
+    c.n = n; c.npad = npad; c.lda = mem[m].lda; c.ldv = mem[m].ldv; c.A = mem[m].A; c.V = mem[m].V;
+    c.d = mem[m].d; c.e = mem[m].e; c.tau = mem[m].tau; c.b = b; c.NRB = NRB; c.xch = M.xch;
+    SymvArgs &sv = M.sv; sv = SymvArgs{};
+    sv.n = n; sv.npad = npad; sv.lda = mem[m].lda; sv.A = mem[m].A; sv.b = b; sv.NRB = NRB; sv.P = P;
+    YredArgs &yr = M.yr; yr = YredArgs{};
+    yr.n = n; yr.npad = npad; yr.lda = mem[m].lda; yr.NRB = NRB; yr.A = mem[m].A; yr.b = b; yr.P = P;
+    yr.xch = M.xch;
+  }
+  // exchange of the window of column jn (with or without the symv sums), then colupd on every member
+  auto exchange = [&](int jn, bool with_y) {
+    const int r0 = (jn / CR) * CR, cnt = npad - r0;
+    for (int m = 0; m < nmem; ++m) {
+      YredArgs &yr = st[m].yr;
+      yr.r0 = r0; yr.cnt = cnt; yr.jn = jn; yr.with_y = with_y ? 1 : 0;
+      yr.own_next = ((jn / TS) % P == mem[m].rank) ? 1 : 0;
+      hipLaunchKernelGGL(yreduce_kernel, dim3(ceil_div(cnt, YR)), dim3(256), 0, s, yr);
+    }
+    x.allreduce(s, nmem, xbufs, with_y ? 2 * (size_t)cnt + 1 : (size_t)cnt, x.user);
+    return cnt;
+  };
+  auto launch_colupd = [&](int row_from, int cnt) {
+    const int r0 = (row_from / CR) * CR;
+    const int nblk = ceil_div(npad - r0, CR);
+    for (int m = 0; m < nmem; ++m) {
+      st[m].c.r0 = r0; st[m].c.xcnt = cnt;
+      hipLaunchKernelGGL(colupd_kernel<true>, dim3(nblk), dim3(256), 0, s, st[m].c);
+    }
+    return nblk;
+  };
+
+  int nchunks_cur = 0;
+  for (int j0 = 0; j0 < n - 1; j0 += NBP) {
+    if (knobs().max_cols >= 0 && j0 >= knobs().max_cols) break;
+    const int pw = (n - 1 - j0 < NBP) ? n - 1 - j0 : NBP;
+    // first column of the panel: its raw entries from the owner of the strip
+    for (int m = 0; m < nmem; ++m) { ColupdArgs &c = st[m].c; c.finalize = 0; c.update = 1; c.j = j0; c.i_new = 0; }
+    nchunks_cur = launch_colupd(j0, exchange(j0, false));
+    for (int i = 0; i < pw; ++i) {
+      const int j = j0 + i;
+      const int S0 = (j + 1) / TS;
+      for (int m = 0; m < nmem; ++m) {
+        SymvArgs &sv = st[m].sv;
+        const int rank = mem[m].rank;
+        const int S0l = S0 + ((rank - S0) % P + P) % P;      // first active strip of this member
+        const int T = NRB - S0l;                              // its length in tiles (<= 0: none)
+        sv.j = j; sv.i = i; sv.S0 = S0l;
+        sv.ntiles = (T > 0) ? tile_start(ceil_div(T, P), T, P) : 0;
+        if (sv.ntiles > 0) {
+          const int target = (knobs().wgs > 0) ? knobs().wgs : (sv.ntiles <= 820 ? 256 : 512);
+          sv.q = ceil_div(sv.ntiles, target);
+          if (knobs().G > 0 && sv.q < knobs().G) sv.q = knobs().G;
+          sv.nwg = ceil_div(sv.ntiles, sv.q);
+        } else { sv.q = 1; sv.nwg = 0; }
+        sv.ndot = (i > 0) ? 1 : 0;
+        sv.nchunks = nchunks_cur;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = g_prof.enabled && m == 0 && (j % g_prof.stride == 0) && sv.nwg > 0;
+        if (timed) {
+          if (g_prof.used + 2 > g_prof.ev.size()) {
+            const size_t old = g_prof.ev.size();
+            g_prof.ev.resize(old + 4096);
+            for (size_t q = old; q < g_prof.ev.size(); ++q) (void)hipEventCreate(&g_prof.ev[q]);
+          }
+          e0 = g_prof.ev[g_prof.used++]; e1 = g_prof.ev[g_prof.used++];
+          (void)hipEventRecord(e0, s);
+        }
+        if (sv.nwg + sv.ndot > 0)
+          hipLaunchKernelGGL(symv_kernel<true>, dim3(sv.nwg + sv.ndot), dim3(256), 0, s, sv);
+        if (timed) {
+          (void)hipEventRecord(e1, s);
+          // this member's share of the lower triangle of the active matrix (by tiles)
+          const double mm = (double)(n - j - 1);
+          const int Tall = NRB - S0;
+          g_prof.bytes += 8.0 * mm * (mm + 1.0) * 0.5 * (double)sv.ntiles / (double)(Tall * (Tall + 1) / 2);
+          g_prof.launches += 1;
+        }
+        YredArgs &yr = st[m].yr;
+        yr.S0 = S0l; yr.T = T > 0 ? T : 0; yr.q = sv.q; yr.nwg = sv.nwg;
+        ColupdArgs &c = st[m].c;
+        c.finalize = 1; c.jp = j; c.ip = i; c.S0p = S0l; c.qp = sv.q; c.nwg_p = sv.nwg;
+        c.nchunks_p = nchunks_cur;
+        c.update = (i + 1 < pw) ? 1 : 0; c.j = j + 1; c.i_new = i + 1;
+      }
+      const int nb = launch_colupd(j + 1, exchange(j + 1, true));
+      if (i + 1 < pw) nchunks_cur = nb;
+    }
+    // trailing update of the strips each member owns: one batched GEMM (a GEMM per strip)
+    const int r2 = j0 + pw;
+    if (n - r2 > 0) {
+      const int Sf = r2 / TS, panel = j0 / NBP;
+      for (int m = 0; m < nmem; ++m) {
+        const int Sfl = Sf + ((mem[m].rank - Sf) % P + P) % P;
+        if (Sfl >= NRB) continue;
+        const int nb = ceil_div(NRB - Sfl, P);
+        long long c0 = (long long)Sfl * TS; if (c0 < r2) c0 = r2;
+        if (c0 >= n) continue;
+        const double *P1 = st[m].b.P, *P2 = st[m].b.P + (size_t)NBP * npad;
+        GemmDesc g{};
+        g.M = n - (int)c0; g.N = TS; g.K = (pw == NBP) ? 2 * NBP : pw;
+        g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
+        g.A = P1; g.lda = npad; g.strideA = 0; g.B = P2; g.ldb = npad; g.strideB = 0;
+        g.C = mem[m].A; g.ldc = mem[m].lda; g.strideC = 0; g.batch = nb; g.lower_only = true;
+        g.d_offs = st[m].offs + (size_t)panel * L.maxb * 3; g.d_dims = st[m].dims + (size_t)panel * L.maxb * 3;
+        gemm(s, g);
+        if (pw != NBP) { g.A = P2; g.B = P1; gemm(s, g); }   // short last panel: columns >= pw of the image are stale
+      }
+    }
+  }
+  // last diagonal entry
+  for (int m = 0; m < nmem; ++m) { ColupdArgs &c = st[m].c; c.finalize = 0; c.update = 1; c.j = n - 1; c.i_new = 0; }
+  launch_colupd(n - 1, exchange(n - 1, false));
+  for (int m = 0; m < nmem; ++m)
+    hipLaunchKernelGGL(put_diag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, mem[m].A, mem[m].lda, mem[m].d);
 }
 
 void symv_profile_enable(int stride) {

@@ -72,6 +72,13 @@ def load_library(path=None):
         "ek_hip_potrf": (c_int, [c_int, _dp, _ip]),
         "ek_hip_sygst": (c_int, [c_int, _dp, _ip, _dp, _ip, _dp]),
         "ek_hip_sytrd": (c_int, [c_int, _dp, _ip, _dp, _dp, _dp]),
+        "ek_hip_sytrd_team": (c_int, [c_int, _dp, _ip, _dp, _dp, _dp, c_int, _llp]),
+        "ek_hip_comm_unique_id": (c_int, [vp, c_int]),
+        "ek_hip_comm_init": (c_int, [vp, c_int, c_int, c_int]),
+        "ek_hip_comm_size": (c_int, []),
+        "ek_hip_comm_rank": (c_int, []),
+        "ek_hip_comm_destroy": (c_int, []),
+        "ek_hip_comm_allreduce_device": (c_int, [vp, ctypes.c_longlong]),
         "ek_hip_stedc": (c_int, [c_int, _dp, _dp, _dp, _ip]),
         "ek_hip_ormtr": (c_int, [c_int, c_int, _dp, _ip, _dp, _dp, _ip]),
         "ek_hip_trtrs": (c_int, [c_int, c_int, _dp, _ip, _dp, _ip]),
@@ -113,6 +120,8 @@ EXPORTED_SYMBOLS = (
     "ek_hip_memcpy_h2d", "ek_hip_memcpy_d2h", "ek_hip_synchronize", "ek_hip_synth_matrix_device",
     "ek_hip_profile_symv", "ek_hip_profile_symv_get", "ek_hip_debug_sytrd",
     "ek_hip_residual_device", "ek_hip_orthogonality_device", "ek_hip_ipratios_device", "ek_hip_check",
+    "ek_hip_sytrd_team", "ek_hip_comm_unique_id", "ek_hip_comm_init", "ek_hip_comm_size", "ek_hip_comm_rank",
+    "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device",
 )
 
 
@@ -310,6 +319,42 @@ def sytrd(A):
     d = np.zeros(max(n, 1)); e = np.zeros(max(n, 1)); tau = np.zeros(max(n, 1))
     info = lib.ek_hip_sytrd(n, _P(A), _I(_desc_for(A)), _P(d), _P(e), _P(tau))
     return A, d[:n], e[:max(n - 1, 0)], tau[:max(n - 1, 0)], info
+
+
+def sytrd_team(A, nteam):
+    """PDSYTRD('L') on a 1 x P grid, 128-wide column blocks (ek_hip_sytrd_team).  nteam >= 1: the
+    whole team rehearsed in this process on one GPU; nteam == 0: this process is one rank of the
+    attached communicator.  Returns (A_reflectors, d, e, tau, info, mismatch)."""
+    lib = load_library()
+    A = np.array(_farr(A), order="F", copy=True)
+    n = A.shape[0]
+    d = np.zeros(max(n, 1)); e = np.zeros(max(n, 1)); tau = np.zeros(max(n, 1))
+    mm = ctypes.c_longlong(-1)
+    info = lib.ek_hip_sytrd_team(n, _P(A), _I(_desc_for(A)), _P(d), _P(e), _P(tau), nteam, ctypes.byref(mm))
+    return A, d[:n], e[:max(n - 1, 0)], tau[:max(n - 1, 0)], info, mm.value
+
+
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 calls this, the host broadcasts it)."""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(128)
+    rc = lib.ek_hip_comm_unique_id(buf, 128)
+    if rc:
+        raise SolverError("ek_hip_comm_unique_id: %d" % rc, rc)
+    return buf.raw
+
+
+def comm_init(uid, nranks, rank):
+    """Attach the RCCL communicator of the distributed path (include/ek_hip.h)."""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(bytes(uid), 128)
+    rc = lib.ek_hip_comm_init(buf, 128, nranks, rank)
+    if rc:
+        raise SolverError("ek_hip_comm_init: %d" % rc, rc)
+
+
+def comm_destroy():
+    load_library().ek_hip_comm_destroy()
 
 
 def stedc(d, e):

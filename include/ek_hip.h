@@ -134,6 +134,27 @@ int ek_hip_solve_device_grid(int problem, int n, int n_vec,
                              int nb, int nprow, int npcol, int myrow, int mycol,
                              double *stage_seconds, int n_stages);
 
+/* ---- Communicator of the distributed path: one rank per GPU, RCCL over xGMI in
+ * place of the BLACS context the reference creates in setup_distribution (processes.f90:42-66).
+ * Rank 0 obtains the id (EK_HIP_COMM_ID_BYTES bytes), the host broadcasts it by its own means
+ * (MPI_Bcast in a Fortran/MPI host, torch.distributed in the tests) and every rank calls
+ * ek_hip_comm_init with its rank in row-major grid order (myrow*npcol + mycol, processes.f90:23).
+ * While a communicator is attached, ek_hip_solve_device_grid / ek_hip_solve_replicated /
+ * ek_hip_solve on a grid of exactly that many ranks distribute PDSYTRD over the ranks (1 x P
+ * column-block-cyclic, 128-wide blocks, one ncclAllReduce of <= 2n+1 doubles per Householder
+ * column issued on the library's stream) on top of the column sharding of the eigenvector stages.
+ * Collective: every rank of the communicator must make the same calls in the same order
+ * (as main.f90:100-104 does).  Returns: -995 no communicator, -996 RCCL error, -997 RCCL not
+ * loadable, -994 rank/grid-cell mismatch. */
+#define EK_HIP_COMM_ID_BYTES 128
+int ek_hip_comm_unique_id(void *id, int bytes);
+int ek_hip_comm_init(const void *id, int bytes, int nranks, int rank);
+int ek_hip_comm_size(void);                     /* 0 when none is attached */
+int ek_hip_comm_rank(void);                     /* -1 when none is attached */
+int ek_hip_comm_destroy(void);
+/* in-place sum over the ranks of a device vector (the collective PDSYTRD issues per column) */
+int ek_hip_comm_allreduce_device(double *dbuf, long long count);
+
 /* Stage-level entry points: one per ScaLAPACK call of the reference, host arrays,
  * 1x1 grid descriptors.  They exist so the path can be replaced (and tested) call by call. */
 /* PDPOTRF('L', n, B, 1, 1, desc_B, info)        generalized_to_standard.f90:24 */
@@ -144,6 +165,14 @@ int ek_hip_sygst(int n, double *A_loc, const int desc_A[9],
 /* PDSYTRD('L', n, A, 1,1, desc_A, d, e, tau, work, lwork, info)     solver_scalapack_all.f90:59
  * d(n), e(n-1), tau(n-1) are returned replicated (the reference gathers them, :75-78). */
 int ek_hip_sytrd(int n, double *A_loc, const int desc_A[9], double *d, double *e, double *tau);
+/* PDSYTRD on a 1 x P process grid (column-block-cyclic, 128-wide blocks).  Input: the full matrix
+ * (replicated-input mode), output: as ek_hip_sytrd, complete and bit-identical on every rank.
+ *   nteam == 0: this process is one rank of the attached communicator;
+ *   nteam >= 1: rehearsal of a whole team of nteam ranks inside this process on one GPU (the
+ *               exchange is a device kernel); *mismatch = number of doubles in which the ranks'
+ *               results (lower triangle of A, d, e, tau) differ from rank 0's (must be 0). */
+int ek_hip_sytrd_team(int n, double *A_loc, const int desc_A[9], double *d, double *e, double *tau,
+                      int nteam, long long *mismatch);
 /* PDSTEDC('I', n, d, e, Z, 1,1, desc_Z, ...)                         :96
  * d in: diagonal, out: eigenvalues ascending; e in: sub-diagonal (destroyed). */
 int ek_hip_stedc(int n, double *d, double *e, double *Z_loc, const int desc_Z[9]);

@@ -1,0 +1,172 @@
+"""GPU parity of the distributed tridiagonalisation (PDSYTRD on a 1 x P grid).
+
+A pool box has one GPU and RCCL refuses two ranks on one device, so the algorithm is checked in
+two halves that together make the production path:
+  * the whole team of P ranks rehearsed inside one process (every rank with its own copy of A and
+    its own workspace; the per-column exchange is a device kernel with all-reduce semantics):
+    ownership of the strips, stale non-owned tiles, the travelling raw column, the per-strip
+    trailing updates -- everything except the wire;
+  * the RCCL binding itself (ncclCommInitRank / ncclAllReduce on the library's stream) with a
+    communicator of size 1, through the same code path a rank of a larger team takes.
+Results are held to the same bounds as the single-GPU stage (tests/test_gpu_blocks.py) and to
+bit-identity across the ranks of a team.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+EPS = 2.220446049250313e-16
+
+
+def _tridiag_check(A, Ar, d, e, tau, oracle):
+    n = A.shape[0]
+    T = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    Q = oracle.ormtr_lower(Ar, tau, np.eye(n))
+    return np.abs(Q @ T @ Q.T - A).max(), np.abs(Q.T @ Q - np.eye(n)).max()
+
+
+def _check_against_single(hip, oracle, A, Ar, d, e, tau):
+    n = A.shape[0]
+    scale = np.abs(A).max()
+    Ar1, d1, e1, tau1, info1 = hip.sytrd(A)
+    assert info1 == 0
+    # same algorithm, different summation order of y = A22 x: element-wise only loosely
+    assert np.abs(d - d1).max() <= 1e-9 * scale
+    assert np.abs(e - e1).max() <= 1e-9 * scale
+    assert np.abs(tau - tau1).max() <= 1e-9
+    res, orth = _tridiag_check(A, Ar, d, e, tau, oracle)
+    assert res <= 64 * n * EPS * scale
+    assert orth <= 64 * n * EPS
+    T = np.diag(d) + np.diag(e, -1) + np.diag(e, 1)
+    assert np.abs(np.linalg.eigvalsh(T) - np.linalg.eigvalsh(A)).max() <= 8 * n * EPS * scale
+
+
+@pytest.mark.parametrize("n,P", [(2, 2), (3, 4), (64, 2), (130, 2), (257, 3), (400, 4), (700, 2),
+                                 (700, 8), (1000, 5), (1100, 16), (1537, 8)])
+def test_sytrd_team_rehearsal(hip, oracle, n, P):
+    A = oracle.synth_matrix(n, 1)
+    Ar, d, e, tau, info, mismatch = hip.sytrd_team(A, P)
+    assert info == 0
+    assert mismatch == 0          # every rank of the team ends with the same bits
+    _check_against_single(hip, oracle, A, Ar, d, e, tau)
+
+
+def test_sytrd_team_of_one_is_the_same_algorithm(hip, oracle):
+    """P = 1 through the distributed code path (exchange of a team of one is the identity)."""
+    n = 515
+    A = oracle.synth_matrix(n, 1)
+    Ar, d, e, tau, info, mismatch = hip.sytrd_team(A, 1)
+    assert info == 0 and mismatch == 0
+    _check_against_single(hip, oracle, A, Ar, d, e, tau)
+
+
+def test_sytrd_team_reproducible(hip, oracle):
+    A = oracle.synth_matrix(600, 1)
+    r1 = hip.sytrd_team(A, 4)
+    r2 = hip.sytrd_team(A, 4)
+    for a, b in zip(r1[:4], r2[:4]):
+        assert np.array_equal(a, b)
+
+
+def test_sytrd_team_rejects_bad_team(hip, oracle):
+    A = oracle.synth_matrix(8, 1)
+    assert hip.sytrd_team(A, 17)[4] == -7
+    assert hip.sytrd_team(A, -1)[4] == -7
+
+
+@pytest.fixture
+def comm1(hip):
+    """A size-1 RCCL communicator attached to the library (the binding a rank of a team uses)."""
+    uid = hip.comm_unique_id()
+    assert len(uid) == 128
+    hip.comm_init(uid, 1, 0)
+    lib = hip.load_library()
+    assert lib.ek_hip_comm_size() == 1 and lib.ek_hip_comm_rank() == 0
+    yield lib
+    hip.comm_destroy()
+    assert lib.ek_hip_comm_size() == 0 and lib.ek_hip_comm_rank() == -1
+
+
+def test_rccl_allreduce_binding(hip, comm1):
+    import ctypes
+    lib = comm1
+    x = np.arange(1000, dtype=np.float64) * 0.5 - 3.0
+    dptr = ctypes.c_void_p()
+    assert lib.ek_hip_malloc(ctypes.byref(dptr), x.nbytes) == 0
+    try:
+        assert lib.ek_hip_memcpy_h2d(dptr, x.ctypes.data_as(ctypes.c_void_p), x.nbytes) == 0
+        assert lib.ek_hip_comm_allreduce_device(dptr, x.size) == 0
+        y = np.zeros_like(x)
+        assert lib.ek_hip_memcpy_d2h(y.ctypes.data_as(ctypes.c_void_p), dptr, x.nbytes) == 0
+        assert np.array_equal(x, y)          # sum over one rank
+    finally:
+        lib.ek_hip_free(dptr)
+
+
+def test_allreduce_without_communicator(hip):
+    lib = hip.load_library()
+    assert lib.ek_hip_comm_size() == 0
+    assert lib.ek_hip_comm_allreduce_device(None, 0) == -995
+
+
+@pytest.mark.parametrize("n", [130, 700])
+def test_sytrd_over_rccl_world_of_one(hip, oracle, comm1, n):
+    A = oracle.synth_matrix(n, 1)
+    Ar, d, e, tau, info, mismatch = hip.sytrd_team(A, 0)     # 0: use the attached communicator
+    assert info == 0
+    _check_against_single(hip, oracle, A, Ar, d, e, tau)
+    # and it is the very computation of the rehearsal with a team of one
+    Ar1, d1, e1, tau1, info1, _ = hip.sytrd_team(A, 1)
+    assert info1 == 0
+    assert np.array_equal(d, d1) and np.array_equal(e, e1) and np.array_equal(tau, tau1)
+    assert np.array_equal(np.tril(Ar), np.tril(Ar1))
+
+
+def test_sytrd_team_zero_needs_communicator(hip, oracle):
+    A = oracle.synth_matrix(8, 1)
+    assert hip.sytrd_team(A, 0)[4] == -7
+
+
+@pytest.mark.parametrize("problem,n,n_vec", [("gep", 300, 300), ("sep", 515, 515), ("gep", 400, 37)])
+def test_whole_path_with_communicator_attached(hip, oracle, comm1, problem, n, n_vec):
+    """ek_hip_solve_device_grid with a communicator of the grid's size takes the distributed
+    tridiagonalisation (here 1 x 1 over RCCL) and must agree with the plain single-GPU solve."""
+    import ctypes
+    lib = comm1
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2) if problem == "gep" else None
+    pb = 1 if problem == "gep" else 0
+
+    def dev(M):
+        p = ctypes.c_void_p()
+        assert lib.ek_hip_malloc(ctypes.byref(p), M.nbytes) == 0
+        assert lib.ek_hip_memcpy_h2d(p, M.ctypes.data_as(ctypes.c_void_p), M.nbytes) == 0
+        return p
+
+    def run(grid):
+        dA = dev(np.asfortranarray(A)); dB = dev(np.asfortranarray(B)) if B is not None else None
+        w = np.zeros(n); Z = np.zeros((n, n_vec), order="F")
+        dw = dev(w); dZ = dev(Z)
+        try:
+            if grid:
+                info = lib.ek_hip_solve_device_grid(pb, n, n_vec, dA, n, dB, n, dw, dZ, n, 64, 1, 1, 0, 0, None, 0)
+            else:
+                info = lib.ek_hip_solve_device(pb, n, n_vec, dA, n, dB, n, dw, dZ, n, None, 0)
+            assert info == 0
+            assert lib.ek_hip_memcpy_d2h(w.ctypes.data_as(ctypes.c_void_p), dw, w.nbytes) == 0
+            assert lib.ek_hip_memcpy_d2h(Z.ctypes.data_as(ctypes.c_void_p), dZ, Z.nbytes) == 0
+        finally:
+            for p in (dA, dB, dw, dZ):
+                if p is not None:
+                    lib.ek_hip_free(p)
+        return w, Z
+
+    w_d, Z_d = run(True)
+    w_or = oracle.solve(A, B)[0] if B is not None else np.linalg.eigvalsh(A)
+    tol = 4 * n * EPS * np.abs(w_or).max()
+    assert np.abs(w_d - w_or).max() <= tol
+    Bm = B if B is not None else np.eye(n)
+    R = A @ Z_d - (Bm @ Z_d) * w_d[:n_vec]
+    assert np.abs(R).max() <= 1e-12
+    G = Z_d.T @ Bm @ Z_d
+    assert np.abs(G - np.eye(n_vec)).max() <= 1e-11
