@@ -103,6 +103,94 @@ def cpu_baseline_scalapack(problem, sample_n):
             "gflops_equiv": flops(problem, sample_n, sample_n) / solve / 1e9}
 
 
+_emitted = False
+_pending = None      # the main JSON line as soon as it exists (the watchdog prints it if the probe hangs)
+
+
+def emit(out):
+    """Prints THE one JSON line, once."""
+    global _emitted
+    if not _emitted:
+        _emitted = True
+        print(json.dumps(out), flush=True)
+
+
+def grid_probe(args, lib, solver, dist, torch, dev, rank, world, n, problem, n_vec, dA, dB, dZ, dw, regenerate):
+    """ONE problem on the 1 x world grid with the library's RCCL communicator attached
+    (tridiagonalisation distributed: one ncclAllReduce per Householder column; eigenvector stages
+    column-sharded).  Measured after, and outside, the headline region; a watchdog abandons it
+    (os._exit after printing the headline) if a collective never returns, since a pool box has a
+    single GPU and this path can only be rehearsed there."""
+    import threading
+    from eigenkernel_amd import descriptor as dsc
+    NB = 64
+    res = {"distribution": "1 x %d process grid, replicated inputs; PDSYTRD distributed over RCCL "
+                           "(1 all-reduce/column), eigenvector columns sharded" % world}
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(args.grid_probe_timeout):
+            sys.stderr.write("[bench] grid probe abandoned after %.0f s on rank %d\n" % (args.grid_probe_timeout, rank))
+            if rank == 0 and _pending is not None:
+                _pending["grid_probe"] = dict(res, error="timeout")
+                emit(_pending)
+            sys.stdout.flush()
+            os._exit(0)
+    try:
+        # the headline line is complete before the probe starts: keep it for the watchdog
+        threading.Thread(target=watchdog, daemon=True).start()
+        uid = [solver.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        solver.comm_init(uid[0], world, rank)
+        my_cols = dsc.local_indices(n_vec, NB, rank, world)
+        nc_loc = len(my_cols)
+        stage = (ctypes.c_double * 8)()
+        times = []
+        for it in range(2):                       # 1 warm-up + 1 timed solve
+            regenerate(0)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            info = lib.ek_hip_solve_device_grid(problem, n, n_vec, dA.data_ptr(), n,
+                                                dB.data_ptr() if dB is not None else None, n,
+                                                dw.data_ptr(), dZ.data_ptr(), n, NB, 1, world, 0, rank, stage, 8)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            if info != 0:
+                raise RuntimeError("ek_hip_solve_device_grid info=%d" % info)
+        tt = torch.tensor([times[-1]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+        res.update({"seconds_per_solve": t, "eigenpairs_per_s": n_vec / t,
+                    "tflops_equiv": flops(problem, n, n_vec) / t / 1e12, "scaling": "strong",
+                    "stage_seconds_rank0": {lib.ek_hip_stage_name(i).decode(): stage[i] for i in range(8)}})
+        # parity of this rank's eigenpairs (reference's acceptance quantities, on the GPU)
+        w = dw.cpu().numpy()
+        ok = bool((w[1:n_vec] >= w[:n_vec - 1]).all())
+        if nc_loc > 0:
+            regenerate(0)
+            an, ave, mx, orth = (ctypes.c_double(0) for _ in range(4))
+            dwc = torch.from_numpy(np.ascontiguousarray(w[my_cols])).to(dev)
+            rc1 = lib.ek_hip_residual_device(problem, n, nc_loc, dA.data_ptr(), n,
+                                             dB.data_ptr() if dB is not None else None, n, dwc.data_ptr(),
+                                             dZ.data_ptr(), n, ctypes.byref(an), ctypes.byref(ave), ctypes.byref(mx))
+            rc2 = lib.ek_hip_orthogonality_device(problem, n, 1, nc_loc, dB.data_ptr() if dB is not None else None, n,
+                                                  dZ.data_ptr(), n, ctypes.byref(orth))
+            ok = ok and rc1 == 0 and rc2 == 0 and mx.value <= 1e-14 * max(1.0, (n / 1024.0) ** 0.5) and orth.value <= 1e-11
+            res["parity_rank0"] = {"residual_norm_max": mx.value, "orthogonality": orth.value}
+        okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        res["parity_ok_all_ranks"] = bool(okt.item() > 0.5)
+        wt = torch.from_numpy(w.copy()).to(dev)
+        wmax = wt.clone(); wmin = wt.clone()
+        dist.all_reduce(wmax, op=dist.ReduceOp.MAX); dist.all_reduce(wmin, op=dist.ReduceOp.MIN)
+        res["eigenvalues_identical_on_all_ranks"] = bool(torch.equal(wmax, wmin))
+        solver.comm_destroy()
+    except Exception as exc:   # the probe never takes the headline down
+        res["error"] = repr(exc)
+    done.set()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,10 +204,12 @@ def main():
                     help="order of the CPU-oracle sample (scalar C port, 1 core)")
     ap.add_argument("--scalapack-sample-n", type=int, default=4096,
                     help="order of the ScaLAPACK-path sample (all physical cores)")
-    ap.add_argument("--distribution", choices=["replicas", "columns"], default="replicas",
+    ap.add_argument("--distribution", choices=["replicas", "columns", "grid"], default="replicas",
                     help="N>1 GPUs: 'replicas' = one independent problem per rank (weak scaling, default); "
                          "'columns' = ONE problem on a 1 x N process grid in replicated-input mode "
-                         "(ek_hip_solve_device_grid: reduction replicated, eigenvector columns sharded; strong scaling)")
+                         "(ek_hip_solve_device_grid: reduction replicated, eigenvector columns sharded; strong scaling); "
+                         "'grid' = the same with the library's RCCL communicator attached: the tridiagonalisation is "
+                         "distributed over the N ranks as well (one all-reduce per Householder column over xGMI)")
     ap.add_argument("--virtual-grid", type=int, default=0,
                     help="with --distribution columns on ONE GPU: play rank --virtual-rank of a 1 x P grid "
                          "(the mode has no collective, so a rank's time does not depend on the others)")
@@ -130,6 +220,14 @@ def main():
                     help="time the symv launch of every k-th column with HIP events (1 = all launches; "
                          "a pair of event records costs ~5 us of host time, 90 ms per solve at k = 1)")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-grid-probe", action="store_true",
+                    help="N>1 with --distribution replicas: skip the extra measurement of ONE problem on the "
+                         "1 x N grid with the tridiagonalisation distributed over RCCL (reported as \"grid_probe\")")
+    ap.add_argument("--force-grid-probe", action="store_true",
+                    help="run the grid probe at world size 1 too (rehearsal of the code path on a one-GPU box; "
+                         "needs a torch.distributed launch)")
+    ap.add_argument("--grid-probe-timeout", type=float, default=240.0,
+                    help="seconds after which a stuck grid probe is abandoned (the main line is still printed)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,7 +260,13 @@ def main():
     K = args.steps
     dAs = [torch.empty((n, n), dtype=torch.float64, device=dev) for _ in range(K)]
     dBs = [torch.empty((n, n), dtype=torch.float64, device=dev) for _ in range(K)] if problem == 1 else None
-    columns = args.distribution == "columns"
+    columns = args.distribution in ("columns", "grid")
+    if args.distribution == "grid":
+        # RCCL communicator inside the library: rank 0 makes the id, torch.distributed carries it
+        uid = [solver.comm_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
+        solver.comm_init(uid[0], world, rank)
     NB = 64                                        # g_block_size (global_variables.f90:5)
     if columns:
         from eigenkernel_amd import descriptor as dsc
@@ -251,6 +355,8 @@ def main():
         assert mx.value <= parity["bounds"]["residual_norm_max"], parity
         assert orth.value <= parity["bounds"]["orthogonality"], parity
 
+    global _pending
+    out = None
     if rank == 0:
         value = (1 if columns else world) * n_vec * K / total
         out = {
@@ -266,8 +372,10 @@ def main():
                                    "full spectrum, 1 problem per GPU" % (n, "generalized EVP (Cholesky+reduce+SEP)"
                                                                          if problem == 1 else "standard EVP"),
                        "n": n, "problem": args.problem, "n_vec": n_vec,
-                       "parallelism": ("1 x %d process grid, replicated inputs, eigenvector columns sharded "
-                                       "(rank %d%s)" % (npcol, mycol, ", played on one GPU" if world == 1 else "")
+                       "parallelism": ("1 x %d process grid, replicated inputs, %seigenvector columns sharded "
+                                       "(rank %d%s)" % (npcol, "tridiagonalisation distributed over RCCL, "
+                                                        if args.distribution == "grid" else "",
+                                                        mycol, ", played on one GPU" if world == 1 else "")
                                        if columns else "replicas x%d" % world if world > 1 else "1 GPU")},
             "tflops_equiv": (1 if columns else world) * flops(problem, n, n_vec) * K / total / 1e12,
             "fp64_mfma_peak_tflops": FP64_MFMA_PEAK_TFLOPS,
@@ -298,7 +406,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline_scalapack(problem, args.scalapack_sample_n)
             out["cpu_baseline"] = base if base is not None else cpu_baseline(problem, args.cpu_sample_n)
-        print(json.dumps(out))
+        _pending = out
+    if ((world > 1 or args.force_grid_probe) and dist is not None and args.distribution == "replicas"
+            and not args.no_grid_probe):
+        probe = grid_probe(args, lib, solver, dist, torch, dev, rank, world, n, problem, n_vec,
+                           dAs[0], dBs[0] if problem == 1 else None, dZ, dw, regenerate)
+        if out is not None:
+            out["grid_probe"] = probe
+    if out is not None:
+        emit(out)
+    if args.distribution == "grid":
+        solver.comm_destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

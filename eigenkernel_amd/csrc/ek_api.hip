@@ -726,6 +726,54 @@ int ek_hip_debug_sytrd(int n, int ld, int reps, double *seconds) {
   return 0;
 }
 
+// Tuning hook: the distributed tridiagonalisation of a device-generated synthetic matrix.
+// nteam >= 1: a whole team rehearsed on this GPU (seconds[0] = time of ALL members' work issued
+// back to back, i.e. ~nteam x one rank's compute plus the rehearsal exchange kernels);
+// nteam == 0: one rank of the attached communicator.
+int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds) {
+  if (n < 1) return -1;
+  if (nteam < 0 || nteam > kMaxTeam) return -2;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nteam == 0 && !g_comm.on) return -995;
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const int nmem = nteam > 0 ? nteam : 1, P = nteam > 0 ? nteam : g_comm.nranks;
+  const size_t wb = sytrd_dist_work_bytes(n, P);
+  const size_t per = al((size_t)ld * ld * 8) + al(wb) + 3 * al((size_t)ld * 8);
+  void *ws;
+  rc = workspace(per * nmem, &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  SytrdMember mem[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    double *dA = a.get<double>((size_t)ld * ld);
+    char *work = a.get<char>(wb);
+    double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld);
+    mem[m] = SytrdMember{dA, ld, dd, de, dt, nullptr, 0, work, nteam > 0 ? m : g_comm.rank};
+  }
+  SytrdExchange x{P, nteam > 0 ? sytrd_team_allreduce : rccl_allreduce, nullptr};
+  hipEvent_t e0, e1;
+  EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
+  double tot = 0.0;
+  g_comm.err = 0;
+  for (int r = 0; r < reps; ++r) {
+    for (int m = 0; m < nmem; ++m) {
+      EK_HIP_CHECK(hipMemsetAsync(mem[m].A, 0, (size_t)ld * ld * 8, s));
+      synth_matrix(s, n, 1, mem[m].A, ld);
+    }
+    EK_HIP_CHECK(hipEventRecord(e0, s));
+    sytrd_lower_dist(s, n, nmem, mem, x);
+    EK_HIP_CHECK(hipEventRecord(e1, s));
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0.f; EK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    tot += ms * 1e-3;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (seconds) *seconds = tot / (reps > 0 ? reps : 1);
+  return g_comm.err ? -996 : 0;
+}
+
 int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int ldm) {
   if (n < 0) return -1;
   if (ldm < (n > 1 ? n : 1)) return -4;

@@ -96,6 +96,7 @@ def load_library(path=None):
         "ek_hip_check": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _dp, _ip, _dp, _ip, _dp, _dp, _ip, _dp]),
         "ek_hip_profile_symv": (c_int, [c_int]),
         "ek_hip_debug_sytrd": (c_int, [c_int, c_int, c_int, _dp]),
+        "ek_hip_debug_sytrd_team": (c_int, [c_int, c_int, c_int, _dp]),
         "ek_hip_profile_symv_get": (c_int, [_dp, ctypes.POINTER(ctypes.c_longlong), _dp]),
     }
     for name, (res, args) in sigs.items():
@@ -121,7 +122,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_profile_symv", "ek_hip_profile_symv_get", "ek_hip_debug_sytrd",
     "ek_hip_residual_device", "ek_hip_orthogonality_device", "ek_hip_ipratios_device", "ek_hip_check",
     "ek_hip_sytrd_team", "ek_hip_comm_unique_id", "ek_hip_comm_init", "ek_hip_comm_size", "ek_hip_comm_rank",
-    "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device",
+    "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device", "ek_hip_debug_sytrd_team",
 )
 
 
