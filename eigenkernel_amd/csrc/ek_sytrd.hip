@@ -869,7 +869,10 @@ void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, co
         sv.j = j; sv.i = i; sv.S0 = S0l;
         sv.ntiles = (T > 0) ? tile_start(ceil_div(T, P), T, P) : 0;
         if (sv.ntiles > 0) {
-          const int target = (knobs().wgs > 0) ? knobs().wgs : (sv.ntiles <= 820 ? 256 : 512);
+          // a member streams 1/P of the triangle per launch, so per-workgroup fixed costs weigh
+          // more than on one GPU: fewer, longer runs (measured, team of 8: N=16384 128 workgroups
+          // 0.55 s/rank vs 0.59 at 256 and 0.63 at 512; N=32768 256 best)
+          const int target = (knobs().wgs > 0) ? knobs().wgs : (sv.ntiles <= 1100 ? 128 : 256);
           sv.q = ceil_div(sv.ntiles, target);
           if (knobs().G > 0 && sv.q < knobs().G) sv.q = knobs().G;
           sv.nwg = ceil_div(sv.ntiles, sv.q);
