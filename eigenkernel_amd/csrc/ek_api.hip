@@ -125,6 +125,9 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   int load() {
     if (h) return 0;
     const char *names[] = {getenv("EK_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -139,7 +142,11 @@ struct Rccl {
     CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
     AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
     GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
+    Broadcast = (decltype(Broadcast))dlsym(h, "ncclBroadcast");
+    GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString || !Broadcast ||
+        !GroupStart || !GroupEnd) {
       fprintf(stderr, "[ek_hip] RCCL symbols missing\n");
       dlclose(h); h = nullptr; return -997;
     }
@@ -159,6 +166,34 @@ void rccl_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t count, 
   if (nmem != 1 || !g_comm.on) { if (!g_comm.err) g_comm.err = (int)ncclInvalidUsage; return; }
   const ncclResult_t r = g_rccl.AllReduce(bufs[0], bufs[0], count, ncclDouble, ncclSum, g_comm.comm, s);
   if (r != ncclSuccess && !g_comm.err) g_comm.err = (int)r;
+}
+
+// all-gather of unequal pieces, in place: one grouped ncclBroadcast per owner
+void rccl_allgatherv(hipStream_t s, int nmem, int, double *const *bufs, const size_t *offs,
+                     const size_t *counts, int nranks, void *) {
+  if (nmem != 1 || !g_comm.on || nranks != g_comm.nranks) { if (!g_comm.err) g_comm.err = (int)ncclInvalidUsage; return; }
+  ncclResult_t r = g_rccl.GroupStart();
+  for (int root = 0; root < nranks && r == ncclSuccess; ++root)
+    if (counts[root] > 0)
+      r = g_rccl.Broadcast(bufs[0] + offs[root], bufs[0] + offs[root], counts[root], ncclDouble, root, g_comm.comm, s);
+  const ncclResult_t r2 = g_rccl.GroupEnd();
+  if (r == ncclSuccess) r = r2;
+  if (r != ncclSuccess && !g_comm.err) g_comm.err = (int)r;
+}
+
+SytrdExchange team_exchange(int nteam) {
+  SytrdExchange x{nteam > 0 ? nteam : g_comm.nranks, nteam > 0 ? sytrd_team_allreduce : rccl_allreduce, nullptr};
+  x.allgatherv = nteam > 0 ? team_allgatherv : rccl_allgatherv;
+  return x;
+}
+
+// test aid (EK_HIP_TEAM_POISON=1): NaN into every column of the strips a member does not own, to
+// prove that the distributed tridiagonalisation never reads them
+__global__ void poison_foreign_strips_kernel(int n, double *A, int lda, int P, int rank) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)n * n) return;
+  const int r = (int)(idx % n), c = (int)(idx / n);
+  if ((c / 128) % P != rank) A[(size_t)r + (size_t)c * lda] = __longlong_as_double(0x7ff8000000000000ll);
 }
 
 __global__ void count_mismatch_kernel(int m, int n, const double *X, int ldx, const double *Y, int ldy,
@@ -402,6 +437,63 @@ int ek_hip_sygst(int n, double *A_loc, const int desc_A[9], const double *L_loc,
   return 0;
 }
 
+// PDSYGST(1,'L') on a 1 x P grid, see sygst_lower_dist.  nteam as in ek_hip_sytrd_team.  Every
+// member leaves the reduced matrix in the columns of its own 128-wide strips; A_loc returns the
+// lower triangle assembled from the owners (nteam >= 1) or this rank's own strips with the other
+// columns untouched (nteam == 0).
+int ek_hip_sygst_team(int n, double *A_loc, const int desc_A[9], const double *L_loc,
+                      const int desc_B[9], int nteam) {
+  if (n < 0) return -1;
+  if (!A_loc && n > 0) return -2;
+  int rc = check_desc(desc_A, 3, n, n); if (rc) return rc;
+  if (!L_loc && n > 0) return -4;
+  rc = check_desc(desc_B, 5, n, n); if (rc) return rc;
+  if (nteam < 0 || nteam > kMaxTeam) return -6;
+  rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nteam == 0 && !g_comm.on) return -6;
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
+  const int nmem = nteam > 0 ? nteam : 1, P = nteam > 0 ? nteam : g_comm.nranks;
+  const size_t scr = sygst_dist_scratch_doubles(n, ld, P);
+  const size_t per = al((size_t)ld * ld * 8) + al((size_t)128 * ld * 8) + al(scr * 8);
+  void *ws;
+  rc = workspace(al((size_t)ld * ld * 8) + al((size_t)nblk * kDiagNB * kDiagNB * 8) + per * nmem, &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *dL = a.get<double>((size_t)ld * ld);
+  double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
+  EK_HIP_CHECK(hipMemsetAsync(dL, 0, (size_t)ld * ld * 8, s));
+  rc = h2d_matrix(n, n, L_loc, desc_B[8], dL, ld, s); if (rc) return rc;
+  trtri_diag_blocks(s, n, dL, ld, dInv);
+  SygstMember mem[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    double *dA = a.get<double>((size_t)ld * ld);
+    double *work = a.get<double>((size_t)128 * ld);
+    double *scratch = a.get<double>(scr);
+    EK_HIP_CHECK(hipMemsetAsync(dA, 0, (size_t)ld * ld * 8, s));
+    rc = h2d_matrix(n, n, A_loc, desc_A[8], dA, ld, s); if (rc) return rc;
+    mem[m] = SygstMember{dA, ld, dL, ld, dInv, work, scratch, nteam > 0 ? m : g_comm.rank};
+  }
+  g_comm.err = 0;
+  sygst_lower_dist(s, n, nmem, mem, team_exchange(nteam));
+  EK_HIP_CHECK(hipGetLastError());
+  // strip S comes from its owner
+  for (int S = 0; S * kDiagNB < n; ++S) {
+    const int owner = S % P;
+    const SygstMember *M = nullptr;
+    for (int m = 0; m < nmem; ++m) if (mem[m].rank == owner) M = &mem[m];
+    if (!M) continue;
+    const int c0 = S * kDiagNB, cols = (n - c0 < kDiagNB) ? n - c0 : kDiagNB;
+    rc = d2h_matrix(n, cols, M->A + (size_t)c0 * ld, ld, A_loc + (size_t)c0 * desc_A[8], desc_A[8], s);
+    if (rc) return rc;
+  }
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  if (g_comm.err) { fprintf(stderr, "[ek_hip] RCCL exchange failed: %s\n", g_rccl.GetErrorString((ncclResult_t)g_comm.err)); return -996; }
+  return 0;
+}
+
 int ek_hip_trtrs(int n, int nrhs, const double *L_loc, const int desc_B[9], double *Z_loc,
                  const int desc_Z[9]) {
   if (n < 0) return -1;
@@ -514,8 +606,12 @@ int ek_hip_sytrd_team(int n, double *A_loc, const int desc_A[9], double *d, doub
     EK_HIP_CHECK(hipMemsetAsync(dd, 0, 3 * al((size_t)ld * 8), s));
     rc = h2d_matrix(n, n, A_loc, desc_A[8], dA, ld, s); if (rc) return rc;
     mem[m] = SytrdMember{dA, ld, dd, de, dt, nullptr, 0, work, nteam > 0 ? m : g_comm.rank};
+    const char *poison = getenv("EK_HIP_TEAM_POISON");
+    if (poison && poison[0] == '1' && P > 1)
+      hipLaunchKernelGGL(poison_foreign_strips_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s,
+                         n, dA, ld, P, mem[m].rank);
   }
-  SytrdExchange x{P, nteam > 0 ? sytrd_team_allreduce : rccl_allreduce, nullptr};
+  const SytrdExchange x = team_exchange(nteam);
   g_comm.err = 0;
   sytrd_lower_dist(s, n, nmem, mem, x);
   EK_HIP_CHECK(hipGetLastError());
@@ -752,7 +848,7 @@ int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds) {
     double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld);
     mem[m] = SytrdMember{dA, ld, dd, de, dt, nullptr, 0, work, nteam > 0 ? m : g_comm.rank};
   }
-  SytrdExchange x{P, nteam > 0 ? sytrd_team_allreduce : rccl_allreduce, nullptr};
+  const SytrdExchange x = team_exchange(nteam);
   hipEvent_t e0, e1;
   EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
   double tot = 0.0;
@@ -828,7 +924,12 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   if (wb_ormtr > scratch) scratch = wb_ormtr;
   const size_t trsm_work = al((size_t)128 * ld * 8);
   void *ws;
-  const size_t sygst_scr = (problem == 1) ? al(sygst_scratch_doubles(n) * 8) : 0;
+  size_t sygst_dbl = (problem == 1) ? sygst_scratch_doubles(n) : 0;
+  if (problem == 1 && dist) {
+    const size_t dd = sygst_dist_scratch_doubles(n, ld, g_comm.nranks);
+    if (dd > sygst_dbl) sygst_dbl = dd;
+  }
+  const size_t sygst_scr = al(sygst_dbl * 8);
   int rc = 0;
   rc = workspace(4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
                      4 * al((size_t)ld * 8) + sygst_scr, &ws);
@@ -842,7 +943,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   double *twork = a.get<double>((size_t)128 * ld);
   char *work = a.get<char>(scratch);
   double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
-  double *sscr = (problem == 1) ? a.get<double>(sygst_scratch_doubles(n)) : nullptr;
+  double *sscr = (problem == 1) ? a.get<double>(sygst_dbl) : nullptr;
 
   StageTimer tm;
   const bool timing = stage_seconds && n_stages > 0;
@@ -882,13 +983,20 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   mark();                                                              // 1
   if (problem == 1) potrf_lower(s, n, wB, ld, dInv, g_ctx.d_info, twork);
   mark();                                                              // 2
-  if (problem == 1) sygst_lower(s, n, wA, ld, wB, ld, dInv, twork, sscr);
+  g_comm.err = 0;
+  if (problem == 1) {
+    // sharding the two solves costs 2 n^3 / P flops per rank against 1.0 - 1.57 n^3 replicated
+    if (dist && g_comm.nranks >= 3) {
+      const SygstMember me{wA, ld, wB, ld, dInv, twork, sscr, g_comm.rank};
+      sygst_lower_dist(s, n, 1, &me, team_exchange(0));
+    } else {
+      sygst_lower(s, n, wA, ld, wB, ld, dInv, twork, sscr);
+    }
+  }
   mark();                                                              // 3
   if (dist) {
     const SytrdMember me{wA, ld, dd, de, dt, wV, ld, work, g_comm.rank};
-    const SytrdExchange x{g_comm.nranks, rccl_allreduce, nullptr};
-    g_comm.err = 0;
-    sytrd_lower_dist(s, n, 1, &me, x);
+    sytrd_lower_dist(s, n, 1, &me, team_exchange(0));
   } else {
     sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, work);
   }

@@ -397,4 +397,51 @@ void sygst_lower(hipStream_t s, int n, double *A, int lda, const double *L, int 
   sygst_rec(s, n, A, lda, L, ldl, invdiag, work, scratch);
 }
 
+size_t sygst_dist_scratch_doubles(int n, int ld, int nranks) {
+  const int NRB = ceil_div(n > 0 ? n : 1, NB);
+  return (size_t)ld * NB * ceil_div(NRB, nranks > 0 ? nranks : 1);
+}
+
+void sygst_lower_dist(hipStream_t s, int n, int nmem, const SygstMember *mem, const SytrdExchange &x) {
+  if (n <= 0 || nmem <= 0 || nmem > kMaxTeam) return;
+  const int P = x.nranks;
+  const int NRB = ceil_div(n, NB);
+  const int wblk = ceil_div(NRB, P) * NB;       // width of a rank's contiguous column block
+  // step 1: Y(:, C_r) = L^-1 A(:, C_r)
+  size_t offs[kMaxTeam], counts[kMaxTeam];
+  for (int r = 0; r < P; ++r) {
+    long long c0 = (long long)r * wblk, c1 = c0 + wblk;
+    if (c0 > n) c0 = n;
+    if (c1 > n) c1 = n;
+    offs[r] = (size_t)c0 * mem[0].lda; counts[r] = (size_t)(c1 - c0) * mem[0].lda;
+  }
+  double *bufs[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    const SygstMember &M = mem[m];
+    bufs[m] = M.A;
+    symmetrize_lower(s, n, M.A, M.lda);
+    const int c0 = (int)(offs[M.rank] / M.lda), w = (int)(counts[M.rank] / M.lda);
+    if (w > 0) trsm_lln(s, n, w, M.L, M.ldl, M.invdiag, M.A + (size_t)c0 * M.lda, M.lda, M.work);
+  }
+  x.allgatherv(s, nmem, mem[0].rank, bufs, offs, counts, P, x.user);
+  // step 2: A'(:, S) = L^-1 (Y(S, :))^T for the owned strips
+  for (int m = 0; m < nmem; ++m) {
+    const SygstMember &M = mem[m];
+    int wtot = 0;
+    for (int S = M.rank; S < NRB; S += P) {
+      const int cols = (n - S * NB < NB) ? n - S * NB : NB;
+      transpose_rows(s, n, cols, M.A, M.lda, S * NB, M.scratch + (size_t)wtot * M.lda, M.lda);
+      wtot += cols;
+    }
+    if (wtot == 0) continue;
+    trsm_lln(s, n, wtot, M.L, M.ldl, M.invdiag, M.scratch, M.lda, M.work);
+    wtot = 0;
+    for (int S = M.rank; S < NRB; S += P) {
+      const int cols = (n - S * NB < NB) ? n - S * NB : NB;
+      copy_matrix(s, n, cols, M.scratch + (size_t)wtot * M.lda, M.lda, M.A + (size_t)S * NB * M.lda, M.lda);
+      wtot += cols;
+    }
+  }
+}
+
 }  // namespace ek

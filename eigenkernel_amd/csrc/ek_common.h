@@ -54,6 +54,8 @@ inline void gemm(hipStream_t s, bool ta, bool tb, int M, int N, int K, double al
 void copy_matrix(hipStream_t s, int m, int n, const double *src, int lds, double *dst, int ldd);
 void set_matrix(hipStream_t s, int m, int n, double offdiag, double diag, double *A, int lda);
 void symmetrize_lower(hipStream_t s, int n, double *A, int lda);   // upper <- lower^T
+// dst (n x m, ldd) <- (src(r0 : r0+m, 0 : n))^T
+void transpose_rows(hipStream_t s, int n, int m, const double *src, int lds, int r0, double *dst, int ldd);
 void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, const int *perm,
                     double *dst, int ldd);                         // dst(:,j) = src(:,perm[j])
 
@@ -88,6 +90,21 @@ inline size_t sygst_scratch_doubles(int n) {
 }
 void sygst_lower(hipStream_t s, int n, double *A, int lda, const double *L, int ldl,
                  const double *invdiag, double *work, double *scratch);
+// Distributed form (PDSYGST on a 1 x P grid): both triangular solves are sharded by columns,
+//   Y(:, C_r) = L^-1 A(:, C_r)   on the rank's contiguous column block C_r, one all-gather of Y,
+//   A'(:, S)  = L^-1 (Y(S, :))^T on every strip S the rank owns (r, r+P, ...: the strips the
+//                                distributed tridiagonalisation reads on this rank; A' = A'^T),
+// 2 n^3 / P flops per rank and no second exchange: on return a member's A holds the reduced matrix
+// in the columns of its OWN strips only.  scratch: >= sygst_dist_scratch_doubles(n, ld, P).
+struct SygstMember {
+  double *A; int lda; const double *L; int ldl; const double *invdiag;
+  double *work;      // >= 128 * lda doubles
+  double *scratch;
+  int rank;
+};
+struct SytrdExchange;
+size_t sygst_dist_scratch_doubles(int n, int ld, int nranks);
+void sygst_lower_dist(hipStream_t s, int n, int nmem, const SygstMember *mem, const SytrdExchange &x);
 
 // ---------------------------------------------------------------- tridiagonalisation (ek_sytrd.hip)
 struct SytrdWork;   // opaque, sized by sytrd_work_bytes
@@ -121,10 +138,17 @@ struct SytrdExchange {
   // members held by this process; stream-ordered
   void (*allreduce)(hipStream_t s, int nmem, double *const *bufs, size_t count, void *user);
   void *user;
+  // in-place all-gather of unequal pieces: rank r's piece [offs[r], offs[r] + counts[r]) of its
+  // array `bufs` ends up at the same place in every rank's array (offs, counts: nranks entries;
+  // members held by this process are the ranks rank0 .. rank0 + nmem - 1)
+  void (*allgatherv)(hipStream_t s, int nmem, int rank0, double *const *bufs, const size_t *offs,
+                     const size_t *counts, int nranks, void *user) = nullptr;
 };
 size_t sytrd_dist_work_bytes(int n, int nranks);
 void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, const SytrdExchange &x);
 void sytrd_team_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t count, void *user);
+void team_allgatherv(hipStream_t s, int nmem, int rank0, double *const *bufs, const size_t *offs,
+                     const size_t *counts, int nranks, void *user);   // rehearsal: nmem == nranks
 
 // instrumentation: HIP events around every symv launch (bench.py roofline line)
 void symv_profile_enable(int stride);   // 0 = off, k = time every k-th column's launch

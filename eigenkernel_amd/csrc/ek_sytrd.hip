@@ -792,6 +792,16 @@ void sytrd_team_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t c
   hipLaunchKernelGGL(team_allreduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, tb, count);
 }
 
+void team_allgatherv(hipStream_t s, int nmem, int rank0, double *const *bufs, const size_t *offs,
+                     const size_t *counts, int nranks, void *) {
+  (void)rank0;
+  for (int r = 0; r < nranks && r < nmem; ++r)
+    for (int m = 0; m < nmem; ++m)
+      if (m != r && counts[r] > 0)
+        (void)hipMemcpyAsync(bufs[m] + offs[r], bufs[r] + offs[r], counts[r] * sizeof(double),
+                             hipMemcpyDeviceToDevice, s);
+}
+
 // Same column loop as sytrd_lower; every phase is issued for each member held by this process
 // (one in production, the whole team in the single-GPU rehearsal), with one exchange per column.
 void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, const SytrdExchange &x) {

@@ -39,6 +39,23 @@ __global__ void symmetrize_kernel(int n, double *A, int lda) {
   }
 }
 
+// dst(i, c) = src(r0 + c, i): 32x33 LDS tile, coalesced on both sides
+__global__ void transpose_rows_kernel(int n, int m, const double *__restrict__ src, int lds, int r0,
+                                      double *__restrict__ dst, int ldd) {
+  __shared__ double tile[32][33];
+  const int bi = blockIdx.x, bc = blockIdx.y;   // tile along i (0..n), along c (0..m)
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int c = bc * 32 + tx, i = bi * 32 + k;            // read src(r0 + c, i): lanes along c (rows)
+    tile[k][tx] = (c < m && i < n) ? src[(size_t)(r0 + c) + (size_t)i * lds] : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int i = bi * 32 + tx, c = bc * 32 + k;            // write dst(i, c): lanes along i (rows)
+    if (i < n && c < m) dst[(size_t)i + (size_t)c * ldd] = tile[tx][k];
+  }
+}
+
 __global__ void gather_columns_kernel(int m, int n, const double *__restrict__ src, int lds,
                                       const int *__restrict__ perm, double *__restrict__ dst,
                                       int ldd) {
@@ -131,6 +148,12 @@ void symmetrize_lower(hipStream_t s, int n, double *A, int lda) {
   const int t = ceil_div(n, 32);
   hipLaunchKernelGGL(symmetrize_kernel, dim3(t, t), dim3(256), 0, s, n, A, lda);
 }
+void transpose_rows(hipStream_t s, int n, int m, const double *src, int lds, int r0, double *dst, int ldd) {
+  if (n <= 0 || m <= 0) return;
+  hipLaunchKernelGGL(transpose_rows_kernel, dim3(ceil_div(n, 32), ceil_div(m, 32)), dim3(256), 0, s, n, m, src,
+                     lds, r0, dst, ldd);
+}
+
 void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, const int *perm,
                     double *dst, int ldd) {
   if (m <= 0 || n <= 0) return;

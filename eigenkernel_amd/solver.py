@@ -73,6 +73,7 @@ def load_library(path=None):
         "ek_hip_sygst": (c_int, [c_int, _dp, _ip, _dp, _ip, _dp]),
         "ek_hip_sytrd": (c_int, [c_int, _dp, _ip, _dp, _dp, _dp]),
         "ek_hip_sytrd_team": (c_int, [c_int, _dp, _ip, _dp, _dp, _dp, c_int, _llp]),
+        "ek_hip_sygst_team": (c_int, [c_int, _dp, _ip, _dp, _ip, c_int]),
         "ek_hip_comm_unique_id": (c_int, [vp, c_int]),
         "ek_hip_comm_init": (c_int, [vp, c_int, c_int, c_int]),
         "ek_hip_comm_size": (c_int, []),
@@ -122,7 +123,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_profile_symv", "ek_hip_profile_symv_get", "ek_hip_debug_sytrd",
     "ek_hip_residual_device", "ek_hip_orthogonality_device", "ek_hip_ipratios_device", "ek_hip_check",
     "ek_hip_sytrd_team", "ek_hip_comm_unique_id", "ek_hip_comm_init", "ek_hip_comm_size", "ek_hip_comm_rank",
-    "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device", "ek_hip_debug_sytrd_team",
+    "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device", "ek_hip_debug_sytrd_team", "ek_hip_sygst_team",
 )
 
 
@@ -333,6 +334,16 @@ def sytrd_team(A, nteam):
     mm = ctypes.c_longlong(-1)
     info = lib.ek_hip_sytrd_team(n, _P(A), _I(_desc_for(A)), _P(d), _P(e), _P(tau), nteam, ctypes.byref(mm))
     return A, d[:n], e[:max(n - 1, 0)], tau[:max(n - 1, 0)], info, mm.value
+
+
+def sygst_team(A, L, nteam):
+    """PDSYGST(1,'L') on a 1 x P grid (ek_hip_sygst_team). Returns (reduced A, info)."""
+    lib = load_library()
+    A = np.array(_farr(A), order="F", copy=True)
+    L = _farr(L)
+    n = A.shape[0]
+    info = lib.ek_hip_sygst_team(n, _P(A), _I(_desc_for(A)), _P(L), _I(_desc_for(L)), nteam)
+    return A, info
 
 
 def comm_unique_id():

@@ -173,6 +173,12 @@ int ek_hip_sytrd(int n, double *A_loc, const int desc_A[9], double *d, double *e
  *               results (lower triangle of A, d, e, tau) differ from rank 0's (must be 0). */
 int ek_hip_sytrd_team(int n, double *A_loc, const int desc_A[9], double *d, double *e, double *tau,
                       int nteam, long long *mismatch);
+/* PDSYGST(1,'L') on a 1 x P grid: the two triangular solves sharded by columns, one all-gather
+ * (grouped ncclBroadcast) in between; nteam as above.  A_loc returns the reduced matrix (whole
+ * columns; the lower triangle is the result) assembled from the owners of the 128-wide strips
+ * (nteam >= 1), or only this rank's strips with the other columns left as they were (nteam == 0). */
+int ek_hip_sygst_team(int n, double *A_loc, const int desc_A[9],
+                      const double *L_loc, const int desc_B[9], int nteam);
 /* PDSTEDC('I', n, d, e, Z, 1,1, desc_Z, ...)                         :96
  * d in: diagonal, out: eigenvalues ascending; e in: sub-diagonal (destroyed). */
 int ek_hip_stedc(int n, double *d, double *e, double *Z_loc, const int desc_Z[9]);

@@ -68,6 +68,50 @@ def test_sytrd_team_reproducible(hip, oracle):
         assert np.array_equal(a, b)
 
 
+def test_sytrd_team_reads_only_owned_strips(hip, oracle, monkeypatch):
+    """NaN in every strip a rank does not own (what the distributed reduction to standard form
+    leaves undefined there): the result must not change by a bit."""
+    A = oracle.synth_matrix(900, 1)
+    ref = hip.sytrd_team(A, 4)
+    monkeypatch.setenv("EK_HIP_TEAM_POISON", "1")
+    got = hip.sytrd_team(A, 4)
+    assert got[4] == 0 and got[5] == 0
+    for a, b in zip(ref[1:4], got[1:4]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(np.tril(ref[0]), np.tril(got[0]))
+
+
+@pytest.mark.parametrize("n,P", [(5, 2), (128, 2), (130, 3), (300, 1), (640, 4), (1000, 8), (1000, 16), (1537, 5)])
+def test_sygst_team_rehearsal(hip, oracle, n, P):
+    """PDSYGST on a 1 x P grid: column-sharded solves + one all-gather; every strip is taken from
+    its owner and the lower triangle held to the single-GPU stage's bound."""
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    L, info = oracle.potrf_lower(B)
+    assert info == 0
+    L = np.tril(L)
+    C_or = oracle.sygst_lower(A, L)
+    got, info = hip.sygst_team(A, L, P)
+    assert info == 0
+    il = np.tril_indices(n)
+    scale = np.abs(C_or[il]).max()
+    assert np.abs(got[il] - C_or[il]).max() <= 32 * n * EPS * scale
+    # oracle-independent identity: L C L^T = A
+    Cs = np.tril(got) + np.tril(got, -1).T
+    assert np.abs(L @ Cs @ L.T - A).max() <= 64 * n * EPS * np.abs(A).max()
+
+
+def test_sygst_over_rccl_world_of_one(hip, oracle, comm1):
+    n = 700
+    A = oracle.synth_matrix(n, 1)
+    L = np.tril(oracle.potrf_lower(oracle.synth_matrix(n, 2))[0])
+    got, info = hip.sygst_team(A, L, 0)          # grouped ncclBroadcast all-gather, one rank
+    assert info == 0
+    ref, info1 = hip.sygst_team(A, L, 1)
+    assert info1 == 0
+    assert np.array_equal(got, ref)
+
+
 def test_sytrd_team_rejects_bad_team(hip, oracle):
     A = oracle.synth_matrix(8, 1)
     assert hip.sytrd_team(A, 17)[4] == -7
