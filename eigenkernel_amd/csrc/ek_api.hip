@@ -181,6 +181,13 @@ void rccl_allgatherv(hipStream_t s, int nmem, int, double *const *bufs, const si
   if (r != ncclSuccess && !g_comm.err) g_comm.err = (int)r;
 }
 
+// From how many ranks on the Cholesky factor and the reduction to standard form are distributed
+// as well (below that their replicated forms are cheaper); EK_HIP_DIST_MIN_RANKS overrides (tests).
+int dist_min_ranks() {
+  const char *e = getenv("EK_HIP_DIST_MIN_RANKS");
+  return e ? atoi(e) : 3;
+}
+
 SytrdExchange team_exchange(int nteam) {
   SytrdExchange x{nteam > 0 ? nteam : g_comm.nranks, nteam > 0 ? sytrd_team_allreduce : rccl_allreduce, nullptr};
   x.allgatherv = nteam > 0 ? team_allgatherv : rccl_allgatherv;
@@ -402,6 +409,63 @@ int ek_hip_potrf(int n, double *B_loc, const int desc_B[9]) {
   int info = 0;
   rc = fetch_info(&info); if (rc) return rc;
   return info;
+}
+
+// PDPOTRF('L') on a 1 x P grid, see potrf_lower_dist.  nteam as in ek_hip_sytrd_team.  B_loc
+// returns the first local member's factor; *mismatch the number of doubles (lower triangle of L
+// and the block inverses) in which another local member differs from it.
+int ek_hip_potrf_team(int n, double *B_loc, const int desc_B[9], int nteam, long long *mismatch) {
+  if (n < 0) return -1;
+  if (!B_loc && n > 0) return -2;
+  int rc = check_desc(desc_B, 3, n, n); if (rc) return rc;
+  if (nteam < 0 || nteam > kMaxTeam) return -4;
+  rc = ensure_init(); if (rc) return rc;
+  if (mismatch) *mismatch = 0;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nteam == 0 && !g_comm.on) return -4;
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
+  const int nmem = nteam > 0 ? nteam : 1, P = nteam > 0 ? nteam : g_comm.nranks;
+  const size_t wb = potrf_dist_work_bytes(n, ld, P);
+  const size_t per = al((size_t)ld * ld * 8) + al((size_t)nblk * kDiagNB * kDiagNB * 8) + al(wb) + 256;
+  void *ws;
+  rc = workspace(per * nmem + 256, &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  unsigned long long *d_cnt = a.get<unsigned long long>(1);
+  EK_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 8, s));
+  PotrfMember mem[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    double *dB = a.get<double>((size_t)ld * ld);
+    double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
+    char *work = a.get<char>(wb);
+    int *dinfo = a.get<int>(1);
+    EK_HIP_CHECK(hipMemsetAsync(dB, 0, (size_t)ld * ld * 8, s));
+    EK_HIP_CHECK(hipMemsetAsync(dinfo, 0, sizeof(int), s));
+    rc = h2d_matrix(n, n, B_loc, desc_B[8], dB, ld, s); if (rc) return rc;
+    mem[m] = PotrfMember{dB, ld, dInv, dinfo, work, nteam > 0 ? m : g_comm.rank};
+  }
+  g_comm.err = 0;
+  potrf_lower_dist(s, n, nmem, mem, team_exchange(nteam));
+  EK_HIP_CHECK(hipGetLastError());
+  for (int m = 1; m < nmem; ++m) {
+    hipLaunchKernelGGL(count_mismatch_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, n, n,
+                       mem[0].B, ld, mem[m].B, ld, 1, d_cnt);
+    hipLaunchKernelGGL(count_mismatch_kernel, dim3((unsigned)(((size_t)nblk * kDiagNB * kDiagNB + 255) / 256)), dim3(256),
+                       0, s, nblk * kDiagNB * kDiagNB, 1, mem[0].invdiag, 1, mem[m].invdiag, 1, 0, d_cnt);
+  }
+  rc = d2h_matrix(n, n, mem[0].B, ld, B_loc, desc_B[8], s); if (rc) return rc;
+  int infos[kMaxTeam] = {0};
+  for (int m = 0; m < nmem; ++m)
+    EK_HIP_CHECK(hipMemcpyAsync(&infos[m], mem[m].d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  unsigned long long cnt = 0;
+  EK_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  for (int m = 1; m < nmem; ++m) if (infos[m] != infos[0]) cnt += 1;   // info must be known to all
+  if (mismatch) *mismatch = (long long)cnt;
+  if (g_comm.err) { fprintf(stderr, "[ek_hip] RCCL exchange failed: %s\n", g_rccl.GetErrorString((ncclResult_t)g_comm.err)); return -996; }
+  return infos[0];
 }
 
 int ek_hip_sygst(int n, double *A_loc, const int desc_A[9], const double *L_loc,
@@ -870,6 +934,63 @@ int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds) {
   return g_comm.err ? -996 : 0;
 }
 
+// Tuning hook: Cholesky + reduction to standard form of the synthetic pair, distributed form;
+// seconds[0] = potrf, seconds[1] = sygst (whole team back to back when nteam >= 1).
+int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds) {
+  if (n < 1) return -1;
+  if (nteam < 0 || nteam > kMaxTeam) return -2;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nteam == 0 && !g_comm.on) return -995;
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
+  const int nmem = nteam > 0 ? nteam : 1, P = nteam > 0 ? nteam : g_comm.nranks;
+  const size_t wb = potrf_dist_work_bytes(n, ld, P), scr = sygst_dist_scratch_doubles(n, ld, P);
+  const size_t per = 2 * al((size_t)ld * ld * 8) + al((size_t)nblk * kDiagNB * kDiagNB * 8) + al(wb) +
+                     al((size_t)128 * ld * 8) + al(scr * 8) + 256;
+  void *ws;
+  rc = workspace(per * nmem, &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  PotrfMember pm[kMaxTeam]; SygstMember sm[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    double *dA = a.get<double>((size_t)ld * ld), *dB = a.get<double>((size_t)ld * ld);
+    double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
+    char *work = a.get<char>(wb);
+    double *tw = a.get<double>((size_t)128 * ld), *sc = a.get<double>(scr);
+    int *dinfo = a.get<int>(1);
+    const int rank = nteam > 0 ? m : g_comm.rank;
+    pm[m] = PotrfMember{dB, ld, dInv, dinfo, work, rank};
+    sm[m] = SygstMember{dA, ld, dB, ld, dInv, tw, sc, rank};
+  }
+  const SytrdExchange x = team_exchange(nteam);
+  hipEvent_t e0, e1, e2;
+  EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1)); EK_HIP_CHECK(hipEventCreate(&e2));
+  double t1 = 0.0, t2 = 0.0;
+  g_comm.err = 0;
+  for (int r = 0; r < reps; ++r) {
+    for (int m = 0; m < nmem; ++m) {
+      EK_HIP_CHECK(hipMemsetAsync(sm[m].A, 0, (size_t)ld * ld * 8, s));
+      EK_HIP_CHECK(hipMemsetAsync(pm[m].B, 0, (size_t)ld * ld * 8, s));
+      EK_HIP_CHECK(hipMemsetAsync(pm[m].d_info, 0, sizeof(int), s));
+      synth_matrix(s, n, 1, sm[m].A, ld);
+      synth_matrix(s, n, 2, pm[m].B, ld);
+    }
+    EK_HIP_CHECK(hipEventRecord(e0, s));
+    potrf_lower_dist(s, n, nmem, pm, x);
+    EK_HIP_CHECK(hipEventRecord(e1, s));
+    sygst_lower_dist(s, n, nmem, sm, x);
+    EK_HIP_CHECK(hipEventRecord(e2, s));
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    EK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1)); t1 += ms * 1e-3;
+    EK_HIP_CHECK(hipEventElapsedTime(&ms, e1, e2)); t2 += ms * 1e-3;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  if (seconds) { seconds[0] = t1 / (reps > 0 ? reps : 1); seconds[1] = t2 / (reps > 0 ? reps : 1); }
+  return g_comm.err ? -996 : 0;
+}
+
 int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int ldm) {
   if (n < 0) return -1;
   if (ldm < (n > 1 ? n : 1)) return -4;
@@ -930,9 +1051,10 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     if (dd > sygst_dbl) sygst_dbl = dd;
   }
   const size_t sygst_scr = al(sygst_dbl * 8);
+  const size_t potrf_wb = (problem == 1 && dist) ? al(potrf_dist_work_bytes(n, ld, g_comm.nranks)) : 0;
   int rc = 0;
   rc = workspace(4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
-                     4 * al((size_t)ld * 8) + sygst_scr, &ws);
+                     4 * al((size_t)ld * 8) + sygst_scr + potrf_wb, &ws);
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
   double *wA = a.get<double>((size_t)ld * ld);
@@ -944,6 +1066,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   char *work = a.get<char>(scratch);
   double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
   double *sscr = (problem == 1) ? a.get<double>(sygst_dbl) : nullptr;
+  char *pwork = potrf_wb ? a.get<char>(potrf_wb) : nullptr;
 
   StageTimer tm;
   const bool timing = stage_seconds && n_stages > 0;
@@ -981,12 +1104,20 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     if (sigma != 1.0) scale_lower(s, n, sigma, wA, ld);
   }
   mark();                                                              // 1
-  if (problem == 1) potrf_lower(s, n, wB, ld, dInv, g_ctx.d_info, twork);
-  mark();                                                              // 2
   g_comm.err = 0;
   if (problem == 1) {
+    // right-looking sweep with one panel broadcast per strip: pays from three ranks on
+    if (dist && g_comm.nranks >= dist_min_ranks()) {
+      const PotrfMember me{wB, ld, dInv, g_ctx.d_info, pwork, g_comm.rank};
+      potrf_lower_dist(s, n, 1, &me, team_exchange(0));
+    } else {
+      potrf_lower(s, n, wB, ld, dInv, g_ctx.d_info, twork);
+    }
+  }
+  mark();                                                              // 2
+  if (problem == 1) {
     // sharding the two solves costs 2 n^3 / P flops per rank against 1.0 - 1.57 n^3 replicated
-    if (dist && g_comm.nranks >= 3) {
+    if (dist && g_comm.nranks >= dist_min_ranks()) {
       const SygstMember me{wA, ld, wB, ld, dInv, twork, sscr, g_comm.rank};
       sygst_lower_dist(s, n, 1, &me, team_exchange(0));
     } else {

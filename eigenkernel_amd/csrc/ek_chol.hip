@@ -397,6 +397,111 @@ void sygst_lower(hipStream_t s, int n, double *A, int lda, const double *L, int 
   sygst_rec(s, n, A, lda, L, ldl, invdiag, work, scratch);
 }
 
+namespace {
+inline size_t al256c(size_t b) { return (b + 255) & ~(size_t)255; }
+struct PotrfDistLayout {
+  int NRB, maxb;
+  size_t off_pbuf, off_infos, off_infod, off_offs, off_dims, total;
+  PotrfDistLayout(int n, int ld, int P) {
+    NRB = ceil_div(n > 0 ? n : 1, NB); maxb = ceil_div(NRB, P) + 1;
+    size_t o = 0;
+    off_pbuf = o; o += al256c((size_t)(2 * NB * NB + (size_t)ld * NB) * 8);
+    off_infos = o; o += al256c((size_t)NRB * sizeof(int));
+    off_infod = o; o += al256c((size_t)NRB * 8);
+    off_offs = o; o += al256c((size_t)NRB * maxb * 3 * sizeof(long long));
+    off_dims = o; o += al256c((size_t)NRB * maxb * 3 * sizeof(int));
+    total = o;
+  }
+};
+
+// per step k and owned strip j > k: A = B = panel rows from j*128 (inside strip k), C = block (j, j)
+__global__ void potrf_table_kernel(int n, int ldb, int P, int rank, int NRB, int maxb, long long *offs, int *dims) {
+  const int k = blockIdx.x, b = threadIdx.x;
+  if (b >= maxb) return;
+  const int jf = k + 1 + ((rank - (k + 1)) % P + P) % P;
+  const int j = jf + b * P;
+  int M = 0, N = 0;
+  const long long r0 = (long long)j * NB;
+  if (j < NRB && r0 < n) { M = n - (int)r0; N = (M < NB) ? M : NB; }
+  const int nbk = (n - k * NB < NB) ? n - k * NB : NB;
+  const size_t e = (size_t)k * maxb + b;
+  offs[3 * e] = r0 + (long long)k * NB * ldb; offs[3 * e + 1] = offs[3 * e]; offs[3 * e + 2] = r0 * ((long long)ldb + 1);
+  dims[3 * e] = M; dims[3 * e + 1] = N; dims[3 * e + 2] = nbk;
+}
+__global__ void info_to_double_kernel(int nrb, const int *infos, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nrb) out[i] = (double)infos[i];
+}
+__global__ void first_info_kernel(int nrb, const double *v, int *d_info) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || *d_info != 0) return;
+  for (int i = 0; i < nrb; ++i)
+    if (v[i] != 0.0) { *d_info = (int)v[i]; return; }
+}
+}  // namespace
+
+size_t potrf_dist_work_bytes(int n, int ld, int nranks) { return PotrfDistLayout(n, ld, nranks > 0 ? nranks : 1).total; }
+
+void potrf_lower_dist(hipStream_t s, int n, int nmem, const PotrfMember *mem, const SytrdExchange &x) {
+  set_attrs();
+  if (n <= 0 || nmem <= 0 || nmem > kMaxTeam) return;
+  const int P = x.nranks;
+  const PotrfDistLayout Ly(n, mem[0].ldb, P);
+  const int NRB = Ly.NRB;
+  double *pbuf[kMaxTeam], *infod[kMaxTeam];
+  int *infos[kMaxTeam]; long long *offs[kMaxTeam]; int *dims[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    char *w = (char *)mem[m].work;
+    pbuf[m] = (double *)(w + Ly.off_pbuf); infos[m] = (int *)(w + Ly.off_infos);
+    infod[m] = (double *)(w + Ly.off_infod); offs[m] = (long long *)(w + Ly.off_offs); dims[m] = (int *)(w + Ly.off_dims);
+    (void)hipMemsetAsync(infos[m], 0, (size_t)NRB * sizeof(int), s);
+    hipLaunchKernelGGL(potrf_table_kernel, dim3(NRB), dim3(round_up(Ly.maxb, 64)), 0, s, n, mem[m].ldb, P,
+                       mem[m].rank, NRB, Ly.maxb, offs[m], dims[m]);
+  }
+  size_t zoffs[kMaxTeam], cnts[kMaxTeam];
+  for (int k = 0; k < NRB; ++k) {
+    const int off = k * NB, nbk = (n - off < NB) ? n - off : NB, mrows = n - off - nbk;
+    const int owner = k % P;
+    const size_t count = (size_t)2 * NB * NB + (size_t)mrows * nbk;
+    for (int m = 0; m < nmem; ++m) {
+      if (mem[m].rank != owner) continue;
+      const PotrfMember &M = mem[m];
+      double *Bd = M.B + (size_t)off + (size_t)off * M.ldb;
+      double *pinv = pbuf[m], *pdiag = pbuf[m] + NB * NB, *ppan = pbuf[m] + 2 * NB * NB;
+      hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), (NB * NB + NB) * sizeof(double), s, nbk,
+                         Bd, M.ldb, pinv, infos[m] + k, off);
+      copy_matrix(s, nbk, nbk, Bd, M.ldb, pdiag, NB);
+      if (mrows > 0) gemm(s, false, true, mrows, nbk, nbk, 1.0, Bd + nbk, M.ldb, pinv, NB, 0.0, ppan, mrows);
+    }
+    for (int r = 0; r < P; ++r) { zoffs[r] = 0; cnts[r] = (r == owner) ? count : 0; }
+    x.allgatherv(s, nmem, mem[0].rank, pbuf, zoffs, cnts, P, x.user);
+    for (int m = 0; m < nmem; ++m) {
+      const PotrfMember &M = mem[m];
+      double *Bd = M.B + (size_t)off + (size_t)off * M.ldb;
+      const double *pinv = pbuf[m], *pdiag = pbuf[m] + NB * NB, *ppan = pbuf[m] + 2 * NB * NB;
+      copy_matrix(s, NB, NB, pinv, NB, M.invdiag + (size_t)k * NB * NB, NB);
+      if (M.rank != owner) copy_matrix(s, nbk, nbk, pdiag, NB, Bd, M.ldb);
+      if (mrows > 0) {
+        copy_matrix(s, mrows, nbk, ppan, mrows, Bd + nbk, M.ldb);
+        const int jf = k + 1 + ((M.rank - (k + 1)) % P + P) % P;
+        if (jf < NRB && jf * NB < n) {
+          GemmDesc g{};
+          g.M = n - jf * NB; g.N = NB; g.K = nbk; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
+          g.A = M.B; g.lda = M.ldb; g.B = M.B; g.ldb = M.ldb; g.C = M.B; g.ldc = M.ldb;
+          g.batch = ceil_div(NRB - jf, P); g.lower_only = true;
+          g.d_offs = offs[m] + (size_t)k * Ly.maxb * 3; g.d_dims = dims[m] + (size_t)k * Ly.maxb * 3;
+          gemm(s, g);
+        }
+      }
+    }
+  }
+  // first failing pivot, known to every rank
+  for (int m = 0; m < nmem; ++m)
+    hipLaunchKernelGGL(info_to_double_kernel, dim3(ceil_div(NRB, 256)), dim3(256), 0, s, NRB, infos[m], infod[m]);
+  x.allreduce(s, nmem, infod, (size_t)NRB, x.user);
+  for (int m = 0; m < nmem; ++m)
+    hipLaunchKernelGGL(first_info_kernel, dim3(1), dim3(64), 0, s, NRB, infod[m], mem[m].d_info);
+}
+
 size_t sygst_dist_scratch_doubles(int n, int ld, int nranks) {
   const int NRB = ceil_div(n > 0 ? n : 1, NB);
   return (size_t)ld * NB * ceil_div(NRB, nranks > 0 ? nranks : 1);

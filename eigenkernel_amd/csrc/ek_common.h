@@ -103,6 +103,15 @@ struct SygstMember {
   int rank;
 };
 struct SytrdExchange;
+// Distributed Cholesky (PDPOTRF on a 1 x P grid, 128-wide column blocks, right-looking): the owner
+// of strip k factors its diagonal block in LDS, solves the panel below it and broadcasts
+// [inverse | diagonal block | panel] in one message; every rank stores it (so L and the block
+// inverses end up complete on all ranks, as the two solves of the reduction need them) and
+// updates the strips it owns.  n^3 / (3P) flops per rank, n^2/2 doubles on the wire in total.
+// *d_info receives the first failing pivot on every rank (one small all-reduce at the end).
+struct PotrfMember { double *B; int ldb; double *invdiag; int *d_info; void *work; int rank; };
+size_t potrf_dist_work_bytes(int n, int ld, int nranks);
+void potrf_lower_dist(hipStream_t s, int n, int nmem, const PotrfMember *mem, const SytrdExchange &x);
 size_t sygst_dist_scratch_doubles(int n, int ld, int nranks);
 void sygst_lower_dist(hipStream_t s, int n, int nmem, const SygstMember *mem, const SytrdExchange &x);
 

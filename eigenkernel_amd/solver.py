@@ -74,6 +74,7 @@ def load_library(path=None):
         "ek_hip_sytrd": (c_int, [c_int, _dp, _ip, _dp, _dp, _dp]),
         "ek_hip_sytrd_team": (c_int, [c_int, _dp, _ip, _dp, _dp, _dp, c_int, _llp]),
         "ek_hip_sygst_team": (c_int, [c_int, _dp, _ip, _dp, _ip, c_int]),
+        "ek_hip_potrf_team": (c_int, [c_int, _dp, _ip, c_int, _llp]),
         "ek_hip_comm_unique_id": (c_int, [vp, c_int]),
         "ek_hip_comm_init": (c_int, [vp, c_int, c_int, c_int]),
         "ek_hip_comm_size": (c_int, []),
@@ -98,6 +99,7 @@ def load_library(path=None):
         "ek_hip_profile_symv": (c_int, [c_int]),
         "ek_hip_debug_sytrd": (c_int, [c_int, c_int, c_int, _dp]),
         "ek_hip_debug_sytrd_team": (c_int, [c_int, c_int, c_int, _dp]),
+        "ek_hip_debug_reduce_team": (c_int, [c_int, c_int, c_int, _dp]),
         "ek_hip_profile_symv_get": (c_int, [_dp, ctypes.POINTER(ctypes.c_longlong), _dp]),
     }
     for name, (res, args) in sigs.items():
@@ -124,6 +126,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_residual_device", "ek_hip_orthogonality_device", "ek_hip_ipratios_device", "ek_hip_check",
     "ek_hip_sytrd_team", "ek_hip_comm_unique_id", "ek_hip_comm_init", "ek_hip_comm_size", "ek_hip_comm_rank",
     "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device", "ek_hip_debug_sytrd_team", "ek_hip_sygst_team",
+    "ek_hip_potrf_team", "ek_hip_debug_reduce_team",
 )
 
 
@@ -334,6 +337,15 @@ def sytrd_team(A, nteam):
     mm = ctypes.c_longlong(-1)
     info = lib.ek_hip_sytrd_team(n, _P(A), _I(_desc_for(A)), _P(d), _P(e), _P(tau), nteam, ctypes.byref(mm))
     return A, d[:n], e[:max(n - 1, 0)], tau[:max(n - 1, 0)], info, mm.value
+
+
+def potrf_team(B, nteam):
+    """PDPOTRF('L') on a 1 x P grid (ek_hip_potrf_team). Returns (B_with_L_in_lower, info, mismatch)."""
+    lib = load_library()
+    B = np.array(_farr(B), order="F", copy=True)
+    mm = ctypes.c_longlong(-1)
+    info = lib.ek_hip_potrf_team(B.shape[0], _P(B), _I(_desc_for(B)), nteam, ctypes.byref(mm))
+    return B, info, mm.value
 
 
 def sygst_team(A, L, nteam):

@@ -173,6 +173,10 @@ int ek_hip_sytrd(int n, double *A_loc, const int desc_A[9], double *d, double *e
  *               results (lower triangle of A, d, e, tau) differ from rank 0's (must be 0). */
 int ek_hip_sytrd_team(int n, double *A_loc, const int desc_A[9], double *d, double *e, double *tau,
                       int nteam, long long *mismatch);
+/* PDPOTRF('L') on a 1 x P grid (128-wide column blocks, right-looking, one broadcast per block
+ * column); nteam and *mismatch as in ek_hip_sytrd_team; returns info (first failing pivot, known
+ * to every rank). */
+int ek_hip_potrf_team(int n, double *B_loc, const int desc_B[9], int nteam, long long *mismatch);
 /* PDSYGST(1,'L') on a 1 x P grid: the two triangular solves sharded by columns, one all-gather
  * (grouped ncclBroadcast) in between; nteam as above.  A_loc returns the reduced matrix (whole
  * columns; the lower triangle is the result) assembled from the owners of the 128-wide strips
@@ -236,7 +240,8 @@ int ek_hip_profile_symv(int enable);
 /* Tuning hook: tridiagonalise a device-generated synthetic matrix (order n, leading dimension
  * ld >= n rounded up to 128) `reps` times; *seconds = stage time per repetition. */
 int ek_hip_debug_sytrd(int n, int ld, int reps, double *seconds);
-int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds);   /* distributed form, see ek_hip_sytrd_team */
+int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds);
+int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds /* [2]: potrf, sygst */);   /* distributed form, see ek_hip_sytrd_team */
 int ek_hip_profile_symv_get(double *seconds, long long *launches, double *algorithmic_bytes);
 
 #ifdef __cplusplus

@@ -101,6 +101,40 @@ def test_sygst_team_rehearsal(hip, oracle, n, P):
     assert np.abs(L @ Cs @ L.T - A).max() <= 64 * n * EPS * np.abs(A).max()
 
 
+@pytest.mark.parametrize("n,P", [(1, 2), (5, 3), (128, 2), (129, 2), (300, 1), (640, 4), (1000, 8), (1000, 16), (1537, 5)])
+def test_potrf_team_rehearsal(hip, oracle, n, P):
+    """PDPOTRF on a 1 x P grid: owner factors + one broadcast per block column; L and the block
+    inverses complete and bit-identical on every rank."""
+    B = oracle.synth_matrix(n, 2)
+    L_or, info_or = oracle.potrf_lower(B)
+    got, info, mismatch = hip.potrf_team(B, P)
+    assert info == info_or == 0
+    assert mismatch == 0
+    il = np.tril_indices(n)
+    assert np.abs(got[il] - L_or[il]).max() <= 16 * n * EPS * np.abs(L_or[il]).max()
+    Lg = np.tril(got)
+    assert np.abs(Lg @ Lg.T - B).max() <= 16 * n * EPS * np.abs(B).max()
+
+
+def test_potrf_team_reports_the_failing_pivot_on_every_rank(hip, oracle):
+    B = oracle.synth_matrix(400, 2)
+    B[150, 150] = -1.0
+    _, info_or = oracle.potrf_lower(B)
+    _, info, mismatch = hip.potrf_team(B, 4)      # block column 1 belongs to rank 1, not to rank 0
+    assert info == info_or == 151
+    # the count includes a unit for every rank whose info differs from rank 0's
+    _, info1, _ = hip.potrf_team(B, 1)
+    assert info1 == 151
+
+
+def test_potrf_over_rccl_world_of_one(hip, oracle, comm1):
+    B = oracle.synth_matrix(700, 2)
+    got, info, _ = hip.potrf_team(B, 0)
+    ref, info1, _ = hip.potrf_team(B, 1)
+    assert info == info1 == 0
+    assert np.array_equal(np.tril(got), np.tril(ref))
+
+
 def test_sygst_over_rccl_world_of_one(hip, oracle, comm1):
     n = 700
     A = oracle.synth_matrix(n, 1)
@@ -171,12 +205,15 @@ def test_sytrd_team_zero_needs_communicator(hip, oracle):
     assert hip.sytrd_team(A, 0)[4] == -7
 
 
+@pytest.mark.parametrize("min_ranks", ["3", "1"])
 @pytest.mark.parametrize("problem,n,n_vec", [("gep", 300, 300), ("sep", 515, 515), ("gep", 400, 37)])
-def test_whole_path_with_communicator_attached(hip, oracle, comm1, problem, n, n_vec):
+def test_whole_path_with_communicator_attached(hip, oracle, comm1, monkeypatch, min_ranks, problem, n, n_vec):
     """ek_hip_solve_device_grid with a communicator of the grid's size takes the distributed
     tridiagonalisation (here 1 x 1 over RCCL) and must agree with the plain single-GPU solve."""
     import ctypes
     lib = comm1
+    # "1": the distributed Cholesky factor and reduction to standard form are taken as well
+    monkeypatch.setenv("EK_HIP_DIST_MIN_RANKS", min_ranks)
     A = oracle.synth_matrix(n, 1)
     B = oracle.synth_matrix(n, 2) if problem == "gep" else None
     pb = 1 if problem == "gep" else 0

@@ -23,6 +23,13 @@ sec = ctypes.c_double(0)
 assert lib.ek_hip_debug_sytrd(n, 0, 1, ctypes.byref(sec)) == 0
 assert lib.ek_hip_debug_sytrd(n, 0, 2, ctypes.byref(sec)) == 0
 print("n=%d single-GPU sytrd: %.4f s" % (n, sec.value), flush=True)
+red = (ctypes.c_double * 2)()
+for P in teams:
+    if P >= 1:
+        assert lib.ek_hip_debug_reduce_team(n, P, 1, red) == 0
+        assert lib.ek_hip_debug_reduce_team(n, P, 2, red) == 0
+        print("n=%d team of %d rehearsed: potrf %.4f s total (%.4f per rank), sygst %.4f s total (%.4f per rank)"
+              % (n, P, red[0], red[0] / P, red[1], red[1] / P), flush=True)
 for P in teams:
     if P == 0:
         solver.comm_init(solver.comm_unique_id(), 1, 0)
