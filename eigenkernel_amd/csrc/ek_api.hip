@@ -156,6 +156,7 @@ struct Rccl {
 Rccl g_rccl;
 struct Comm {
   bool on = false;
+  bool host = false;    // exchanges go through the host's allgatherv hook instead of RCCL
   ncclComm_t comm = nullptr;
   int nranks = 0, rank = 0;
   int err = 0;          // first failing collective since the last check (ncclResult_t)
@@ -188,10 +189,63 @@ int dist_min_ranks() {
   return e ? atoi(e) : 3;
 }
 
+// ---- the same two exchanges through the host's allgatherv hook (ek_hip_set_allgatherv): for
+// hosts that have MPI but no RCCL-capable node, and for multi-process tests on one GPU.  Every
+// exchange drains the stream and crosses PCIe twice, so this is a compatibility path, not a fast
+// one.  The sum is formed on the host in rank order: bit-identical on every rank.
+std::vector<double> g_hx_send, g_hx_recv;
+void host_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t count, void *) {
+  if (nmem != 1 || !g_comm.on || !g_allgatherv) { if (!g_comm.err) g_comm.err = (int)ncclInvalidUsage; return; }
+  const int P = g_comm.nranks;
+  g_hx_send.resize(count); g_hx_recv.resize(count * P);
+  std::vector<long long> counts(P, (long long)count), displs(P);
+  for (int r = 0; r < P; ++r) displs[r] = (long long)r * (long long)count;
+  bool ok = hipStreamSynchronize(s) == hipSuccess &&
+            hipMemcpy(g_hx_send.data(), bufs[0], count * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  if (ok) ok = g_allgatherv(g_hx_send.data(), (long long)count, g_hx_recv.data(), counts.data(), displs.data(),
+                            g_allgatherv_user) == 0;
+  if (ok) {
+    for (size_t i = 0; i < count; ++i) {
+      double v = 0.0;
+      for (int r = 0; r < P; ++r) v += g_hx_recv[(size_t)r * count + i];
+      g_hx_send[i] = v;
+    }
+    ok = hipMemcpy(bufs[0], g_hx_send.data(), count * 8, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (!ok && !g_comm.err) g_comm.err = (int)ncclSystemError;
+}
+void host_allgatherv(hipStream_t s, int nmem, int, double *const *bufs, const size_t *offs, const size_t *counts,
+                     int nranks, void *) {
+  if (nmem != 1 || !g_comm.on || !g_allgatherv || nranks != g_comm.nranks) {
+    if (!g_comm.err) g_comm.err = (int)ncclInvalidUsage;
+    return;
+  }
+  const int me = g_comm.rank;
+  std::vector<long long> cnt(nranks), displs(nranks);
+  long long tot = 0;
+  for (int r = 0; r < nranks; ++r) { cnt[r] = (long long)counts[r]; displs[r] = tot; tot += cnt[r]; }
+  g_hx_send.resize(counts[me] > 0 ? counts[me] : 1); g_hx_recv.resize(tot > 0 ? (size_t)tot : 1);
+  bool ok = hipStreamSynchronize(s) == hipSuccess;
+  if (ok && counts[me] > 0)
+    ok = hipMemcpy(g_hx_send.data(), bufs[0] + offs[me], counts[me] * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  if (ok) ok = g_allgatherv(g_hx_send.data(), cnt[me], g_hx_recv.data(), cnt.data(), displs.data(), g_allgatherv_user) == 0;
+  for (int r = 0; ok && r < nranks; ++r)
+    if (r != me && counts[r] > 0)
+      ok = hipMemcpy(bufs[0] + offs[r], g_hx_recv.data() + displs[r], counts[r] * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok && !g_comm.err) g_comm.err = (int)ncclSystemError;
+}
+
 SytrdExchange team_exchange(int nteam) {
-  SytrdExchange x{nteam > 0 ? nteam : g_comm.nranks, nteam > 0 ? sytrd_team_allreduce : rccl_allreduce, nullptr};
-  x.allgatherv = nteam > 0 ? team_allgatherv : rccl_allgatherv;
+  SytrdExchange x{nteam > 0 ? nteam : g_comm.nranks, nullptr, nullptr};
+  if (nteam > 0) { x.allreduce = sytrd_team_allreduce; x.allgatherv = team_allgatherv; }
+  else if (g_comm.host) { x.allreduce = host_allreduce; x.allgatherv = host_allgatherv; }
+  else { x.allreduce = rccl_allreduce; x.allgatherv = rccl_allgatherv; }
   return x;
+}
+
+const char *comm_error_string() {
+  if (g_comm.host || !g_rccl.GetErrorString) return "exchange through the host hook failed";
+  return g_rccl.GetErrorString((ncclResult_t)g_comm.err);
 }
 
 // test aid (EK_HIP_TEAM_POISON=1): NaN into every column of the strips a member does not own, to
@@ -464,7 +518,7 @@ int ek_hip_potrf_team(int n, double *B_loc, const int desc_B[9], int nteam, long
   EK_HIP_CHECK(hipStreamSynchronize(s));
   for (int m = 1; m < nmem; ++m) if (infos[m] != infos[0]) cnt += 1;   // info must be known to all
   if (mismatch) *mismatch = (long long)cnt;
-  if (g_comm.err) { fprintf(stderr, "[ek_hip] RCCL exchange failed: %s\n", g_rccl.GetErrorString((ncclResult_t)g_comm.err)); return -996; }
+  if (g_comm.err) { fprintf(stderr, "[ek_hip] RCCL exchange failed: %s\n", comm_error_string()); return -996; }
   return infos[0];
 }
 
@@ -554,7 +608,7 @@ int ek_hip_sygst_team(int n, double *A_loc, const int desc_A[9], const double *L
     if (rc) return rc;
   }
   EK_HIP_CHECK(hipStreamSynchronize(s));
-  if (g_comm.err) { fprintf(stderr, "[ek_hip] RCCL exchange failed: %s\n", g_rccl.GetErrorString((ncclResult_t)g_comm.err)); return -996; }
+  if (g_comm.err) { fprintf(stderr, "[ek_hip] RCCL exchange failed: %s\n", comm_error_string()); return -996; }
   return 0;
 }
 
@@ -698,7 +752,7 @@ int ek_hip_sytrd_team(int n, double *A_loc, const int desc_A[9], double *d, doub
   EK_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
   EK_HIP_CHECK(hipStreamSynchronize(s));
   if (mismatch) *mismatch = (long long)cnt;
-  if (g_comm.err) { fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", g_rccl.GetErrorString((ncclResult_t)g_comm.err)); return -996; }
+  if (g_comm.err) { fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", comm_error_string()); return -996; }
   return 0;
 }
 
@@ -726,12 +780,28 @@ int ek_hip_comm_init(const void *id, int bytes, int nranks, int rank) {
   int rc = ensure_init(); if (rc) return rc;
   std::lock_guard<std::mutex> lk(g_mu);
   rc = g_rccl.load(); if (rc) return rc;
-  if (g_comm.on) { (void)g_rccl.CommDestroy(g_comm.comm); g_comm = Comm{}; }
+  if (g_comm.on && !g_comm.host) (void)g_rccl.CommDestroy(g_comm.comm);
+  g_comm = Comm{};
+  EK_HIP_CHECK(hipSetDevice(g_ctx.device));
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
   const ncclResult_t r = g_rccl.CommInitRank(&g_comm.comm, nranks, uid, rank);
   if (r != ncclSuccess) { fprintf(stderr, "[ek_hip] ncclCommInitRank: %s\n", g_rccl.GetErrorString(r)); return -996; }
   g_comm.on = true; g_comm.nranks = nranks; g_comm.rank = rank; g_comm.err = 0;
+  return 0;
+}
+
+// The same distributed stages with every exchange routed through the host's allgatherv hook
+// (ek_hip_set_allgatherv) instead of RCCL.
+int ek_hip_comm_attach_host(int nranks, int rank) {
+  if (nranks < 1 || nranks > kMaxTeam) return -1;
+  if (rank < 0 || rank >= nranks) return -2;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_allgatherv) return -998;
+  if (g_comm.on && !g_comm.host) (void)g_rccl.CommDestroy(g_comm.comm);
+  g_comm = Comm{};
+  g_comm.on = true; g_comm.host = true; g_comm.nranks = nranks; g_comm.rank = rank;
   return 0;
 }
 
@@ -742,7 +812,7 @@ int ek_hip_comm_destroy(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_comm.on) {
     if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
-    (void)g_rccl.CommDestroy(g_comm.comm);
+    if (!g_comm.host) (void)g_rccl.CommDestroy(g_comm.comm);
   }
   g_comm = Comm{};
   return 0;
@@ -758,7 +828,7 @@ int ek_hip_comm_allreduce_device(double *dbuf, long long count) {
   if (!g_comm.on) return -995;
   g_comm.err = 0;
   double *bufs[1] = {dbuf};
-  if (count > 0) rccl_allreduce(g_ctx.stream, 1, bufs, (size_t)count, nullptr);
+  if (count > 0) team_exchange(0).allreduce(g_ctx.stream, 1, bufs, (size_t)count, nullptr);
   EK_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
   return g_comm.err ? -996 : 0;
 }
@@ -1169,7 +1239,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     tm.destroy();
   }
   if (dist && g_comm.err) {
-    fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", g_rccl.GetErrorString((ncclResult_t)g_comm.err));
+    fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", comm_error_string());
     return -996;
   }
   if (info[0] != 0) return info[0];          // Cholesky: leading minor not positive definite

@@ -77,6 +77,7 @@ def load_library(path=None):
         "ek_hip_potrf_team": (c_int, [c_int, _dp, _ip, c_int, _llp]),
         "ek_hip_comm_unique_id": (c_int, [vp, c_int]),
         "ek_hip_comm_init": (c_int, [vp, c_int, c_int, c_int]),
+        "ek_hip_comm_attach_host": (c_int, [c_int, c_int]),
         "ek_hip_comm_size": (c_int, []),
         "ek_hip_comm_rank": (c_int, []),
         "ek_hip_comm_destroy": (c_int, []),
@@ -126,7 +127,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_residual_device", "ek_hip_orthogonality_device", "ek_hip_ipratios_device", "ek_hip_check",
     "ek_hip_sytrd_team", "ek_hip_comm_unique_id", "ek_hip_comm_init", "ek_hip_comm_size", "ek_hip_comm_rank",
     "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device", "ek_hip_debug_sytrd_team", "ek_hip_sygst_team",
-    "ek_hip_potrf_team", "ek_hip_debug_reduce_team",
+    "ek_hip_potrf_team", "ek_hip_debug_reduce_team", "ek_hip_comm_attach_host",
 )
 
 
@@ -375,6 +376,13 @@ def comm_init(uid, nranks, rank):
     rc = lib.ek_hip_comm_init(buf, 128, nranks, rank)
     if rc:
         raise SolverError("ek_hip_comm_init: %d" % rc, rc)
+
+
+def comm_attach_host(nranks, rank):
+    """Distributed stages with the exchanges going through the registered allgatherv hook."""
+    rc = load_library().ek_hip_comm_attach_host(nranks, rank)
+    if rc:
+        raise SolverError("ek_hip_comm_attach_host: %d" % rc, rc)
 
 
 def comm_destroy():

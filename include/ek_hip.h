@@ -149,6 +149,11 @@ int ek_hip_solve_device_grid(int problem, int n, int n_vec,
 #define EK_HIP_COMM_ID_BYTES 128
 int ek_hip_comm_unique_id(void *id, int bytes);
 int ek_hip_comm_init(const void *id, int bytes, int nranks, int rank);
+/* The same distributed stages with every exchange routed through the host's allgatherv hook
+ * (ek_hip_set_allgatherv, below) instead of RCCL: for an MPI host on a node without an
+ * RCCL-capable fabric, and for multi-process tests that share one GPU.  Every exchange drains
+ * the stream and crosses PCIe twice -- a compatibility path.  -998 if no hook is registered. */
+int ek_hip_comm_attach_host(int nranks, int rank);
 int ek_hip_comm_size(void);                     /* 0 when none is attached */
 int ek_hip_comm_rank(void);                     /* -1 when none is attached */
 int ek_hip_comm_destroy(void);

@@ -11,6 +11,8 @@ two halves that together make the production path:
 Results are held to the same bounds as the single-GPU stage (tests/test_gpu_blocks.py) and to
 bit-identity across the ranks of a team.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -251,3 +253,149 @@ def test_whole_path_with_communicator_attached(hip, oracle, comm1, monkeypatch, 
     assert np.abs(R).max() <= 1e-12
     G = Z_d.T @ Bm @ Z_d
     assert np.abs(G - np.eye(n_vec)).max() <= 1e-11
+
+
+# ------------------------------------------------------------------------------------------------
+# Real multi-process runs on ONE GPU: three ranks (processes) share the device, each holds only its
+# own data, and every exchange of the distributed stages travels between the processes through
+# the host hook (gloo all-gather on CPU tensors) -- ek_hip_comm_attach_host.  What the team
+# rehearsal cannot show (a rank other than 0 taking the one-member code path, true process
+# separation) is shown here; what neither shows is RCCL's wire, which needs more than one GPU.
+def _mp_worker(rank, world, port, q):
+    import faulthandler
+    import sys
+    import traceback
+    faulthandler.dump_traceback_later(150, exit=True)     # a stuck rank says where, then goes away
+
+    def say(what):
+        sys.stderr.write("[rank %d] %s\n" % (rank, what)); sys.stderr.flush()
+    try:
+        say("start")
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from eigenkernel_amd import solver as sv, descriptor as d
+        from oracle import ek_oracle
+        say("process group up")
+        lib = sv.load_library()
+        assert lib.ek_hip_init(0) == 0
+        say("GPU bound")
+        sv.set_allgatherv(sv.torch_allgatherv(dist))
+        sv.comm_attach_host(world, rank)
+        out = {}
+        # (1) the distributed tridiagonalisation, this process being rank `rank` of the team
+        n = 700
+        A = ek_oracle.synth_matrix(n, 1)
+        Ar, dd, ee, tau, info, _ = sv.sytrd_team(A, 0)
+        assert info == 0
+        out["sytrd"] = (dd.copy(), ee.copy(), tau.copy(), np.tril(Ar))
+        say("sytrd done")
+        # (2) Cholesky factor (complete on every rank) and the reduction (own strips only)
+        B = ek_oracle.synth_matrix(n, 2)
+        Lg, info, _ = sv.potrf_team(B, 0)
+        assert info == 0
+        out["potrf"] = np.tril(Lg)
+        C, info = sv.sygst_team(A, np.tril(Lg), 0)
+        assert info == 0
+        own = [c for c in range(n) if (c // 128) % world == rank]
+        out["sygst_cols"] = (own, C[:, own].copy())
+        say("potrf, sygst done")
+        # (3) whole path, replicated inputs, 1 x world grid: this rank's block-cyclic piece of Z
+        res = {}
+        for solver_name, nv in (("general_hip", None), ("hip", None), ("general_hip_select", 50)):
+            gen = solver_name.startswith("general")
+            proc = sv.Process(rank, world, 0, 1, world, 0, rank)
+            ep, _ = sv.eigen_solver(solver_name, A, B if gen else None, n_vec=nv, proc=proc)
+            nb = int(ep.desc[d.BLOCK_ROW_])
+            nvec = ep.n_vec
+            cols = d.local_indices(nvec, nb, rank, world)
+            res[solver_name] = (ep.values.copy(), cols, ep.Vectors[:, :len(cols)].copy())
+            say(solver_name + " done")
+        out["solve"] = res
+        sv.comm_destroy()
+        q.put((rank, out, None))
+        dist.barrier()
+        dist.destroy_process_group()
+        say("finished")
+    except Exception:
+        q.put((rank, None, traceback.format_exc()))
+    faulthandler.cancel_dump_traceback_later()
+    # hand the result over completely, then leave without the interpreter's tear-down (GPU runtime,
+    # gloo threads): nothing a rank does after its report may hold up the test
+    q.close(); q.join_thread()
+    sys.stderr.flush()
+    os._exit(0)
+
+
+def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle):
+    # the standard library's spawn, not torch.multiprocessing: this (pytest) process has the ROCm
+    # HIP runtime loaded through libek_hip.so and must not load PyTorch's bundled copy on top of it
+    import multiprocessing as mp
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_mp_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    got = []
+    try:
+        for _ in procs:
+            got.append(q.get(timeout=200))
+    except _queue.Empty:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        pytest.fail("only %d of %d ranks reported (their progress lines are on stderr)" % (len(got), world))
+    res = sorted(got, key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.terminate()
+    for rank, out, err in res:
+        assert err is None, "rank %d:\n%s" % (rank, err)
+    outs = [r[1] for r in res]
+    n = 700
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    # sytrd: identical bits on the three processes, and the rehearsal of a team of three gives them too
+    for o in outs[1:]:
+        for a, b in zip(outs[0]["sytrd"], o["sytrd"]):
+            assert np.array_equal(a, b)
+    Ar, dd, ee, tau, info, mm = hip.sytrd_team(A, world)
+    assert info == 0 and mm == 0
+    assert np.array_equal(dd, outs[0]["sytrd"][0]) and np.array_equal(ee, outs[0]["sytrd"][1])
+    assert np.array_equal(tau, outs[0]["sytrd"][2]) and np.array_equal(np.tril(Ar), outs[0]["sytrd"][3])
+    _check_against_single(hip, oracle, A, outs[0]["sytrd"][3], *outs[0]["sytrd"][:3])
+    # potrf: the complete factor on every process
+    for o in outs[1:]:
+        assert np.array_equal(outs[0]["potrf"], o["potrf"])
+    L = outs[0]["potrf"]
+    assert np.abs(L @ L.T - B).max() <= 16 * n * EPS * np.abs(B).max()
+    # sygst: every strip from its owner
+    C = np.zeros((n, n))
+    for o in outs:
+        own, cols = o["sygst_cols"]
+        C[:, own] = cols
+    Cs = np.tril(C) + np.tril(C, -1).T
+    assert np.abs(L @ Cs @ L.T - A).max() <= 64 * n * EPS * np.abs(A).max()
+    # whole path: eigenvalues identical on all processes and equal to the oracle's; the pieces of Z
+    # assemble to B-orthonormal eigenvectors with a small residual
+    for name, Bm in (("general_hip", B), ("hip", None), ("general_hip_select", B)):
+        w0 = outs[0]["solve"][name][0]
+        for o in outs[1:]:
+            assert np.array_equal(w0, o["solve"][name][0])
+        w_or = oracle.solve(A, Bm)[0] if Bm is not None else np.linalg.eigvalsh(A)
+        nvec = 50 if name.endswith("select") else n
+        assert np.abs(w0[:nvec] - w_or[:nvec]).max() <= 4 * n * EPS * np.abs(w_or).max()
+        Z = np.zeros((n, nvec))
+        seen = np.zeros(nvec, dtype=int)
+        for o in outs:
+            _, cols, Zl = o["solve"][name]
+            Z[:, cols] = Zl[:n, :]
+            seen[cols] += 1
+        assert (seen == 1).all()
+        Bd = Bm if Bm is not None else np.eye(n)
+        assert np.abs(A @ Z - (Bd @ Z) * w0[:nvec]).max() <= 1e-12
+        assert np.abs(Z.T @ Bd @ Z - np.eye(nvec)).max() <= 1e-11
