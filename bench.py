@@ -424,7 +424,9 @@ def main():
 
 if __name__ == "__main__":
     main()
-    # the line is out; leave without the interpreter's tear-down of the GPU runtime and the
-    # process-group threads, so that nothing after the measurement can hold a rank up
-    sys.stdout.flush(); sys.stderr.flush()
-    os._exit(0)
+    # multi-rank runs: the line is out; leave without the interpreter's tear-down of the GPU
+    # runtime and the process-group threads, so that nothing after the measurement can hold a rank
+    # up (a single rank exits normally: a profiler attached to it writes its output at exit)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
