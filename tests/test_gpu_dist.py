@@ -399,3 +399,89 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
         Bd = Bm if Bm is not None else np.eye(n)
         assert np.abs(A @ Z - (Bd @ Z) * w0[:nvec]).max() <= 1e-12
         assert np.abs(Z.T @ Bd @ Z - np.eye(nvec)).max() <= 1e-11
+
+
+def _mp_grid_worker(rank, world, port, q, nprow, npcol, inputs):
+    """Whole path on an nprow x npcol grid, one process per cell, exchanges through the host."""
+    import faulthandler
+    import sys
+    import traceback
+    faulthandler.dump_traceback_later(150, exit=True)
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from eigenkernel_amd import solver as sv, descriptor as d
+        from oracle import ek_oracle
+        lib = sv.load_library()
+        assert lib.ek_hip_init(0) == 0
+        sv.set_allgatherv(sv.torch_allgatherv(dist))
+        sv.comm_attach_host(world, rank)
+        n = 450
+        A = ek_oracle.synth_matrix(n, 1)
+        B = ek_oracle.synth_matrix(n, 2)
+        _, _, myrow, mycol = d.make_process_grid(rank, world, nprow, npcol)
+        proc = sv.Process(rank, world, 0, nprow, npcol, myrow, mycol)
+        ep, _ = sv.eigen_solver("general_hip", A, B, proc=proc, inputs=inputs)
+        sys.stderr.write("[rank %d] (%d,%d) solved, stages %s\n" % (rank, myrow, mycol, sorted(ep.stage_seconds)[:1]))
+        out = (myrow, mycol, int(ep.desc[d.BLOCK_ROW_]), ep.values.copy(), ep.Vectors.copy(),
+               getattr(ep, "B_loc", None))
+        sv.comm_destroy()
+        q.put((rank, out, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, None, traceback.format_exc()))
+    faulthandler.cancel_dump_traceback_later()
+    q.close(); q.join_thread()
+    sys.stderr.flush()
+    os._exit(0)
+
+
+@pytest.mark.parametrize("inputs", ["replicated", "distributed"])
+def test_four_processes_on_a_2x2_grid(hip, oracle, inputs):
+    """The reference's near-square grid for four ranks (processes.f90:56-65): rank = myrow*npcol +
+    mycol is the team index of the distributed stages whatever the grid's shape; with
+    inputs="distributed" the ranks hand in block-cyclic pieces of A and B as the reference does and
+    get back pieces of Z and of L."""
+    import multiprocessing as mp
+    import queue as _queue
+    from eigenkernel_amd import descriptor as d
+    world, nprow, npcol, n = 4, 2, 2, 450
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37600 + (os.getpid() % 1000) + (0 if inputs == "replicated" else 1000)
+    procs = [ctx.Process(target=_mp_grid_worker, args=(r, world, port, q, nprow, npcol, inputs), daemon=True)
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in procs:
+            got.append(q.get(timeout=200))
+    except _queue.Empty:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        pytest.fail("only %d of %d ranks reported" % (len(got), world))
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.terminate()
+    for rank, out, err in got:
+        assert err is None, "rank %d:\n%s" % (rank, err)
+    outs = [g[1] for g in sorted(got, key=lambda t: t[0])]
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2)
+    w_or = oracle.solve(A, B)[0]
+    nb = outs[0][2]
+    for o in outs:
+        assert o[2] == nb and np.array_equal(o[3], outs[0][3])
+    w = outs[0][3]
+    assert np.abs(w - w_or).max() <= 4 * n * EPS * np.abs(w_or).max()
+    Z = d.assemble_global({(o[0], o[1]): o[4] for o in outs}, n, n, nb, nprow, npcol)
+    assert np.abs(A @ Z - (B @ Z) * w).max() <= 1e-12
+    assert np.abs(Z.T @ B @ Z - np.eye(n)).max() <= 1e-11
+    if inputs == "distributed":      # B_loc came back as the pieces of L
+        L = np.tril(d.assemble_global({(o[0], o[1]): o[5] for o in outs}, n, n, nb, nprow, npcol))
+        assert np.abs(L @ L.T - B).max() <= 16 * n * EPS * np.abs(B).max()
