@@ -1411,13 +1411,86 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
   if (n > 0 && !Z_loc) return -9;
   rc = check_desc(desc_Z, 10, n, n, rows_of(desc_Z)); if (rc) return rc;
   // grids other than 1x1 need the host's exchange hook (ek_hip_set_allgatherv)
-  if (nprow != 1 && !(nprow > 1 && g_allgatherv)) return -11;
-  if (npcol != 1 && !(npcol > 1 && g_allgatherv)) return -12;
+  const bool have_exchange = g_allgatherv || (g_comm.on && nprow > 0 && npcol > 0 && g_comm.nranks == nprow * npcol);
+  if (nprow != 1 && !(nprow > 1 && have_exchange)) return -11;
+  if (npcol != 1 && !(npcol > 1 && have_exchange)) return -12;
   if (myrow < 0 || myrow >= nprow) return -13;
   if (mycol < 0 || mycol >= npcol) return -14;
   rc = ensure_init(); if (rc) return rc;
   if (n == 0) return 0;
   std::lock_guard<std::mutex> lk(g_mu);
+  if (nprow * npcol > 1 && g_comm.on && g_comm.nranks == nprow * npcol) {
+    // distributed inputs with a communicator attached: only the local pieces cross PCIe; the full
+    // matrices are assembled in HBM by one all-gather per matrix (RCCL over xGMI, or the host hook
+    // of a host communicator) and the pieces of the reflectors / of L are cut out on the device
+    const GridCell cell{desc_Z[4], nprow, npcol, myrow, mycol};
+    if (g_comm.rank != myrow * npcol + mycol) return -994;
+    hipStream_t s = g_ctx.stream;
+    const int P = nprow * npcol, me = g_comm.rank;
+    const SytrdExchange x = team_exchange(0);
+    auto t0 = std::chrono::steady_clock::now();
+    DevMem mem;
+    double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr, *pk = nullptr;
+    const size_t nn = (size_t)n * n;
+    const int nrz = numroc0(n, cell.nb, myrow, nprow), ncz = numroc0(n_vec, cell.nb, mycol, npcol);
+    const int ldzl = nrz > 1 ? nrz : 1;
+    rc = mem.alloc(&uA, nn * 8);
+    if (!rc && problem == 1) rc = mem.alloc(&uB, nn * 8);
+    if (!rc) rc = mem.alloc(&pk, nn * 8);
+    if (!rc) rc = mem.alloc(&uZ, (size_t)ldzl * (ncz > 0 ? ncz : 1) * 8);
+    if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
+    if (rc) return rc;
+    g_comm.err = 0;
+    auto assemble = [&](const double *M_loc, const int *desc, double *full) -> int {
+      const int nb = desc[4];
+      size_t offs[kMaxTeam], counts[kMaxTeam];
+      size_t tot = 0;
+      for (int r = 0; r < P; ++r) {
+        counts[r] = (size_t)numroc0(n, nb, r / npcol, nprow) * numroc0(n, nb, r % npcol, npcol);
+        offs[r] = tot; tot += counts[r];
+      }
+      const int nr = numroc0(n, nb, myrow, nprow), nc = numroc0(n, nb, mycol, npcol);
+      if (nr > 0 && nc > 0) { int r2 = h2d_matrix(nr, nc, M_loc, desc[8], pk + offs[me], nr, s); if (r2) return r2; }
+      double *bufs[1] = {pk};
+      x.allgatherv(s, 1, me, bufs, offs, counts, P, x.user);
+      for (int r = 0; r < P; ++r)
+        scatter_block_cyclic(s, numroc0(n, nb, r / npcol, nprow), numroc0(n, nb, r % npcol, npcol), pk + offs[r],
+                             numroc0(n, nb, r / npcol, nprow) > 1 ? numroc0(n, nb, r / npcol, nprow) : 1, nb, nprow,
+                             r / npcol, npcol, r % npcol, full, n);
+      return 0;
+    };
+    auto tg0 = std::chrono::steady_clock::now();
+    int info = assemble(A_loc, desc_A, uA);
+    if (!info && problem == 1) info = assemble(B_loc, desc_B, uB);
+    if (!info) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) info = -1000 - (int)e; }
+    if (!info && g_comm.err) info = -996;
+    const double tg = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
+    auto t1 = std::chrono::steady_clock::now();
+    if (!info) info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, ldzl, stage_seconds, n_stages, &cell);
+    auto t2 = std::chrono::steady_clock::now();
+    if (info > -1000) {
+      int rc2 = 0;
+      if (nrz > 0 && ncz > 0) rc2 = d2h_matrix(nrz, ncz, uZ, ldzl, Z_loc, desc_Z[8], s);
+      auto cut = [&](const double *full, const int *desc, double *M_loc) -> int {
+        const int nb = desc[4], nr = numroc0(n, nb, myrow, nprow), nc = numroc0(n, nb, mycol, npcol);
+        if (nr <= 0 || nc <= 0) return 0;
+        gather_block_cyclic(s, nr, nc, full, n, nb, nprow, myrow, npcol, mycol, pk, nr);
+        return d2h_matrix(nr, nc, pk, nr, M_loc, desc[8], s);
+      };
+      if (!rc2) rc2 = cut(uA, desc_A, A_loc);
+      if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }   // pk is reused
+      if (!rc2 && problem == 1) rc2 = cut(uB, desc_B, B_loc);
+      if (!rc2) { hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+      if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+      if (rc2 && info == 0) info = rc2;
+    }
+    auto t3 = std::chrono::steady_clock::now();
+    if (stage_seconds && n_stages > EK_STAGE_COPY)
+      stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() - tg +
+                                      std::chrono::duration<double>(t3 - t2).count();
+    if (stage_seconds && n_stages > EK_STAGE_GATHER) stage_seconds[EK_STAGE_GATHER] += tg;
+    return info;
+  }
   if (nprow * npcol > 1) {
     // distributed inputs: assemble the full matrices on every rank through the hook, then
     // proceed as in the replicated-input mode; A_loc / B_loc receive their pieces of the

@@ -63,6 +63,10 @@ void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, con
 void gather_block_cyclic(hipStream_t s, int mr, int nc, const double *src, int lds, int nb, int pr,
                          int me_r, int pc, int me_c, double *dst, int ldd);
 
+// global dst <- the local piece src (mr x nc, lds) of owner (me_r, me_c)
+void scatter_block_cyclic(hipStream_t s, int mr, int nc, const double *src, int lds, int nb, int pr,
+                          int me_r, int pc, int me_c, double *dst, int ldd);
+
 void maxabs_lower(hipStream_t s, int n, const double *A, int lda, double *partial /* 256 */);
 void scale_lower(hipStream_t s, int n, double alpha, double *A, int lda);
 void scale_vector(hipStream_t s, int n, double alpha, double *x);

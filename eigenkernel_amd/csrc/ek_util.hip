@@ -161,6 +161,25 @@ void gather_columns(hipStream_t s, int m, int n, const double *src, int lds, con
                      dst, ldd);
 }
 
+// the inverse map: dst(global) <- src(local piece of owner (me_r, me_c))
+__global__ void bc_scatter_kernel(int mr, int nc, const double *__restrict__ src, int lds, int nb,
+                                  int pr, int me_r, int pc, int me_c, double *__restrict__ dst, int ldd) {
+  const int lr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lr >= mr) return;
+  const size_t gr = (size_t)((lr / nb) * pr + me_r) * nb + lr % nb;
+  for (int lc = blockIdx.y; lc < nc; lc += gridDim.y) {
+    const size_t gc = (size_t)((lc / nb) * pc + me_c) * nb + lc % nb;
+    dst[gr + gc * ldd] = src[(size_t)lr + (size_t)lc * lds];
+  }
+}
+
+void scatter_block_cyclic(hipStream_t s, int mr, int nc, const double *src, int lds, int nb, int pr,
+                          int me_r, int pc, int me_c, double *dst, int ldd) {
+  if (mr <= 0 || nc <= 0) return;
+  hipLaunchKernelGGL(bc_scatter_kernel, grid2d(mr, nc), dim3(256), 0, s, mr, nc, src, lds, nb, pr, me_r,
+                     pc, me_c, dst, ldd);
+}
+
 void gather_block_cyclic(hipStream_t s, int mr, int nc, const double *src, int lds, int nb, int pr,
                          int me_r, int pc, int me_c, double *dst, int ldd) {
   if (mr <= 0 || nc <= 0) return;

@@ -143,6 +143,10 @@ int ek_hip_solve_device_grid(int problem, int n, int n_vec,
  * ek_hip_solve on a grid of exactly that many ranks distribute PDSYTRD over the ranks (1 x P
  * column-block-cyclic, 128-wide blocks, one ncclAllReduce of <= 2n+1 doubles per Householder
  * column issued on the library's stream) on top of the column sharding of the eigenvector stages.
+ * With a communicator attached ek_hip_solve also takes the reference's own data contract (block-
+ * cyclic pieces of A and B in; pieces of Z, of the reflectors and of L out) on that grid WITHOUT the
+ * host hook: only the local pieces cross PCIe, the full matrices are assembled in HBM by one
+ * all-gather per matrix and the returned pieces are cut out on the device.
  * Collective: every rank of the communicator must make the same calls in the same order
  * (as main.f90:100-104 does).  Returns: -995 no communicator, -996 RCCL error, -997 RCCL not
  * loadable, -994 rank/grid-cell mismatch. */
