@@ -265,13 +265,13 @@ def _mp_worker(rank, world, port, q):
     import faulthandler
     import sys
     import traceback
-    faulthandler.dump_traceback_later(150, exit=True)     # a stuck rank says where, then goes away
 
     def say(what):
         sys.stderr.write("[rank %d] %s\n" % (rank, what)); sys.stderr.flush()
     try:
         say("start")
-        import torch.distributed as dist
+        import torch.distributed as dist      # the first import on a fresh box can take minutes
+        faulthandler.dump_traceback_later(150, exit=True)     # from here a stuck rank says where, then goes away
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from eigenkernel_amd import solver as sv, descriptor as d
@@ -342,7 +342,7 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
     got = []
     try:
         for _ in procs:
-            got.append(q.get(timeout=200))
+            got.append(q.get(timeout=420 if not got else 200))
     except _queue.Empty:
         for p in procs:
             if p.is_alive():
@@ -406,9 +406,9 @@ def _mp_grid_worker(rank, world, port, q, nprow, npcol, inputs):
     import faulthandler
     import sys
     import traceback
-    faulthandler.dump_traceback_later(150, exit=True)
     try:
         import torch.distributed as dist
+        faulthandler.dump_traceback_later(150, exit=True)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from eigenkernel_amd import solver as sv, descriptor as d
@@ -458,7 +458,7 @@ def test_four_processes_on_a_2x2_grid(hip, oracle, inputs):
     got = []
     try:
         for _ in procs:
-            got.append(q.get(timeout=200))
+            got.append(q.get(timeout=420 if not got else 200))
     except _queue.Empty:
         for p in procs:
             if p.is_alive():
