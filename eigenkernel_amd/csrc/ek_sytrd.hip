@@ -34,6 +34,10 @@ namespace {
 
 constexpr int NBP = 64;      // panel width (128 measured equal: shorter SYR2K, longer column updates)
 constexpr int TS = 128;      // symv strip width / row-block height
+#ifndef EK_NDOT
+#define EK_NDOT 8
+#endif
+constexpr int NDOT = EK_NDOT;   // reducer workgroups of the panel products inside a symv launch
 
 struct SytrdBufs {
   double *xbuf;      // npad     unscaled current column (0 above the active part)
@@ -339,7 +343,7 @@ struct SymvArgs {
   int P;            // strip stride: 1, or the team size of a distributed run (strips S0, S0+P, ...)
   int q, nwg;       // tiles per workgroup, symv workgroups
   int ntiles;
-  int ndot;         // 1 if a reducer workgroup (blockIdx 0) totals the panel products, else 0
+  int ndot;         // reducer workgroups (blockIdx < ndot) that total the panel products: NDOT or 0
   int nchunks;      // colupd workgroups that produced normpart / dotpart
 };
 
@@ -387,23 +391,32 @@ __global__ __launch_bounds__(256, 2) void symv_kernel(SymvArgs p) {
   const double *__restrict__ xbuf = p.b.xbuf;
 
   if ((int)blockIdx.x < p.ndot) {
-    // ---- reducer: totals of the raw panel products V^T x, W^T x (colupd applies the scaling)
-    constexpr int HALVES = 256 / (2 * NBP);          // thread groups that share the chunk range
-    double a0 = 0.0, a1 = 0.0;
-    const int k2 = t & (2 * NBP - 1), half = t / (2 * NBP);
-    int c = half;
-    for (; c + HALVES < p.nchunks; c += 2 * HALVES) {
-      a0 += p.b.dotpart[(size_t)c * 2 * NBP + k2];
-      a1 += p.b.dotpart[(size_t)(c + HALVES) * 2 * NBP + k2];
+    // ---- reducers: totals of the raw panel products V^T x, W^T x (colupd applies the scaling).
+    // NDOT workgroups, each owning 2*NBP/NDOT of the 2*NBP columns (so no cross-workgroup sum):
+    // thread = (column, one of GRP chunk groups), 4 loads in flight, fixed-order LDS finish.
+    constexpr int CPW = 2 * NBP / NDOT;              // columns per reducer workgroup
+    constexpr int GRP = 256 / CPW;                   // chunk groups
+    const int col = t % CPW, grp = t / CPW;
+    const int k2 = (int)blockIdx.x * CPW + col;
+    const double *dp = p.b.dotpart + k2;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int c = grp;
+    for (; c + 3 * GRP < p.nchunks; c += 4 * GRP) {
+      a0 += dp[(size_t)c * 2 * NBP];
+      a1 += dp[(size_t)(c + GRP) * 2 * NBP];
+      a2 += dp[(size_t)(c + 2 * GRP) * 2 * NBP];
+      a3 += dp[(size_t)(c + 3 * GRP) * 2 * NBP];
     }
-    if (c < p.nchunks) a0 += p.b.dotpart[(size_t)c * 2 * NBP + k2];
-    s_dot[half][k2] = a0 + a1;
+    for (; c < p.nchunks; c += GRP) a0 += dp[(size_t)c * 2 * NBP];
+    double *sd = &s_dot[0][0];                       // 2 * 2 * NBP >= 256 doubles
+    sd[grp * CPW + col] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (t < 2 * NBP) {
+    if (t < CPW) {
       double tot = 0.0;
 #pragma unroll
-      for (int h = 0; h < HALVES; ++h) tot += s_dot[h][t];
-      p.b.dottot[t] = ((t & (NBP - 1)) < p.i) ? tot : 0.0;
+      for (int g = 0; g < GRP; ++g) tot += sd[g * CPW + t];
+      const int kk = (int)blockIdx.x * CPW + t;
+      p.b.dottot[kk] = ((kk & (NBP - 1)) < p.i) ? tot : 0.0;
     }
     return;
   }
@@ -718,7 +731,7 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
       sv.q = ceil_div(sv.ntiles, target);
       if (knobs().G > 0 && sv.q < knobs().G) sv.q = knobs().G;
       sv.nwg = ceil_div(sv.ntiles, sv.q);
-      sv.ndot = (i > 0) ? 1 : 0;
+      sv.ndot = (i > 0) ? NDOT : 0;
       sv.nchunks = nchunks_cur;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       const bool timed = g_prof.enabled && (j % g_prof.stride == 0);
@@ -880,14 +893,14 @@ void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, co
         sv.ntiles = (T > 0) ? tile_start(ceil_div(T, P), T, P) : 0;
         if (sv.ntiles > 0) {
           // a member streams 1/P of the triangle per launch, so per-workgroup fixed costs weigh
-          // more than on one GPU: fewer, longer runs (measured, team of 8: N=16384 128 workgroups
-          // 0.55 s/rank vs 0.59 at 256 and 0.63 at 512; N=32768 256 best)
-          const int target = (knobs().wgs > 0) ? knobs().wgs : (sv.ntiles <= 1100 ? 128 : 256);
+          // more than on one GPU: one workgroup per CU (measured, team of 8, s per rank: N=16384
+          // 0.470 / 0.460 / 0.474 / 0.472 at 192 / 256 / 384 / 512; N=32768 1.70 / 1.72 at 256 / 512)
+          const int target = (knobs().wgs > 0) ? knobs().wgs : 256;
           sv.q = ceil_div(sv.ntiles, target);
           if (knobs().G > 0 && sv.q < knobs().G) sv.q = knobs().G;
           sv.nwg = ceil_div(sv.ntiles, sv.q);
         } else { sv.q = 1; sv.nwg = 0; }
-        sv.ndot = (i > 0) ? 1 : 0;
+        sv.ndot = (i > 0) ? NDOT : 0;
         sv.nchunks = nchunks_cur;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = g_prof.enabled && m == 0 && (j % g_prof.stride == 0) && sv.nwg > 0;
