@@ -235,8 +235,43 @@ void host_allgatherv(hipStream_t s, int nmem, int, double *const *bufs, const si
   if (!ok && !g_comm.err) g_comm.err = (int)ncclSystemError;
 }
 
+// ---- peer windows (ek_hip_comm_peer_enable): the per-column exchange of the tridiagonalisation
+// without a collective.  Each rank allocates one receive area in its HBM, exports it with
+// hipIpcGetMemHandle, and maps everybody else's; contributions are stored straight into the peers'
+// areas by yreduce and announced by stream memory operations.
+struct PeerX {
+  bool on = false;
+  PeerWindow win{};
+  unsigned long long seq = 0;
+  size_t bytes = 0;
+  bool opened[kMaxTeam] = {};
+};
+PeerX g_peer;
+constexpr size_t kPeerFlagBytes = 256;    // kMaxTeam 64-bit flags, padded
+
+void peer_signal(hipStream_t s, unsigned long long seq, void *) {
+  const PeerWindow &w = g_peer.win;
+  hipError_t e = hipSuccess;
+  for (int r = 0; r < w.nranks && e == hipSuccess; ++r)      // my number into my flag on every peer
+    if (r != w.me) e = hipStreamWriteValue64(s, w.base[r] + 8 * (size_t)w.me, seq, 0);
+  for (int r = 0; r < w.nranks && e == hipSuccess; ++r)      // every peer's number in my area
+    if (r != w.me)
+      e = hipStreamWaitValue64(s, w.base[w.me] + 8 * (size_t)r, seq, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull);
+  if (e != hipSuccess && !g_comm.err) g_comm.err = (int)ncclSystemError;
+}
+
+void peer_teardown() {
+  if (!g_peer.on) return;
+  if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+  for (int r = 0; r < g_peer.win.nranks; ++r)
+    if (r != g_peer.win.me && g_peer.opened[r]) (void)hipIpcCloseMemHandle(g_peer.win.base[r]);
+  if (g_peer.win.base[g_peer.win.me]) (void)hipFree(g_peer.win.base[g_peer.win.me]);
+  g_peer = PeerX{};
+}
+
 SytrdExchange team_exchange(int nteam) {
   SytrdExchange x{nteam > 0 ? nteam : g_comm.nranks, nullptr, nullptr};
+  if (nteam == 0 && g_peer.on && g_peer.win.nranks == g_comm.nranks) x.peer = &g_peer.win;
   if (nteam > 0) { x.allreduce = sytrd_team_allreduce; x.allgatherv = team_allgatherv; }
   else if (g_comm.host) { x.allreduce = host_allreduce; x.allgatherv = host_allgatherv; }
   else { x.allreduce = rccl_allreduce; x.allgatherv = rccl_allgatherv; }
@@ -780,6 +815,7 @@ int ek_hip_comm_init(const void *id, int bytes, int nranks, int rank) {
   int rc = ensure_init(); if (rc) return rc;
   std::lock_guard<std::mutex> lk(g_mu);
   rc = g_rccl.load(); if (rc) return rc;
+  peer_teardown();
   if (g_comm.on && !g_comm.host) (void)g_rccl.CommDestroy(g_comm.comm);
   g_comm = Comm{};
   EK_HIP_CHECK(hipSetDevice(g_ctx.device));
@@ -799,9 +835,71 @@ int ek_hip_comm_attach_host(int nranks, int rank) {
   int rc = ensure_init(); if (rc) return rc;
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_allgatherv) return -998;
+  peer_teardown();
   if (g_comm.on && !g_comm.host) (void)g_rccl.CommDestroy(g_comm.comm);
   g_comm = Comm{};
   g_comm.on = true; g_comm.host = true; g_comm.nranks = nranks; g_comm.rank = rank;
+  return 0;
+}
+
+// Peer windows for the attached communicator (collective call).  n_max = largest matrix order that
+// will be solved while they are enabled.  The handles travel through the communicator itself.
+int ek_hip_comm_peer_enable(int n_max) {
+  if (n_max < 1) return -1;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_comm.on) return -995;
+  peer_teardown();
+  hipStream_t s = g_ctx.stream;
+  const int P = g_comm.nranks, me = g_comm.rank;
+  PeerWindow &w = g_peer.win;
+  w.nranks = P; w.me = me; w.slots_off = kPeerFlagBytes;
+  w.maxcount = 2 * (size_t)pad_ld(n_max) + 8;
+  w.seq = &g_peer.seq; w.signal = peer_signal; w.user = nullptr;
+  g_peer.bytes = kPeerFlagBytes + (size_t)P * 2 * w.maxcount * sizeof(double);
+  char *mine = nullptr;
+  EK_HIP_CHECK(hipExtMallocWithFlags((void **)&mine, g_peer.bytes, hipDeviceMallocFinegrained));
+  EK_HIP_CHECK(hipMemset(mine, 0, g_peer.bytes));
+  EK_HIP_CHECK(hipDeviceSynchronize());
+  w.base[me] = mine;
+  // 64-byte handles, carried as 8 doubles per rank through the communicator's all-gather
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+  hipIpcMemHandle_t hs[kMaxTeam];
+  memset(hs, 0, sizeof(hs));
+  double *dh = nullptr;
+  DevMem mem;
+  rc = mem.alloc(&dh, sizeof(hs));
+  if (rc) return rc;
+  if (P > 1) {
+    EK_HIP_CHECK(hipIpcGetMemHandle(&hs[me], mine));
+    EK_HIP_CHECK(hipMemcpy(dh, hs, sizeof(hs), hipMemcpyHostToDevice));
+    size_t offs[kMaxTeam], counts[kMaxTeam];
+    for (int r = 0; r < P; ++r) { offs[r] = (size_t)r * 8; counts[r] = 8; }
+    g_comm.err = 0;
+    double *bufs[1] = {dh};
+    const SytrdExchange x = team_exchange(0);
+    x.allgatherv(s, 1, me, bufs, offs, counts, P, x.user);
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    if (g_comm.err) return -996;
+    EK_HIP_CHECK(hipMemcpy(hs, dh, sizeof(hs), hipMemcpyDeviceToHost));
+    for (int r = 0; r < P; ++r) {
+      if (r == me) continue;
+      EK_HIP_CHECK(hipIpcOpenMemHandle((void **)&w.base[r], hs[r], hipIpcMemLazyEnablePeerAccess));
+      g_peer.opened[r] = true;
+    }
+    // nobody stores into a peer before every rank has mapped every area: one more round trip
+    x.allgatherv(s, 1, me, bufs, offs, counts, P, x.user);
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    if (g_comm.err) return -996;
+  }
+  g_peer.seq = 0;
+  g_peer.on = true;
+  return 0;
+}
+
+int ek_hip_comm_peer_disable(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  peer_teardown();
   return 0;
 }
 
@@ -810,6 +908,7 @@ int ek_hip_comm_rank(void) { return g_comm.on ? g_comm.rank : -1; }
 
 int ek_hip_comm_destroy(void) {
   std::lock_guard<std::mutex> lk(g_mu);
+  peer_teardown();
   if (g_comm.on) {
     if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
     if (!g_comm.host) (void)g_rccl.CommDestroy(g_comm.comm);

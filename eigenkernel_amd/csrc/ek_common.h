@@ -145,6 +145,19 @@ struct SytrdMember {
   void *work;          // >= sytrd_dist_work_bytes(n, nranks)
   int rank;
 };
+// Peer mode of the per-column exchange: every rank owns a receive area in its HBM
+//   [flags: one 64-bit sequence number per source rank | slots: nranks x 2 x maxcount doubles]
+// that all ranks have mapped (base[r], hipIpc across processes).  signal() enqueues, on the
+// stream, "write seq into my flag on every peer, then wait until every peer's flag here is >= seq"
+// (stream memory operations executed by the command processor).
+struct PeerWindow {
+  int nranks, me;
+  char *base[kMaxTeam];
+  size_t slots_off, maxcount;
+  unsigned long long *seq;     // host counter of exchanges, identical on all ranks
+  void (*signal)(hipStream_t s, unsigned long long seq, void *user);
+  void *user;
+};
 struct SytrdExchange {
   int nranks;
   // in-place sum over ALL ranks of the team of `count` doubles; bufs = the windows of the nmem
@@ -156,6 +169,8 @@ struct SytrdExchange {
   // members held by this process are the ranks rank0 .. rank0 + nmem - 1)
   void (*allgatherv)(hipStream_t s, int nmem, int rank0, double *const *bufs, const size_t *offs,
                      const size_t *counts, int nranks, void *user) = nullptr;
+  const PeerWindow *peer = nullptr;   // if set (and one member per process): the window exchange of the
+                                      // tridiagonalisation goes peer to peer instead of through allreduce
 };
 size_t sytrd_dist_work_bytes(int n, int nranks);
 void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, const SytrdExchange &x);

@@ -117,6 +117,27 @@ __device__ __forceinline__ int num_pieces(int s, int T, int q, int P = 1) {
   return (tile_start(s + 1, T, P) - 1) / q - tile_start(s, T, P) / q + 1;
 }
 
+// Where the exchange window of a distributed run lives.  Collective mode: one local array that an
+// all-reduce has summed in place.  Peer mode: every rank has stored its contribution straight into
+// a slot of every rank's receive area (xGMI stores from yreduce), and the reader sums the P slots
+// in rank order -- the same order on every rank, so the sums are bit-identical across the team.
+struct XWin {
+  const double *slot[kMaxTeam];   // slot[r]: rank r's contribution (peer mode); slot[0]: the summed window
+  int nslots;                     // P in peer mode, 1 in collective mode
+  __device__ __forceinline__ double get(size_t i) const {
+    double v = slot[0][i];
+    for (int r = 1; r < nslots; ++r) v += slot[r][i];
+    return v;
+  }
+};
+struct XDst {
+  double *slot[kMaxTeam];         // where this rank's contribution goes: its slot on every rank (peer
+  int nslots;                     // mode), or its own window (collective mode, nslots = 1)
+  __device__ __forceinline__ void put(size_t i, double v) const {
+    for (int d = 0; d < nslots; ++d) slot[d][i] = v;
+  }
+};
+
 struct ColupdArgs {
   int n, npad, lda, ldv;
   double *A, *V;          // V: explicit reflector matrix (may be null)
@@ -136,7 +157,7 @@ struct ColupdArgs {
   int i_new;              // finished panel columns once this launch is done (dots needed for them)
   // distributed run: the all-reduced exchange window of this column (rows r0 .. npad-1):
   // [0, xcnt) raw entries of column j, [xcnt, 2 xcnt) y = A22 x, [2 xcnt] x^T A x
-  const double *xch;
+  XWin xw;
   int xcnt;
 };
 
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
     const double *normp = p.b.normpart + (size_t)(jp & 1) * p.b.nch;
     for (int c = t; c < p.nchunks_p; c += 256) red3[0] += normp[c];
     if (DIST) {
-      if (t == 0) { red3[1] = p.xch[2 * (size_t)p.xcnt]; red3[2] = p.xch[(size_t)p.xcnt + (j - p.r0)]; }
+      if (t == 0) { red3[1] = p.xw.get(2 * (size_t)p.xcnt); red3[2] = p.xw.get((size_t)p.xcnt + (j - p.r0)); }
     } else {
       for (int u = t; u < p.nwg_p; u += 256) red3[1] += p.b.vavpart[u];
       const int nS = rbj - p.S0p + 1;
@@ -190,8 +211,8 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
     }
     const double alpha0 = p.b.scal[jp & 1];
     // still the panel-start value: A(:,j) is not written until column j is finalized
-    const double ajj = DIST ? p.xch[j - p.r0] : p.A[(size_t)j + (size_t)j * p.lda];
-    if (r >= j && r < p.n) a_old = DIST ? p.xch[r - p.r0] : p.A[(size_t)r + (size_t)j * p.lda];
+    const double ajj = DIST ? p.xw.get(j - p.r0) : p.A[(size_t)j + (size_t)j * p.lda];
+    if (r >= j && r < p.n) a_old = DIST ? p.xw.get(r - p.r0) : p.A[(size_t)r + (size_t)j * p.lda];
     block_sum_n<3>(red3, s_red);
     const Refl rf = reflector(red3[0], alpha0);
     const double corr = 1.0 - rf.scale * alpha0;
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
     if (r >= j && r < p.npad) {
       const int rb = r / TS;
       if (DIST) {
-        if (q == 0) y = p.xch[(size_t)p.xcnt + (r - p.r0)];
+        if (q == 0) y = p.xw.get((size_t)p.xcnt + (r - p.r0));
       } else {
         double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
         int S = p.S0p + q;
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(256) void colupd_kernel(ColupdArgs p) {
   const int j = p.j;
   double sq = 0.0, xr = 0.0;
   if (q == 0 && r >= j && r < p.n) {
-    if (!p.finalize) a_old = DIST ? p.xch[r - p.r0] : p.A[(size_t)r + (size_t)j * p.lda];
+    if (!p.finalize) a_old = DIST ? p.xw.get(r - p.r0) : p.A[(size_t)r + (size_t)j * p.lda];
     const double a = a_old - accB;   // the updated column lives in xbuf / d only
     if (r == j) { p.d[j] = a; p.b.xbuf[r] = 0.0; }
     else {
@@ -542,7 +563,7 @@ struct YredArgs {
   int own_next;      // this member owns the strip of column jn
   int with_y;        // 0 at a panel start: only the column part is filled
   int S0, P, T, q, nwg;   // the member's symv geometry of this column (nwg = 0: it had no tiles)
-  double *xch;
+  XDst xd;
 };
 
 constexpr int YR = 64;   // rows per yreduce workgroup (4 slices per row)
@@ -555,7 +576,7 @@ __global__ __launch_bounds__(256) void yreduce_kernel(YredArgs p) {
   if (q4 == 0 && r < p.npad) {
     double a = 0.0;
     if (p.jn >= 0 && p.own_next && r >= p.jn && r < p.n) a = p.A[(size_t)r + (size_t)p.jn * p.lda];
-    p.xch[r - p.r0] = a;
+    p.xd.put(r - p.r0, a);
   }
   if (!p.with_y) return;
   double y = 0.0;
@@ -580,12 +601,12 @@ __global__ __launch_bounds__(256) void yreduce_kernel(YredArgs p) {
   s_acc[q4][lane] = y;
   __syncthreads();
   if (q4 == 0 && r < p.npad)
-    p.xch[(size_t)p.cnt + (r - p.r0)] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+    p.xd.put((size_t)p.cnt + (r - p.r0), (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]));
   if (blockIdx.x == 0) {
     double v = 0.0;
     for (int u = t; u < p.nwg; u += 256) v += p.b.vavpart[u];
     const double tot = block_sum(v, s_red);
-    if (t == 0) p.xch[2 * (size_t)p.cnt] = tot;
+    if (t == 0) p.xd.put(2 * (size_t)p.cnt, tot);
   }
 }
 
@@ -845,16 +866,40 @@ void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, co
                        mem[m].lda, P, mem[m].rank, L.maxb, M.offs, M.dims);
     ColupdArgs &c = M.c; c = ColupdArgs{};
     c.n = n; c.npad = npad; c.lda = mem[m].lda; c.ldv = mem[m].ldv; c.A = mem[m].A; c.V = mem[m].V;
-    c.d = mem[m].d; c.e = mem[m].e; c.tau = mem[m].tau; c.b = b; c.NRB = NRB; c.xch = M.xch;
+    c.d = mem[m].d; c.e = mem[m].e; c.tau = mem[m].tau; c.b = b; c.NRB = NRB;
+    c.xw.slot[0] = M.xch; c.xw.nslots = 1;
     SymvArgs &sv = M.sv; sv = SymvArgs{};
     sv.n = n; sv.npad = npad; sv.lda = mem[m].lda; sv.A = mem[m].A; sv.b = b; sv.NRB = NRB; sv.P = P;
     YredArgs &yr = M.yr; yr = YredArgs{};
     yr.n = n; yr.npad = npad; yr.lda = mem[m].lda; yr.NRB = NRB; yr.A = mem[m].A; yr.b = b; yr.P = P;
-    yr.xch = M.xch;
+    yr.xd.slot[0] = M.xch; yr.xd.nslots = 1;
   }
   // exchange of the window of column jn (with or without the symv sums), then colupd on every member
+  const PeerWindow *pw_ = (nmem == 1) ? x.peer : nullptr;   // peer mode needs one member per process
   auto exchange = [&](int jn, bool with_y) {
     const int r0 = (jn / CR) * CR, cnt = npad - r0;
+    if (pw_) {
+      // peer mode: yreduce stores this rank's contribution into its slot on every rank; the command
+      // processors then raise this rank's sequence number in every peer's flag and wait for every
+      // peer's number in ours (stream-ordered memory operations: no collective kernel, no spinning
+      // wavefront); colupd sums the P slots.  Slots alternate with the parity of the sequence
+      // number: a peer can only be one exchange ahead, because its next contribution needs ours.
+      const PeerWindow &pw = *pw_;
+      const unsigned long long seq = ++*pw.seq;
+      const int par = (int)(seq & 1), me = pw.me;
+      YredArgs &yr = st[0].yr;
+      ColupdArgs &c = st[0].c;
+      yr.xd.nslots = P; c.xw.nslots = P;
+      for (int r = 0; r < P; ++r) {
+        yr.xd.slot[r] = (double *)(pw.base[r] + pw.slots_off) + ((size_t)me * 2 + par) * pw.maxcount;
+        c.xw.slot[r] = (const double *)(pw.base[me] + pw.slots_off) + ((size_t)r * 2 + par) * pw.maxcount;
+      }
+      yr.r0 = r0; yr.cnt = cnt; yr.jn = jn; yr.with_y = with_y ? 1 : 0;
+      yr.own_next = ((jn / TS) % P == mem[0].rank) ? 1 : 0;
+      hipLaunchKernelGGL(yreduce_kernel, dim3(ceil_div(cnt, YR)), dim3(256), 0, s, yr);
+      pw.signal(s, seq, pw.user);
+      return cnt;
+    }
     for (int m = 0; m < nmem; ++m) {
       YredArgs &yr = st[m].yr;
       yr.r0 = r0; yr.cnt = cnt; yr.jn = jn; yr.with_y = with_y ? 1 : 0;

@@ -78,6 +78,8 @@ def load_library(path=None):
         "ek_hip_comm_unique_id": (c_int, [vp, c_int]),
         "ek_hip_comm_init": (c_int, [vp, c_int, c_int, c_int]),
         "ek_hip_comm_attach_host": (c_int, [c_int, c_int]),
+        "ek_hip_comm_peer_enable": (c_int, [c_int]),
+        "ek_hip_comm_peer_disable": (c_int, []),
         "ek_hip_comm_size": (c_int, []),
         "ek_hip_comm_rank": (c_int, []),
         "ek_hip_comm_destroy": (c_int, []),
@@ -128,6 +130,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_sytrd_team", "ek_hip_comm_unique_id", "ek_hip_comm_init", "ek_hip_comm_size", "ek_hip_comm_rank",
     "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device", "ek_hip_debug_sytrd_team", "ek_hip_sygst_team",
     "ek_hip_potrf_team", "ek_hip_debug_reduce_team", "ek_hip_comm_attach_host",
+    "ek_hip_comm_peer_enable", "ek_hip_comm_peer_disable",
 )
 
 

@@ -158,6 +158,15 @@ int ek_hip_comm_init(const void *id, int bytes, int nranks, int rank);
  * RCCL-capable fabric, and for multi-process tests that share one GPU.  Every exchange drains
  * the stream and crosses PCIe twice -- a compatibility path.  -998 if no hook is registered. */
 int ek_hip_comm_attach_host(int nranks, int rank);
+/* Peer windows (optional, collective): the per-column exchange of the distributed PDSYTRD without a
+ * collective kernel.  Every rank allocates a receive area in its HBM, the ranks map each other's
+ * areas (hipIpc handles carried by the communicator), and from then on a column's contribution is
+ * stored by the producing kernel straight into every peer's area over xGMI and announced with
+ * stream memory operations (hipStreamBatchMemOp: write my sequence number on every peer, wait for
+ * every peer's number here).  n_max = largest order solved while enabled.  The all-gather and the
+ * broadcasts of the other distributed stages keep using the communicator. */
+int ek_hip_comm_peer_enable(int n_max);
+int ek_hip_comm_peer_disable(void);
 int ek_hip_comm_size(void);                     /* 0 when none is attached */
 int ek_hip_comm_rank(void);                     /* -1 when none is attached */
 int ek_hip_comm_destroy(void);

@@ -312,6 +312,18 @@ def _mp_worker(rank, world, port, q):
             res[solver_name] = (ep.values.copy(), cols, ep.Vectors[:, :len(cols)].copy())
             say(solver_name + " done")
         out["solve"] = res
+        # (4) the same tridiagonalisation and whole path with PEER WINDOWS: contributions stored
+        # straight into the other processes' HBM (hipIpc), announced by stream memory operations
+        assert lib.ek_hip_comm_peer_enable(n) == 0
+        Ar2, dd2, ee2, tau2, info, _ = sv.sytrd_team(A, 0)
+        assert info == 0
+        out["sytrd_peer"] = (dd2.copy(), ee2.copy(), tau2.copy(), np.tril(Ar2))
+        proc = sv.Process(rank, world, 0, 1, world, 0, rank)
+        ep, _ = sv.eigen_solver("general_hip", A, B, proc=proc)
+        cols = d.local_indices(n, int(ep.desc[d.BLOCK_ROW_]), rank, world)
+        out["solve_peer"] = (ep.values.copy(), ep.Vectors[:, :len(cols)].copy())
+        assert lib.ek_hip_comm_peer_disable() == 0
+        say("peer windows done")
         sv.comm_destroy()
         q.put((rank, out, None))
         dist.barrier()
@@ -368,6 +380,12 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
     assert np.array_equal(dd, outs[0]["sytrd"][0]) and np.array_equal(ee, outs[0]["sytrd"][1])
     assert np.array_equal(tau, outs[0]["sytrd"][2]) and np.array_equal(np.tril(Ar), outs[0]["sytrd"][3])
     _check_against_single(hip, oracle, A, outs[0]["sytrd"][3], *outs[0]["sytrd"][:3])
+    # peer windows: the very same bits as through the collective
+    for o in outs:
+        for a, b in zip(o["sytrd"], o["sytrd_peer"]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(o["solve"]["general_hip"][0], o["solve_peer"][0])
+        assert np.array_equal(o["solve"]["general_hip"][2], o["solve_peer"][1])
     # potrf: the complete factor on every process
     for o in outs[1:]:
         assert np.array_equal(outs[0]["potrf"], o["potrf"])
