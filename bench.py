@@ -163,6 +163,36 @@ def grid_probe(args, lib, solver, dist, torch, dev, rank, world, n, problem, n_v
         res.update({"seconds_per_solve": t, "eigenpairs_per_s": n_vec / t,
                     "tflops_equiv": flops(problem, n, n_vec) / t / 1e12, "scaling": "strong",
                     "stage_seconds_rank0": {lib.ek_hip_stage_name(i).decode(): stage[i] for i in range(8)}})
+        w_collective = dw.cpu().numpy().copy()
+        # the same solve with PEER WINDOWS for the per-column exchange (contributions stored straight
+        # into the peers' HBM over xGMI, one command-processor wait per column instead of a collective)
+        try:
+            rc = lib.ek_hip_comm_peer_enable(n)
+            if rc != 0:
+                raise RuntimeError("ek_hip_comm_peer_enable: %d" % rc)
+            ptimes = []
+            for it in range(2):
+                regenerate(0)
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                info = lib.ek_hip_solve_device_grid(problem, n, n_vec, dA.data_ptr(), n,
+                                                    dB.data_ptr() if dB is not None else None, n,
+                                                    dw.data_ptr(), dZ.data_ptr(), n, NB, 1, world, 0, rank, stage, 8)
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                ptimes.append(time.perf_counter() - t0)
+                if info != 0:
+                    raise RuntimeError("ek_hip_solve_device_grid (peer windows) info=%d" % info)
+            tp = torch.tensor([ptimes[-1]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            same = bool((dw.cpu().numpy() == w_collective).all())
+            st = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(st, op=dist.ReduceOp.MIN)
+            res["peer_windows"] = {"seconds_per_solve": float(tp.item()), "eigenpairs_per_s": n_vec / float(tp.item()),
+                                   "stage_seconds_rank0": {lib.ek_hip_stage_name(i).decode(): stage[i] for i in range(8)},
+                                   "eigenvalues_bit_identical_to_collective_path": bool(st.item() > 0.5)}
+        except Exception as exc:
+            res["peer_windows"] = {"error": repr(exc)}
+        lib.ek_hip_comm_peer_disable()
         # parity of this rank's eigenpairs (reference's acceptance quantities, on the GPU)
         w = dw.cpu().numpy()
         ok = bool((w[1:n_vec] >= w[:n_vec - 1]).all())

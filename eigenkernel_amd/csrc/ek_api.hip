@@ -251,12 +251,9 @@ constexpr size_t kPeerFlagBytes = 256;    // kMaxTeam 64-bit flags, padded
 
 void peer_signal(hipStream_t s, unsigned long long seq, void *) {
   const PeerWindow &w = g_peer.win;
-  hipError_t e = hipSuccess;
-  for (int r = 0; r < w.nranks && e == hipSuccess; ++r)      // my number into my flag on every peer
-    if (r != w.me) e = hipStreamWriteValue64(s, w.base[r] + 8 * (size_t)w.me, seq, 0);
-  for (int r = 0; r < w.nranks && e == hipSuccess; ++r)      // every peer's number in my area
-    if (r != w.me)
-      e = hipStreamWaitValue64(s, w.base[w.me] + 8 * (size_t)r, seq, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull);
+  if (w.nranks <= 1) return;
+  const hipError_t e = hipStreamWaitValue64(s, w.base[w.me], seq * (unsigned long long)(w.nranks - 1),
+                                            hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull);
   if (e != hipSuccess && !g_comm.err) g_comm.err = (int)ncclSystemError;
 }
 
@@ -266,6 +263,7 @@ void peer_teardown() {
   for (int r = 0; r < g_peer.win.nranks; ++r)
     if (r != g_peer.win.me && g_peer.opened[r]) (void)hipIpcCloseMemHandle(g_peer.win.base[r]);
   if (g_peer.win.base[g_peer.win.me]) (void)hipFree(g_peer.win.base[g_peer.win.me]);
+  if (g_peer.win.done) (void)hipFree(g_peer.win.done);
   g_peer = PeerX{};
 }
 
@@ -862,6 +860,8 @@ int ek_hip_comm_peer_enable(int n_max) {
   EK_HIP_CHECK(hipMemset(mine, 0, g_peer.bytes));
   EK_HIP_CHECK(hipDeviceSynchronize());
   w.base[me] = mine;
+  EK_HIP_CHECK(hipMalloc((void **)&w.done, 256));
+  EK_HIP_CHECK(hipMemset(w.done, 0, 256));
   // 64-byte handles, carried as 8 doubles per rank through the communicator's all-gather
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
   hipIpcMemHandle_t hs[kMaxTeam];

@@ -146,14 +146,18 @@ struct SytrdMember {
   int rank;
 };
 // Peer mode of the per-column exchange: every rank owns a receive area in its HBM
-//   [flags: one 64-bit sequence number per source rank | slots: nranks x 2 x maxcount doubles]
-// that all ranks have mapped (base[r], hipIpc across processes).  signal() enqueues, on the
-// stream, "write seq into my flag on every peer, then wait until every peer's flag here is >= seq"
-// (stream memory operations executed by the command processor).
+//   [arrival counter (64 bit) | slots: nranks x 2 x maxcount doubles]
+// that all ranks have mapped (base[r], hipIpc across processes).  The producing kernel stores the
+// rank's contribution into its slot on every rank and its last workgroup bumps every peer's arrival
+// counter; signal() enqueues, on the stream, ONE wait "my arrival counter >= seq * (nranks - 1)"
+// executed by the command processor (hipStreamWaitValue64), after which the consumer kernel sums the
+// slots.  (A sender raises counters only after all its stores of that exchange are visible
+// system-wide, so early arrivals of a faster peer's next exchange cannot expose missing data.)
 struct PeerWindow {
   int nranks, me;
   char *base[kMaxTeam];
   size_t slots_off, maxcount;
+  unsigned int *done;          // device: workgroups-done counter of the producing kernel
   unsigned long long *seq;     // host counter of exchanges, identical on all ranks
   void (*signal)(hipStream_t s, unsigned long long seq, void *user);
   void *user;

@@ -133,8 +133,29 @@ struct XWin {
 struct XDst {
   double *slot[kMaxTeam];         // where this rank's contribution goes: its slot on every rank (peer
   int nslots;                     // mode), or its own window (collective mode, nslots = 1)
+  // peer mode: arrival counters of the other ranks (null for this rank itself and in collective
+  // mode) and this rank's local "workgroups done" counter
+  unsigned long long *ctr[kMaxTeam];
+  unsigned int *done;
   __device__ __forceinline__ void put(size_t i, double v) const {
     for (int d = 0; d < nslots; ++d) slot[d][i] = v;
+  }
+  // Called by every thread at the end of the producing kernel.  The last workgroup to finish, after
+  // every workgroup's stores have been fenced system-wide, adds 1 to each peer's arrival counter
+  // (a remote atomic over xGMI); the peer's stream waits for P-1 such arrivals per exchange.
+  __device__ __forceinline__ void announce() const {
+    if (!done) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned prev = atomicAdd(done, 1u);
+      if (prev == gridDim.x - 1) {
+        *done = 0;                       // the next producer launch is stream-ordered after this one
+        __threadfence_system();
+        for (int d = 0; d < nslots; ++d)
+          if (ctr[d]) __hip_atomic_fetch_add(ctr[d], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 };
 
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(256) void yreduce_kernel(YredArgs p) {
     if (p.jn >= 0 && p.own_next && r >= p.jn && r < p.n) a = p.A[(size_t)r + (size_t)p.jn * p.lda];
     p.xd.put(r - p.r0, a);
   }
-  if (!p.with_y) return;
+  if (!p.with_y) { p.xd.announce(); return; }
   double y = 0.0;
   if (p.nwg > 0 && r < p.npad && r >= p.jn) {
     const int rb = r / TS;
@@ -608,6 +629,7 @@ __global__ __launch_bounds__(256) void yreduce_kernel(YredArgs p) {
     const double tot = block_sum(v, s_red);
     if (t == 0) p.xd.put(2 * (size_t)p.cnt, tot);
   }
+  p.xd.announce();
 }
 
 // Rehearsal exchange for a team held by ONE process on one GPU: sum of the members' windows in
@@ -890,8 +912,10 @@ void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, co
       YredArgs &yr = st[0].yr;
       ColupdArgs &c = st[0].c;
       yr.xd.nslots = P; c.xw.nslots = P;
+      yr.xd.done = pw.done;
       for (int r = 0; r < P; ++r) {
         yr.xd.slot[r] = (double *)(pw.base[r] + pw.slots_off) + ((size_t)me * 2 + par) * pw.maxcount;
+        yr.xd.ctr[r] = (r == me) ? nullptr : (unsigned long long *)pw.base[r];
         c.xw.slot[r] = (const double *)(pw.base[me] + pw.slots_off) + ((size_t)r * 2 + par) * pw.maxcount;
       }
       yr.r0 = r0; yr.cnt = cnt; yr.jn = jn; yr.with_y = with_y ? 1 : 0;

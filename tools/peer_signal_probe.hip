@@ -78,6 +78,43 @@ static int run(int me, int rd, int wr, int kind, int rounds) {
   // both sides ready
   char c = 1;
   if (write(wr, &c, 1) != 1 || read(rd, &c, 1) != 1) return 2;
+  // (b) the exchange as the library does it: ONE handshake per round, payload slots alternating
+  // with the parity of the round; host enqueue time measured apart from completion
+  {
+    const int n2 = 2048;
+    double *my_slots = (double *)(mine + 4096), *peer_slots = (double *)(peer + 4096);
+    const auto tb0 = std::chrono::steady_clock::now();
+    for (int r = 1; r <= rounds; ++r) {
+      const int par = r & 1;
+      hipLaunchKernelGGL(push_kernel, dim3(n2 / 256), dim3(256), 0, s, peer_slots + par * n2, (double)(7000 * r + me), n2);
+      CK(hipStreamWriteValue64(s, peer + 16, (uint64_t)r, 0));
+      CK(hipStreamWaitValue64(s, mine + 16, (uint64_t)r, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+      hipLaunchKernelGGL(check_kernel, dim3(n2 / 256), dim3(256), 0, s, (const double *)(my_slots + par * n2),
+                         (double)(7000 * r + (1 - me)), n2, bad);
+    }
+    const double t_enq = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
+    if (!wait_stream(s, 20.0)) { fprintf(stderr, "[%d] kind %d: one-handshake loop stuck\n", me, kind); _exit(3); }
+    const double t_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
+    int hb = -1;
+    CK(hipMemcpy(&hb, bad, sizeof(int), hipMemcpyDeviceToHost));
+    printf("[%d] kind %d one handshake per round (2 kernels, 1 write, 1 wait): %.2f us per round, host enqueue %.2f us per round, %d bad\n",
+           me, kind, 1e6 * t_all / rounds, 1e6 * t_enq / rounds, hb);
+    // (c) is the batched form accepted for these addresses?
+    hipStreamBatchMemOpParams ops[2];
+    memset(ops, 0, sizeof(ops));
+    ops[0].operation = hipStreamMemOpWriteValue64;
+    ops[0].writeValue.address = (hipDeviceptr_t)(peer + 24);
+    ops[0].writeValue.value64 = 1;
+    ops[1].operation = hipStreamMemOpWaitValue64;
+    ops[1].waitValue.address = (hipDeviceptr_t)(mine + 24);
+    ops[1].waitValue.value64 = 1;
+    ops[1].waitValue.flags = hipStreamWaitValueGte;
+    hipError_t eb = hipStreamBatchMemOp(s, 2, ops, 0);
+    printf("[%d] kind %d hipStreamBatchMemOp(write peer, wait mine): %s\n", me, kind, hipGetErrorString(eb));
+    (void)hipGetLastError();
+    if (eb == hipSuccess && !wait_stream(s, 10.0)) { fprintf(stderr, "[%d] batch stuck\n", me); _exit(3); }
+    fflush(stdout);
+  }
   const auto t0 = std::chrono::steady_clock::now();
   for (int r = 1; r <= rounds; ++r) {
     // my payload for this round into the peer's region, then raise my number in the peer's flag
