@@ -503,3 +503,30 @@ def test_four_processes_on_a_2x2_grid(hip, oracle, inputs):
     if inputs == "distributed":      # B_loc came back as the pieces of L
         L = np.tril(d.assemble_global({(o[0], o[1]): o[5] for o in outs}, n, n, nb, nprow, npcol))
         assert np.abs(L @ L.T - B).max() <= 16 * n * EPS * np.abs(B).max()
+
+
+def test_peer_windows_need_a_communicator(hip):
+    lib = hip.load_library()
+    assert lib.ek_hip_comm_size() == 0
+    assert lib.ek_hip_comm_peer_enable(128) == -995
+    assert lib.ek_hip_comm_peer_disable() == 0       # nothing to release: still fine
+
+
+def test_peer_windows_with_one_rank_over_rccl(hip, oracle, comm1):
+    """A team of one has no peers: the window is this rank's own receive area, no wait is issued,
+    and the result is the collective path's bit for bit; enabling twice / disabling twice is legal."""
+    lib = comm1
+    A = oracle.synth_matrix(700, 1)
+    ref = hip.sytrd_team(A, 0)
+    assert ref[4] == 0
+    assert lib.ek_hip_comm_peer_enable(700) == 0
+    assert lib.ek_hip_comm_peer_enable(1024) == 0
+    got = hip.sytrd_team(A, 0)
+    assert got[4] == 0
+    for a, b in zip(ref[1:4], got[1:4]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(np.tril(ref[0]), np.tril(got[0]))
+    assert lib.ek_hip_comm_peer_disable() == 0
+    assert lib.ek_hip_comm_peer_disable() == 0
+    again = hip.sytrd_team(A, 0)
+    assert np.array_equal(again[1], ref[1])
