@@ -530,3 +530,21 @@ def test_peer_windows_with_one_rank_over_rccl(hip, oracle, comm1):
     assert lib.ek_hip_comm_peer_disable() == 0
     again = hip.sytrd_team(A, 0)
     assert np.array_equal(again[1], ref[1])
+
+
+@pytest.mark.parametrize("n,P", [(4096, 8), (5000, 3), (6144, 5)])
+def test_sytrd_team_large_orders(hip, oracle, n, P):
+    """Many strips per rank (T = 32 .. 48): the strip-stride tile enumeration at sizes the small
+    cases do not reach.  Checked without an O(n^3) CPU step: the ranks agree bit for bit, and the
+    spectrum of T equals that of the single-GPU tridiagonalisation of the same matrix."""
+    from scipy.linalg import eigvalsh_tridiagonal
+    A = oracle.synth_matrix(n, 1)
+    Ar, d, e, tau, info, mismatch = hip.sytrd_team(A, P)
+    assert info == 0 and mismatch == 0
+    Ar1, d1, e1, tau1, info1 = hip.sytrd(A)
+    assert info1 == 0
+    w = eigvalsh_tridiagonal(d, e)
+    w1 = eigvalsh_tridiagonal(d1, e1)
+    assert np.abs(w - w1).max() <= 8 * n * EPS * np.abs(w1).max()
+    assert abs(d.sum() - np.trace(A)) <= 8 * n * EPS * np.abs(np.diag(A)).sum()
+    assert np.isfinite(Ar).all() and np.abs(tau).max() <= 2.0 + 1e-12
