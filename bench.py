@@ -115,7 +115,20 @@ def emit(out):
         print(json.dumps(out), flush=True)
 
 
-def grid_probe(args, lib, solver, dist, torch, dev, rank, world, n, problem, n_vec, dA, dB, dZ, dw, regenerate):
+def attach_communicator(solver, dist, rank, world, rehearse):
+    """The library's communicator: RCCL from an id made on rank 0 and carried by torch.distributed,
+    or (one-GPU rehearsal) the host communicator over torch.distributed itself."""
+    if rehearse:
+        solver.set_allgatherv(solver.torch_allgatherv(dist))
+        solver.comm_attach_host(world, rank)
+        return
+    uid = [solver.comm_unique_id() if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(uid, src=0)
+    solver.comm_init(uid[0], world, rank)
+
+
+def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, problem, n_vec, dA, dB, dZ, dw, regenerate):
     """ONE problem on the 1 x world grid with the library's RCCL communicator attached
     (tridiagonalisation distributed: one ncclAllReduce per Householder column; eigenvector stages
     column-sharded).  Measured after, and outside, the headline region; a watchdog abandons it
@@ -139,9 +152,7 @@ def grid_probe(args, lib, solver, dist, torch, dev, rank, world, n, problem, n_v
     try:
         # the headline line is complete before the probe starts: keep it for the watchdog
         threading.Thread(target=watchdog, daemon=True).start()
-        uid = [solver.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        solver.comm_init(uid[0], world, rank)
+        attach_communicator(solver, dist, rank, world, args.rehearse_on_one_gpu)
         my_cols = dsc.local_indices(n_vec, NB, rank, world)
         nc_loc = len(my_cols)
         stage = (ctypes.c_double * 8)()
@@ -157,7 +168,7 @@ def grid_probe(args, lib, solver, dist, torch, dev, rank, world, n, problem, n_v
             times.append(time.perf_counter() - t0)
             if info != 0:
                 raise RuntimeError("ek_hip_solve_device_grid info=%d" % info)
-        tt = torch.tensor([times[-1]], dtype=torch.float64, device=dev)
+        tt = torch.tensor([times[-1]], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
         res.update({"seconds_per_solve": t, "eigenpairs_per_s": n_vec / t,
@@ -182,10 +193,10 @@ def grid_probe(args, lib, solver, dist, torch, dev, rank, world, n, problem, n_v
                 ptimes.append(time.perf_counter() - t0)
                 if info != 0:
                     raise RuntimeError("ek_hip_solve_device_grid (peer windows) info=%d" % info)
-            tp = torch.tensor([ptimes[-1]], dtype=torch.float64, device=dev)
+            tp = torch.tensor([ptimes[-1]], dtype=torch.float64, device=cdev)
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
             same = bool((dw.cpu().numpy() == w_collective).all())
-            st = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev)
+            st = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=cdev)
             dist.all_reduce(st, op=dist.ReduceOp.MIN)
             res["peer_windows"] = {"seconds_per_solve": float(tp.item()), "eigenpairs_per_s": n_vec / float(tp.item()),
                                    "stage_seconds_rank0": {lib.ek_hip_stage_name(i).decode(): stage[i] for i in range(8)},
@@ -207,10 +218,10 @@ def grid_probe(args, lib, solver, dist, torch, dev, rank, world, n, problem, n_v
                                                   dZ.data_ptr(), n, ctypes.byref(orth))
             ok = ok and rc1 == 0 and rc2 == 0 and mx.value <= 1e-14 * max(1.0, (n / 1024.0) ** 0.5) and orth.value <= 1e-11
             res["parity_rank0"] = {"residual_norm_max": mx.value, "orthogonality": orth.value}
-        okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         res["parity_ok_all_ranks"] = bool(okt.item() > 0.5)
-        wt = torch.from_numpy(w.copy()).to(dev)
+        wt = torch.from_numpy(w.copy()).to(cdev)
         wmax = wt.clone(); wmin = wt.clone()
         dist.all_reduce(wmax, op=dist.ReduceOp.MAX); dist.all_reduce(wmin, op=dist.ReduceOp.MIN)
         res["eigenvalues_identical_on_all_ranks"] = bool(torch.equal(wmax, wmin))
@@ -256,6 +267,10 @@ def main():
     ap.add_argument("--force-grid-probe", action="store_true",
                     help="run the grid probe at world size 1 too (rehearsal of the code path on a one-GPU box; "
                          "needs a torch.distributed launch)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 ranks that all use GPU 0 (a pool box has one): gloo process group, collective "
+                         "tensors on the CPU, the library's HOST communicator instead of RCCL (which refuses two "
+                         "ranks on one device).  Exercises the whole N>1 control flow; the timings mean nothing")
     ap.add_argument("--grid-probe-timeout", type=float, default=240.0,
                     help="seconds after which a stuck grid probe is abandoned (the main line is still printed)")
     args = ap.parse_args()
@@ -269,11 +284,17 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the product path has no CPU fallback")
+    rehearse = args.rehearse_on_one_gpu
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:   # launched by torch.distributed.run
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == world
 
     from eigenkernel_amd import solver
@@ -283,6 +304,7 @@ def main():
         raise RuntimeError("ek_hip_init(%d) failed: %d" % (local_rank, rc))
 
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else dev      # where the collectives' tensors live
     # Device-resident operands (torch only owns the memory; the library does all the work).
     # The solve overwrites A and B (as PDSYTRD / PDPOTRF do), so every timed step gets its own
     # pre-generated copy of the inputs: 288 GB of HBM holds them easily and the timed region
@@ -292,11 +314,7 @@ def main():
     dBs = [torch.empty((n, n), dtype=torch.float64, device=dev) for _ in range(K)] if problem == 1 else None
     columns = args.distribution in ("columns", "grid")
     if args.distribution == "grid":
-        # RCCL communicator inside the library: rank 0 makes the id, torch.distributed carries it
-        uid = [solver.comm_unique_id() if rank == 0 else None]
-        if dist is not None:
-            dist.broadcast_object_list(uid, src=0)
-        solver.comm_init(uid[0], world, rank)
+        attach_communicator(solver, dist, rank, world, rehearse)
     NB = 64                                        # g_block_size (global_variables.f90:5)
     if columns:
         from eigenkernel_amd import descriptor as dsc
@@ -351,7 +369,7 @@ def main():
     barrier()
     total = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([total], dtype=torch.float64, device=dev)
+        tt = torch.tensor([total], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         total = float(tt.item())
 
@@ -439,7 +457,7 @@ def main():
         _pending = out
     if ((world > 1 or args.force_grid_probe) and dist is not None and args.distribution == "replicas"
             and not args.no_grid_probe):
-        probe = grid_probe(args, lib, solver, dist, torch, dev, rank, world, n, problem, n_vec,
+        probe = grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, problem, n_vec,
                            dAs[0], dBs[0] if problem == 1 else None, dZ, dw, regenerate)
         if out is not None:
             out["grid_probe"] = probe
