@@ -137,8 +137,10 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
     import threading
     from eigenkernel_amd import descriptor as dsc
     NB = 64
-    res = {"distribution": "1 x %d process grid, replicated inputs; PDSYTRD distributed over RCCL "
-                           "(1 all-reduce/column), eigenvector columns sharded" % world}
+    res = {"distribution": "1 x %d process grid, replicated inputs; PDPOTRF/PDSYGST (from 3 ranks on) and PDSYTRD "
+                           "distributed over %s (1 all-reduce/column), eigenvector columns sharded"
+                           % (world, "the HOST communicator (one-GPU rehearsal: timings mean nothing)"
+                              if args.rehearse_on_one_gpu else "RCCL")}
     done = threading.Event()
 
     def watchdog():
