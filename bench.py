@@ -10,12 +10,17 @@ timed region, because the solve overwrites A and B as the reference does).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--order 16384] [--problem gep|sep]
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; by default every
-rank solves its own problem (replicas: independent problems sharded over ranks, no data-path
-collective, "scaling": "weak").  `--distribution columns` instead solves ONE problem on a
-1 x N process grid in replicated-input mode (reduction replicated on every rank, eigenvector
-columns sharded; still no collective; "scaling": "strong").  Distributing the reduction
-itself over the grid with RCCL is the remaining part of SURVEY.md 8(e), see DESIGN.md.
+For N > 1 the driver launches one rank per GPU with torch.distributed.run.  By default
+(`--distribution auto`) the ranks first solve one problem each (replicas: no data-path collective;
+the safe measurement, kept in the line as "replicas"), then ONE problem on the 1 x N process grid
+with the library's RCCL communicator attached -- Cholesky factor, reduction and tridiagonalisation
+distributed over the ranks (one exchange per Householder column), eigenvector stages sharded by
+columns -- once with the per-column exchange as an ncclAllReduce and once with peer windows, each to
+the full contract (W warm-up solves, exactly K solves between barriers, max over ranks, parity
+checked on every rank).  The faster distributed mode that passed becomes the headline
+("scaling": "strong", value = n_vec * K / time: the eigenpairs of the one problem all ranks worked
+on); if neither passes (or an exchange hangs: a watchdog abandons it) the replicas line is the
+headline ("scaling": "weak").  `--distribution replicas | columns | grid` force one mode.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline"     : the dominant kernel (symv of the tridiagonalisation, HBM-bound), timed
@@ -128,19 +133,25 @@ def attach_communicator(solver, dist, rank, world, rehearse):
     solver.comm_init(uid[0], world, rank)
 
 
-def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, problem, n_vec, dA, dB, dZ, dw, regenerate):
-    """ONE problem on the 1 x world grid with the library's RCCL communicator attached
-    (tridiagonalisation distributed: one ncclAllReduce per Householder column; eigenvector stages
-    column-sharded).  Measured after, and outside, the headline region; a watchdog abandons it
-    (os._exit after printing the headline) if a collective never returns, since a pool box has a
-    single GPU and this path can only be rehearsed there."""
+def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, problem, n_vec, dAs, dBs, dZ, dw, regenerate):
+    """ONE problem on the 1 x world grid with the library's communicator attached (Cholesky factor and
+    reduction from three ranks on, tridiagonalisation always: distributed; eigenvector stages
+    column-sharded), measured to the same contract as the headline (W warm-up solves, then exactly K
+    solves between barriers, max over ranks) once per exchange mode:
+      "collective"   : one ncclAllReduce per Householder column,
+      "peer_windows" : contributions stored straight into the peers' HBM, one command-processor wait.
+    Runs after the replicas region; a watchdog abandons it (os._exit after printing the line that
+    exists by then) if an exchange never returns: a pool box has a single GPU, so this path could
+    only be rehearsed there (team rehearsal, RCCL with one rank, processes sharing the GPU)."""
     import threading
     from eigenkernel_amd import descriptor as dsc
     NB = 64
+    K, W = args.steps, max(1, args.warmup)
     res = {"distribution": "1 x %d process grid, replicated inputs; PDPOTRF/PDSYGST (from 3 ranks on) and PDSYTRD "
-                           "distributed over %s (1 all-reduce/column), eigenvector columns sharded"
+                           "distributed over %s, eigenvector columns sharded"
                            % (world, "the HOST communicator (one-GPU rehearsal: timings mean nothing)"
-                              if args.rehearse_on_one_gpu else "RCCL")}
+                              if args.rehearse_on_one_gpu else "RCCL / xGMI"),
+           "steps": K, "warmup": W, "modes": {}}
     done = threading.Event()
 
     def watchdog():
@@ -151,87 +162,137 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
                 emit(_pending)
             sys.stdout.flush()
             os._exit(0)
-    try:
-        # the headline line is complete before the probe starts: keep it for the watchdog
-        threading.Thread(target=watchdog, daemon=True).start()
-        attach_communicator(solver, dist, rank, world, args.rehearse_on_one_gpu)
-        my_cols = dsc.local_indices(n_vec, NB, rank, world)
-        nc_loc = len(my_cols)
-        stage = (ctypes.c_double * 8)()
-        times = []
-        for it in range(2):                       # 1 warm-up + 1 timed solve
-            regenerate(0)
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            info = lib.ek_hip_solve_device_grid(problem, n, n_vec, dA.data_ptr(), n,
-                                                dB.data_ptr() if dB is not None else None, n,
-                                                dw.data_ptr(), dZ.data_ptr(), n, NB, 1, world, 0, rank, stage, 8)
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-            times.append(time.perf_counter() - t0)
-            if info != 0:
-                raise RuntimeError("ek_hip_solve_device_grid info=%d" % info)
-        tt = torch.tensor([times[-1]], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t = float(tt.item())
-        res.update({"seconds_per_solve": t, "eigenpairs_per_s": n_vec / t,
-                    "tflops_equiv": flops(problem, n, n_vec) / t / 1e12, "scaling": "strong",
-                    "stage_seconds_rank0": {lib.ek_hip_stage_name(i).decode(): stage[i] for i in range(8)}})
-        w_collective = dw.cpu().numpy().copy()
-        # the same solve with PEER WINDOWS for the per-column exchange (contributions stored straight
-        # into the peers' HBM over xGMI, one command-processor wait per column instead of a collective)
-        try:
+
+    def sync():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    def allreduce(value, op):
+        t = torch.tensor([value], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    my_cols = dsc.local_indices(n_vec, NB, rank, world)
+    nc_loc = len(my_cols)
+    stage = (ctypes.c_double * 8)()
+
+    def solve(i):
+        info = lib.ek_hip_solve_device_grid(problem, n, n_vec, dAs[i].data_ptr(), n,
+                                            dBs[i].data_ptr() if dBs is not None else None, n,
+                                            dw.data_ptr(), dZ.data_ptr(), n, NB, 1, world, 0, rank, stage, 8)
+        if info != 0:
+            raise RuntimeError("ek_hip_solve_device_grid info=%d" % info)
+
+    def measure(mode):
+        m = {}
+        if mode == "peer_windows":
             rc = lib.ek_hip_comm_peer_enable(n)
             if rc != 0:
                 raise RuntimeError("ek_hip_comm_peer_enable: %d" % rc)
-            ptimes = []
-            for it in range(2):
-                regenerate(0)
-                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                info = lib.ek_hip_solve_device_grid(problem, n, n_vec, dA.data_ptr(), n,
-                                                    dB.data_ptr() if dB is not None else None, n,
-                                                    dw.data_ptr(), dZ.data_ptr(), n, NB, 1, world, 0, rank, stage, 8)
-                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-                ptimes.append(time.perf_counter() - t0)
-                if info != 0:
-                    raise RuntimeError("ek_hip_solve_device_grid (peer windows) info=%d" % info)
-            tp = torch.tensor([ptimes[-1]], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-            same = bool((dw.cpu().numpy() == w_collective).all())
-            st = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=cdev)
-            dist.all_reduce(st, op=dist.ReduceOp.MIN)
-            res["peer_windows"] = {"seconds_per_solve": float(tp.item()), "eigenpairs_per_s": n_vec / float(tp.item()),
-                                   "stage_seconds_rank0": {lib.ek_hip_stage_name(i).decode(): stage[i] for i in range(8)},
-                                   "eigenvalues_bit_identical_to_collective_path": bool(st.item() > 0.5)}
-        except Exception as exc:
-            res["peer_windows"] = {"error": repr(exc)}
-        lib.ek_hip_comm_peer_disable()
-        # parity of this rank's eigenpairs (reference's acceptance quantities, on the GPU)
+        for _ in range(W):
+            regenerate(0)
+            solve(0)
+        for i in range(K):
+            regenerate(i)
+        stage_sum = [0.0] * 8
+        if not args.no_symv_events:
+            lib.ek_hip_profile_symv(max(1, args.symv_events_stride))
+        sync()
+        t0 = time.perf_counter()
+        for i in range(K):
+            solve(i)
+            for q in range(8):
+                stage_sum[q] += stage[q]
+        sync()
+        total = allreduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
+        sv_s, sv_l, sv_b = ctypes.c_double(0), ctypes.c_longlong(0), ctypes.c_double(0)
+        if not args.no_symv_events:
+            lib.ek_hip_profile_symv_get(ctypes.byref(sv_s), ctypes.byref(sv_l), ctypes.byref(sv_b))
+            lib.ek_hip_profile_symv(0)
+        m.update({"ms_per_step": 1e3 * total / K, "value": n_vec * K / total, "unit": "eigenpairs/s",
+                  "tflops_equiv": flops(problem, n, n_vec) * K / total / 1e12, "scaling": "strong",
+                  "stage_seconds_per_step_rank0": {lib.ek_hip_stage_name(q).decode(): stage_sum[q] / K for q in range(8)}})
+        if sv_l.value > 0 and sv_s.value > 0:
+            ach = sv_b.value / sv_s.value / 1e9
+            m["roofline"] = {"kernel": "symv_kernel<DIST> on rank 0 (its 1/%d share of the lower triangle per column)" % world,
+                             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": sv_l.value,
+                             "timed_every_kth_column": max(1, args.symv_events_stride),
+                             "avg_launch_us": 1e6 * sv_s.value / sv_l.value,
+                             "algorithmic_bytes_per_launch": sv_b.value / sv_l.value}
+        # parity of every rank's eigenpairs (the reference's acceptance quantities, on the GPU)
         w = dw.cpu().numpy()
         ok = bool((w[1:n_vec] >= w[:n_vec - 1]).all())
         if nc_loc > 0:
             regenerate(0)
             an, ave, mx, orth = (ctypes.c_double(0) for _ in range(4))
             dwc = torch.from_numpy(np.ascontiguousarray(w[my_cols])).to(dev)
-            rc1 = lib.ek_hip_residual_device(problem, n, nc_loc, dA.data_ptr(), n,
-                                             dB.data_ptr() if dB is not None else None, n, dwc.data_ptr(),
+            rc1 = lib.ek_hip_residual_device(problem, n, nc_loc, dAs[0].data_ptr(), n,
+                                             dBs[0].data_ptr() if dBs is not None else None, n, dwc.data_ptr(),
                                              dZ.data_ptr(), n, ctypes.byref(an), ctypes.byref(ave), ctypes.byref(mx))
-            rc2 = lib.ek_hip_orthogonality_device(problem, n, 1, nc_loc, dB.data_ptr() if dB is not None else None, n,
-                                                  dZ.data_ptr(), n, ctypes.byref(orth))
-            ok = ok and rc1 == 0 and rc2 == 0 and mx.value <= 1e-14 * max(1.0, (n / 1024.0) ** 0.5) and orth.value <= 1e-11
-            res["parity_rank0"] = {"residual_norm_max": mx.value, "orthogonality": orth.value}
-        okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=cdev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        res["parity_ok_all_ranks"] = bool(okt.item() > 0.5)
+            rc2 = lib.ek_hip_orthogonality_device(problem, n, 1, nc_loc, dBs[0].data_ptr() if dBs is not None else None,
+                                                  n, dZ.data_ptr(), n, ctypes.byref(orth))
+            bound = 1e-14 * max(1.0, (n / 1024.0) ** 0.5)
+            ok = ok and rc1 == 0 and rc2 == 0 and mx.value <= bound and orth.value <= 1e-11
+            m["parity_rank0"] = {"A_norm": an.value, "residual_norm_average": ave.value, "residual_norm_max": mx.value,
+                                 "orthogonality": orth.value,
+                                 "bounds": {"residual_norm_max": bound, "orthogonality": 1e-11}}
+        m["parity_ok_all_ranks"] = allreduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
         wt = torch.from_numpy(w.copy()).to(cdev)
         wmax = wt.clone(); wmin = wt.clone()
         dist.all_reduce(wmax, op=dist.ReduceOp.MAX); dist.all_reduce(wmin, op=dist.ReduceOp.MIN)
-        res["eigenvalues_identical_on_all_ranks"] = bool(torch.equal(wmax, wmin))
+        m["eigenvalues_identical_on_all_ranks"] = bool(torch.equal(wmax, wmin))
+        if mode == "peer_windows":
+            lib.ek_hip_comm_peer_disable()
+        return m, w.copy()
+
+    try:
+        threading.Thread(target=watchdog, daemon=True).start()
+        attach_communicator(solver, dist, rank, world, args.rehearse_on_one_gpu)
+        w_first = None
+        for mode in ("collective", "peer_windows"):
+            try:
+                m, w = measure(mode)
+                if w_first is None:
+                    w_first = w
+                else:
+                    same = allreduce(1.0 if bool((w == w_first).all()) else 0.0, dist.ReduceOp.MIN) > 0.5
+                    m["eigenvalues_bit_identical_to_collective_path"] = same
+                res["modes"][mode] = m
+            except Exception as exc:          # ranks fail alike (collective calls): record and go on
+                res["modes"][mode] = {"error": repr(exc)}
+                if mode == "peer_windows":
+                    lib.ek_hip_comm_peer_disable()
         solver.comm_destroy()
-    except Exception as exc:   # the probe never takes the headline down
+    except Exception as exc:   # the probe never takes the line down
         res["error"] = repr(exc)
     done.set()
     return res
+
+
+def promote_grid_mode(out, probe, world):
+    """--distribution auto: the faster distributed mode that passed parity on every rank becomes the
+    headline; the replicas measurement stays in the line as "replicas"."""
+    good = {k: m for k, m in probe.get("modes", {}).items()
+            if "error" not in m and m.get("parity_ok_all_ranks") and m.get("eigenvalues_identical_on_all_ranks")}
+    if not good:
+        return
+    mode = max(good, key=lambda k: good[k]["value"])
+    m = good[mode]
+    out["replicas"] = {k: out[k] for k in ("value", "unit", "ms_per_step", "scaling", "tflops_equiv",
+                                           "stage_seconds_per_step", "parity", "roofline") if k in out}
+    out["replicas"]["config_parallelism"] = out["config"]["parallelism"]
+    out["value"] = m["value"]
+    out["ms_per_step"] = m["ms_per_step"]
+    out["scaling"] = "strong"
+    out["tflops_equiv"] = m["tflops_equiv"]
+    out["stage_seconds_per_step"] = m["stage_seconds_per_step_rank0"]
+    out["parity"] = m.get("parity_rank0")
+    out["roofline"] = m.get("roofline")
+    out["config"]["workload"] = out["config"]["workload"].replace("1 problem per GPU", "ONE problem on all GPUs")
+    out["config"]["parallelism"] = ("1 x %d process grid over RCCL/xGMI, replicated inputs: Cholesky factor, reduction and "
+                                    "tridiagonalisation distributed (1 x P block-cyclic, 128-wide blocks; per-column "
+                                    "exchange: %s), eigenvector stages sharded by columns" % (world, mode))
+    out["headline_mode"] = mode
 
 
 def main():
@@ -247,8 +308,13 @@ def main():
                     help="order of the CPU-oracle sample (scalar C port, 1 core)")
     ap.add_argument("--scalapack-sample-n", type=int, default=4096,
                     help="order of the ScaLAPACK-path sample (all physical cores)")
-    ap.add_argument("--distribution", choices=["replicas", "columns", "grid"], default="replicas",
-                    help="N>1 GPUs: 'replicas' = one independent problem per rank (weak scaling, default); "
+    ap.add_argument("--distribution", choices=["auto", "replicas", "columns", "grid"], default="auto",
+                    help="N>1 GPUs: 'auto' (default) = measure replicas first (one independent problem per rank: "
+                         "the safe line), then ONE problem distributed over the 1 x N grid in both exchange modes "
+                         "(the 'grid_probe'), and report the faster distributed mode that passed the parity check on "
+                         "every rank as the headline (\"scaling\": \"strong\"), the replicas numbers beside it; if "
+                         "neither did, the replicas line is the headline.  "
+                         "'replicas' = one independent problem per rank (weak scaling) as the headline; "
                          "'columns' = ONE problem on a 1 x N process grid in replicated-input mode "
                          "(ek_hip_solve_device_grid: reduction replicated, eigenvector columns sharded; strong scaling); "
                          "'grid' = the same with the library's RCCL communicator attached: the tridiagonalisation is "
@@ -314,7 +380,7 @@ def main():
     K = args.steps
     dAs = [torch.empty((n, n), dtype=torch.float64, device=dev) for _ in range(K)]
     dBs = [torch.empty((n, n), dtype=torch.float64, device=dev) for _ in range(K)] if problem == 1 else None
-    columns = args.distribution in ("columns", "grid")
+    columns = args.distribution in ("columns", "grid")     # "auto" and "replicas": one problem per rank first
     if args.distribution == "grid":
         attach_communicator(solver, dist, rank, world, rehearse)
     NB = 64                                        # g_block_size (global_variables.f90:5)
@@ -457,12 +523,14 @@ def main():
             base = cpu_baseline_scalapack(problem, args.scalapack_sample_n)
             out["cpu_baseline"] = base if base is not None else cpu_baseline(problem, args.cpu_sample_n)
         _pending = out
-    if ((world > 1 or args.force_grid_probe) and dist is not None and args.distribution == "replicas"
+    if ((world > 1 or args.force_grid_probe) and dist is not None and args.distribution in ("auto", "replicas")
             and not args.no_grid_probe):
         probe = grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, problem, n_vec,
-                           dAs[0], dBs[0] if problem == 1 else None, dZ, dw, regenerate)
+                           dAs, dBs, dZ, dw, regenerate)
         if out is not None:
             out["grid_probe"] = probe
+            if args.distribution == "auto":
+                promote_grid_mode(out, probe, world)
     if out is not None:
         emit(out)
     if args.distribution == "grid":
