@@ -533,6 +533,11 @@ def main():
                 promote_grid_mode(out, probe, world)
     if out is not None:
         emit(out)
+    if world > 1:
+        # the line is out: no closing barrier (a rank whose probe failed differently from its
+        # peers' must not wait for them), no tear-down of the GPU runtime and the process-group threads
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
     if args.distribution == "grid":
         solver.comm_destroy()
     if dist is not None:
