@@ -324,6 +324,24 @@ def _mp_worker(rank, world, port, q):
         out["solve_peer"] = (ep.values.copy(), ep.Vectors[:, :len(cols)].copy())
         assert lib.ek_hip_comm_peer_disable() == 0
         say("peer windows done")
+        # (5) failures are reported alike on every rank: a B that is not positive definite (the
+        # failing block column belongs to rank 1) and a NaN in A
+        Bbad = B.copy(); Bbad[150, 150] = -1.0
+        proc = sv.Process(rank, world, 0, 1, world, 0, rank)
+        try:
+            sv.eigen_solver("general_hip", A, Bbad, proc=proc)
+            out["info_bad_B"] = 0
+        except sv.SolverError as exc:
+            out["info_bad_B"] = exc.info
+        Anan = A.copy(); Anan[3, 2] = np.nan; Anan[2, 3] = np.nan
+        try:
+            sv.eigen_solver("general_hip", Anan, B, proc=proc)
+            out["info_nan_A"] = 0
+        except sv.SolverError as exc:
+            out["info_nan_A"] = exc.info
+        # and the team is still usable afterwards
+        ep, _ = sv.eigen_solver("hip", A, proc=proc)
+        out["w_after"] = ep.values.copy()
         sv.comm_destroy()
         q.put((rank, out, None))
         dist.barrier()
@@ -386,6 +404,9 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
             assert np.array_equal(a, b)
         assert np.array_equal(o["solve"]["general_hip"][0], o["solve_peer"][0])
         assert np.array_equal(o["solve"]["general_hip"][2], o["solve_peer"][1])
+    for o in outs:
+        assert o["info_bad_B"] == 151 and o["info_nan_A"] == -4
+        assert np.array_equal(o["w_after"], outs[0]["solve"]["hip"][0])
     # potrf: the complete factor on every process
     for o in outs[1:]:
         assert np.array_equal(outs[0]["potrf"], o["potrf"])
