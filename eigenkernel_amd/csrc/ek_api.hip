@@ -23,6 +23,7 @@ struct Context {
   bool ready = false;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // look-ahead work (panel chain of the Cholesky factorisation)
   // cached device workspace (grown on demand, never shrunk until finalize)
   void *ws = nullptr;
   size_t ws_bytes = 0;
@@ -41,6 +42,7 @@ int ensure_init() {
   }
   EK_HIP_CHECK(hipSetDevice(g_ctx.device));
   EK_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  EK_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream2, hipStreamNonBlocking));
   EK_HIP_CHECK(hipMalloc((void **)&g_ctx.d_info, 64 * sizeof(int)));
   g_ctx.ready = true;
   return 0;
@@ -181,6 +183,8 @@ void rccl_allgatherv(hipStream_t s, int nmem, int, double *const *bufs, const si
   if (r == ncclSuccess) r = r2;
   if (r != ncclSuccess && !g_comm.err) g_comm.err = (int)r;
 }
+
+constexpr int kPotrfRlMin = 1024;
 
 // From how many ranks on the Cholesky factor and the reduction to standard form are distributed
 // as well (below that their replicated forms are cheaper); EK_HIP_DIST_MIN_RANKS overrides (tests).
@@ -481,16 +485,19 @@ int ek_hip_potrf(int n, double *B_loc, const int desc_B[9]) {
   hipStream_t s = g_ctx.stream;
   const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
   void *ws;
+  const size_t rlb = al(potrf_rl_work_bytes(n, ld));
   rc = workspace(al((size_t)ld * n * 8) + al((size_t)nblk * kDiagNB * kDiagNB * 8) +
-                 al((size_t)128 * ld * 8), &ws);
+                 al((size_t)128 * ld * 8) + rlb, &ws);
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
   double *dB = a.get<double>((size_t)ld * n);
   double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
   double *work = a.get<double>((size_t)128 * ld);
+  char *rlwork = a.get<char>(rlb);
   rc = h2d_matrix(n, n, B_loc, desc_B[8], dB, ld, s); if (rc) return rc;
   EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, sizeof(int), s));
-  potrf_lower(s, n, dB, ld, dInv, g_ctx.d_info, work);
+  if (n >= kPotrfRlMin) potrf_lower_rl(s, g_ctx.stream2, n, dB, ld, dInv, g_ctx.d_info, rlwork);
+  else potrf_lower(s, n, dB, ld, dInv, g_ctx.d_info, work);
   EK_HIP_CHECK(hipGetLastError());
   rc = d2h_matrix(n, n, dB, ld, B_loc, desc_B[8], s); if (rc) return rc;
   int info = 0;
@@ -1220,7 +1227,10 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     if (dd > sygst_dbl) sygst_dbl = dd;
   }
   const size_t sygst_scr = al(sygst_dbl * 8);
-  const size_t potrf_wb = (problem == 1 && dist) ? al(potrf_dist_work_bytes(n, ld, g_comm.nranks)) : 0;
+  // right-looking Cholesky with look-ahead from this order on (below it the recursion is as fast)
+  const bool potrf_rl = problem == 1 && n >= kPotrfRlMin;
+  size_t potrf_wb = (problem == 1 && dist) ? al(potrf_dist_work_bytes(n, ld, g_comm.nranks)) : 0;
+  if (potrf_rl && al(potrf_rl_work_bytes(n, ld)) > potrf_wb) potrf_wb = al(potrf_rl_work_bytes(n, ld));
   int rc = 0;
   rc = workspace(4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
                      4 * al((size_t)ld * 8) + sygst_scr + potrf_wb, &ws);
@@ -1279,6 +1289,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     if (dist && g_comm.nranks >= dist_min_ranks()) {
       const PotrfMember me{wB, ld, dInv, g_ctx.d_info, pwork, g_comm.rank};
       potrf_lower_dist(s, n, 1, &me, team_exchange(0));
+    } else if (potrf_rl) {
+      potrf_lower_rl(s, g_ctx.stream2, n, wB, ld, dInv, g_ctx.d_info, pwork);
     } else {
       potrf_lower(s, n, wB, ld, dInv, g_ctx.d_info, twork);
     }

@@ -502,6 +502,79 @@ void potrf_lower_dist(hipStream_t s, int n, int nmem, const PotrfMember *mem, co
     hipLaunchKernelGGL(first_info_kernel, dim3(1), dim3(64), 0, s, NRB, infod[m], mem[m].d_info);
 }
 
+// Single-GPU right-looking Cholesky with look-ahead: the chain "factor + invert the 128x128 diagonal
+// block in LDS (one workgroup, ~0.2 ms), solve the panel below it" of block column k+1 runs on a
+// second stream while the first stream is still applying block column k to the rest of the
+// matrix, so the latency-bound chain (a third of the recursive form's time) hides behind the GEMMs.
+size_t potrf_rl_work_bytes(int n, int ld) { return PotrfDistLayout(n, ld, 1).total; }
+
+void potrf_lower_rl(hipStream_t s, hipStream_t s2, int n, double *B, int ldb, double *invdiag, int *d_info,
+                    void *work) {
+  set_attrs();
+  if (n <= 0) return;
+  const PotrfDistLayout Ly(n, ldb, 1);
+  const int NRB = Ly.NRB;
+  char *w = (char *)work;
+  double *ppan = (double *)(w + Ly.off_pbuf);
+  int *infos = (int *)(w + Ly.off_infos);
+  double *infod = (double *)(w + Ly.off_infod);
+  long long *offs = (long long *)(w + Ly.off_offs);
+  int *dims = (int *)(w + Ly.off_dims);
+  static hipEvent_t evU[2], evP[2], evFork;
+  static bool ev_ready = false;
+  if (!ev_ready) {
+    for (int i = 0; i < 2; ++i) {
+      (void)hipEventCreateWithFlags(&evU[i], hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&evP[i], hipEventDisableTiming);
+    }
+    (void)hipEventCreateWithFlags(&evFork, hipEventDisableTiming);
+    ev_ready = true;
+  }
+  (void)hipMemsetAsync(infos, 0, (size_t)NRB * sizeof(int), s);
+  hipLaunchKernelGGL(potrf_table_kernel, dim3(NRB), dim3(round_up(Ly.maxb, 64)), 0, s, n, ldb, 1, 0, NRB, Ly.maxb,
+                     offs, dims);
+  auto factor_panel = [&](hipStream_t st, int k) {
+    const int off = k * NB, nbk = (n - off < NB) ? n - off : NB, mrows = n - off - nbk;
+    double *Bd = B + (size_t)off + (size_t)off * ldb;
+    double *inv = invdiag + (size_t)k * NB * NB;
+    hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), (NB * NB + NB) * sizeof(double), st, nbk, Bd,
+                       ldb, inv, infos + k, off);
+    if (mrows > 0) {
+      gemm(st, false, true, mrows, nbk, nbk, 1.0, Bd + nbk, ldb, inv, NB, 0.0, ppan, mrows);
+      copy_matrix(st, mrows, nbk, ppan, mrows, Bd + nbk, ldb);
+    }
+  };
+  (void)hipEventRecord(evFork, s);
+  (void)hipStreamWaitEvent(s2, evFork, 0);
+  factor_panel(s2, 0);
+  (void)hipEventRecord(evP[0], s2);
+  for (int k = 0; k + 1 < NRB; ++k) {
+    const int nbk = (n - k * NB < NB) ? n - k * NB : NB;
+    (void)hipStreamWaitEvent(s, evP[k & 1], 0);                 // block column k is factored
+    GemmDesc g{};
+    g.N = NB; g.K = nbk; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
+    g.A = B; g.lda = ldb; g.B = B; g.ldb = ldb; g.C = B; g.ldc = ldb; g.lower_only = true;
+    const long long *po = offs + (size_t)k * Ly.maxb * 3;
+    const int *pd = dims + (size_t)k * Ly.maxb * 3;
+    // block column k+1 first, so that its factorisation can start ...
+    g.M = n - (k + 1) * NB; g.batch = 1; g.d_offs = po; g.d_dims = pd;
+    gemm(s, g);
+    (void)hipEventRecord(evU[(k + 1) & 1], s);
+    (void)hipStreamWaitEvent(s2, evU[(k + 1) & 1], 0);
+    factor_panel(s2, k + 1);
+    (void)hipEventRecord(evP[(k + 1) & 1], s2);
+    // ... while block column k is applied to the block columns behind it
+    const int rest = NRB - (k + 2);
+    if (rest > 0) {
+      g.M = n - (k + 2) * NB; g.batch = rest; g.d_offs = po + 3; g.d_dims = pd + 3;
+      gemm(s, g);
+    }
+  }
+  (void)hipStreamWaitEvent(s, evP[(NRB - 1) & 1], 0);
+  hipLaunchKernelGGL(info_to_double_kernel, dim3(ceil_div(NRB, 256)), dim3(256), 0, s, NRB, infos, infod);
+  hipLaunchKernelGGL(first_info_kernel, dim3(1), dim3(64), 0, s, NRB, infod, d_info);
+}
+
 size_t sygst_dist_scratch_doubles(int n, int ld, int nranks) {
   const int NRB = ceil_div(n > 0 ? n : 1, NB);
   return (size_t)ld * NB * ceil_div(NRB, nranks > 0 ? nranks : 1);

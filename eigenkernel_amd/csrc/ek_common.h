@@ -106,6 +106,11 @@ struct SygstMember {
   double *scratch;
   int rank;
 };
+// Right-looking form with look-ahead on a second stream (single GPU): same results contract as
+// potrf_lower; work: >= potrf_rl_work_bytes(n, ldb).
+size_t potrf_rl_work_bytes(int n, int ld);
+void potrf_lower_rl(hipStream_t s, hipStream_t s2, int n, double *B, int ldb, double *invdiag, int *d_info,
+                    void *work);
 struct SytrdExchange;
 // Distributed Cholesky (PDPOTRF on a 1 x P grid, 128-wide column blocks, right-looking): the owner
 // of strip k factors its diagonal block in LDS, solves the panel below it and broadcasts

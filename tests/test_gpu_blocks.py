@@ -54,7 +54,7 @@ def test_dgemm_lower_only(hip):
     assert np.array_equal(got[:128, 256:], C[:128, 256:])
 
 
-@pytest.mark.parametrize("n", [1, 5, 64, 128, 129, 300, 640, 1000])
+@pytest.mark.parametrize("n", [1, 5, 64, 128, 129, 300, 640, 1000, 1024, 1500, 2177])   # >= 1024: look-ahead form
 def test_potrf_matches_oracle(hip, oracle, n):
     B = oracle.synth_matrix(n, 2)
     L_or, info_or = oracle.potrf_lower(B)
@@ -63,6 +63,15 @@ def test_potrf_matches_oracle(hip, oracle, n):
     L = np.tril(got)
     assert np.abs(L - np.tril(L_or)).max() <= 8 * n * EPS * np.abs(L_or).max()
     assert np.abs(L @ L.T - B).max() <= 8 * n * EPS * np.abs(B).max()
+
+
+def test_potrf_lookahead_reports_first_bad_pivot(hip, oracle):
+    n = 1300
+    B = oracle.synth_matrix(n, 2)
+    B[700, 700] = -1.0
+    B[1100, 1100] = -1.0
+    _, info = hip.potrf(B)
+    assert info == 701
 
 
 def test_potrf_reports_first_bad_pivot(hip, oracle):
