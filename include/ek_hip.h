@@ -23,7 +23,9 @@
  *     ek_hip_solve*: -4 also when A contains NaN/Inf; 100000 + k = the tridiagonal eigensolver
  *     failed (k <= n: QL iteration of the leaf containing row k; k = n+1: non-finite eigenvalue);
  *   - SPMD: called once, collectively, by the single main thread of every rank
- *     (main.f90:100-104).  This round implements the 1x1 grid (one GPU); a call with
+ *     (main.f90:100-104), one rank per GPU.  Grids larger than 1x1 need a way to exchange data:
+ *     the RCCL communicator (ek_hip_comm_init), the host communicator (ek_hip_comm_attach_host)
+ *     or at least the all-gather hook (ek_hip_set_allgatherv); without any, a call with
  *     nprow*npcol != 1 returns the negative index of the offending argument.
  *   - there is no CPU fallback anywhere behind this interface.
  */

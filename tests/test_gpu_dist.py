@@ -569,3 +569,17 @@ def test_sytrd_team_large_orders(hip, oracle, n, P):
     assert np.abs(w - w1).max() <= 8 * n * EPS * np.abs(w1).max()
     assert abs(d.sum() - np.trace(A)) <= 8 * n * EPS * np.abs(np.diag(A)).sum()
     assert np.isfinite(Ar).all() and np.abs(tau).max() <= 2.0 + 1e-12
+
+
+@pytest.mark.parametrize("argv", [["1500", "2", "2", "1", "1"], ["900", "1", "3", "0", "0"], ["700", "2", "1", "1", "1"]])
+def test_plain_c_host_with_forked_ranks(hip, argv):
+    """host/ek_ranks_demo.c: an MPI-shaped C program that uses nothing but include/ek_hip.h -- forked
+    ranks on a process grid, the all-gather hook over shared memory, host communicator, peer windows,
+    ek_hip_solve on block-cyclic pieces; it checks its own eigenpairs and exits non-zero otherwise."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "ek_ranks_demo")
+    assert os.path.exists(exe), "build it with `make -C host` (or __graft_entry__.build())"
+    out = subprocess.run(["timeout", "-k", "5", "120", exe] + argv, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "max |A z - lambda B z|" in out.stdout
