@@ -159,6 +159,11 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
             sys.stderr.write("[bench] grid probe abandoned after %.0f s on rank %d\n" % (args.grid_probe_timeout, rank))
             if rank == 0 and _pending is not None:
                 _pending["grid_probe"] = dict(res, error="timeout")
+                if args.distribution == "auto":      # a mode that had finished and passed still counts
+                    try:
+                        promote_grid_mode(_pending, res, world)
+                    except Exception:
+                        pass
                 emit(_pending)
             sys.stdout.flush()
             os._exit(0)
