@@ -862,43 +862,58 @@ int ek_hip_comm_peer_enable(int n_max) {
   w.maxcount = 2 * (size_t)pad_ld(n_max) + 8;
   w.seq = &g_peer.seq; w.signal = peer_signal; w.user = nullptr;
   g_peer.bytes = kPeerFlagBytes + (size_t)P * 2 * w.maxcount * sizeof(double);
-  char *mine = nullptr;
-  EK_HIP_CHECK(hipExtMallocWithFlags((void **)&mine, g_peer.bytes, hipDeviceMallocFinegrained));
-  EK_HIP_CHECK(hipMemset(mine, 0, g_peer.bytes));
-  EK_HIP_CHECK(hipDeviceSynchronize());
-  w.base[me] = mine;
-  EK_HIP_CHECK(hipMalloc((void **)&w.done, 256));
-  EK_HIP_CHECK(hipMemset(w.done, 0, 256));
-  // 64-byte handles, carried as 8 doubles per rank through the communicator's all-gather
+  // A rank whose local step fails keeps taking part in the exchanges below and says so in its
+  // status word, so that all ranks give up together (-993) instead of waiting for each other.
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
-  hipIpcMemHandle_t hs[kMaxTeam];
-  memset(hs, 0, sizeof(hs));
+  constexpr int kRec = 9;                    // doubles per rank: 8 = the 64-byte handle, 1 = status
+  double rec[kMaxTeam * kRec];
+  memset(rec, 0, sizeof(rec));
+  bool ok = true;
+  char *mine = nullptr;
+  ok = ok && hipExtMallocWithFlags((void **)&mine, g_peer.bytes, hipDeviceMallocFinegrained) == hipSuccess;
+  ok = ok && hipMemset(mine, 0, g_peer.bytes) == hipSuccess;
+  ok = ok && hipMalloc((void **)&w.done, 256) == hipSuccess && hipMemset(w.done, 0, 256) == hipSuccess;
+  ok = ok && hipDeviceSynchronize() == hipSuccess;
+  w.base[me] = mine;
+  if (ok && P > 1) {
+    hipIpcMemHandle_t h;
+    ok = hipIpcGetMemHandle(&h, mine) == hipSuccess;
+    if (ok) memcpy(&rec[me * kRec], &h, sizeof(h));
+  }
+  rec[me * kRec + 8] = ok ? 0.0 : 1.0;
+  (void)hipGetLastError();
   double *dh = nullptr;
   DevMem mem;
-  rc = mem.alloc(&dh, sizeof(hs));
-  if (rc) return rc;
-  if (P > 1) {
-    EK_HIP_CHECK(hipIpcGetMemHandle(&hs[me], mine));
-    EK_HIP_CHECK(hipMemcpy(dh, hs, sizeof(hs), hipMemcpyHostToDevice));
-    size_t offs[kMaxTeam], counts[kMaxTeam];
-    for (int r = 0; r < P; ++r) { offs[r] = (size_t)r * 8; counts[r] = 8; }
+  rc = mem.alloc(&dh, sizeof(rec));
+  if (rc) { peer_teardown(); return rc; }
+  size_t offs[kMaxTeam], counts[kMaxTeam];
+  for (int r = 0; r < P; ++r) { offs[r] = (size_t)r * kRec; counts[r] = kRec; }
+  double *bufs[1] = {dh};
+  const SytrdExchange x = team_exchange(0);
+  auto exchange_status = [&]() -> int {     // everyone's record; returns the number of ranks that failed, or < 0
+    if (hipMemcpy(dh, rec, sizeof(rec), hipMemcpyHostToDevice) != hipSuccess) return -1;
     g_comm.err = 0;
-    double *bufs[1] = {dh};
-    const SytrdExchange x = team_exchange(0);
-    x.allgatherv(s, 1, me, bufs, offs, counts, P, x.user);
-    EK_HIP_CHECK(hipStreamSynchronize(s));
-    if (g_comm.err) return -996;
-    EK_HIP_CHECK(hipMemcpy(hs, dh, sizeof(hs), hipMemcpyDeviceToHost));
-    for (int r = 0; r < P; ++r) {
-      if (r == me) continue;
-      EK_HIP_CHECK(hipIpcOpenMemHandle((void **)&w.base[r], hs[r], hipIpcMemLazyEnablePeerAccess));
-      g_peer.opened[r] = true;
-    }
-    // nobody stores into a peer before every rank has mapped every area: one more round trip
-    x.allgatherv(s, 1, me, bufs, offs, counts, P, x.user);
-    EK_HIP_CHECK(hipStreamSynchronize(s));
-    if (g_comm.err) return -996;
+    if (P > 1) x.allgatherv(s, 1, me, bufs, offs, counts, P, x.user);
+    if (hipStreamSynchronize(s) != hipSuccess || g_comm.err) return -1;
+    if (hipMemcpy(rec, dh, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int bad = 0;
+    for (int r = 0; r < P; ++r) if (rec[r * kRec + 8] != 0.0) ++bad;
+    return bad;
+  };
+  int bad = exchange_status();
+  if (bad != 0) { peer_teardown(); return bad < 0 ? -996 : -993; }
+  for (int r = 0; r < P && ok; ++r) {
+    if (r == me) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, &rec[r * kRec], sizeof(h));
+    ok = hipIpcOpenMemHandle((void **)&w.base[r], h, hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+    if (ok) g_peer.opened[r] = true;
   }
+  (void)hipGetLastError();
+  // nobody stores into a peer before every rank has mapped every area -- and has said so
+  rec[me * kRec + 8] = ok ? 0.0 : 1.0;
+  bad = exchange_status();
+  if (bad != 0) { peer_teardown(); return bad < 0 ? -996 : -993; }
   g_peer.seq = 0;
   g_peer.on = true;
   return 0;

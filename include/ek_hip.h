@@ -166,7 +166,9 @@ int ek_hip_comm_attach_host(int nranks, int rank);
  * stored by the producing kernel straight into every peer's area over xGMI and announced with
  * stream memory operations (hipStreamBatchMemOp: write my sequence number on every peer, wait for
  * every peer's number here).  n_max = largest order solved while enabled.  The all-gather and the
- * broadcasts of the other distributed stages keep using the communicator. */
+ * broadcasts of the other distributed stages keep using the communicator.  Returns 0 on every rank
+ * or the same failure on every rank: -993 = some rank could not allocate, export or map an area
+ * (the ranks agree on it through the communicator, so nobody is left waiting), -995/-996 as above. */
 int ek_hip_comm_peer_enable(int n_max);
 int ek_hip_comm_peer_disable(void);
 int ek_hip_comm_size(void);                     /* 0 when none is attached */
