@@ -365,3 +365,38 @@ def test_gather_matrix_gloo_world2():
         p.join(120)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_bench_promotes_the_faster_distributed_mode_that_passed():
+    """bench.py --distribution auto: the replicas line stays the headline unless a distributed mode
+    finished with parity ok and identical eigenvalues on every rank; then the faster such mode is
+    the headline ("strong") and the replicas numbers move to "replicas"."""
+    import copy
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ek_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    base = {"metric": "m", "value": 70000.0, "unit": "eigenpairs/s", "n_gpus": 8, "steps": 2, "warmup": 1,
+            "ms_per_step": 1850.0, "scaling": "weak", "tflops_equiv": 130.0,
+            "stage_seconds_per_step": {"a": 1.0}, "parity": {"p": 1}, "roofline": {"frac": 0.67},
+            "config": {"workload": "N=16384 ..., full spectrum, 1 problem per GPU", "parallelism": "replicas x8"}}
+    good = {"ms_per_step": 800.0, "value": 20480.0, "tflops_equiv": 38.0, "stage_seconds_per_step_rank0": {"a": 0.5},
+            "parity_rank0": {"p": 2}, "roofline": {"frac": 0.3}, "parity_ok_all_ranks": True,
+            "eigenvalues_identical_on_all_ranks": True}
+    faster = dict(good, ms_per_step=700.0, value=23405.0)
+    # nothing usable: unchanged
+    out = copy.deepcopy(base)
+    bench.promote_grid_mode(out, {"modes": {"collective": {"error": "x"}, "peer_windows": dict(good, parity_ok_all_ranks=False)}}, 8)
+    assert out == base
+    # both passed: the faster one
+    out = copy.deepcopy(base)
+    bench.promote_grid_mode(out, {"modes": {"collective": good, "peer_windows": faster}}, 8)
+    assert out["headline_mode"] == "peer_windows" and out["scaling"] == "strong"
+    assert out["value"] == 23405.0 and out["ms_per_step"] == 700.0 and out["parity"] == {"p": 2}
+    assert out["replicas"]["value"] == 70000.0 and out["replicas"]["scaling"] == "weak"
+    assert "ONE problem on all GPUs" in out["config"]["workload"] and "peer_windows" in out["config"]["parallelism"]
+    assert out["metric"] == "m" and out["n_gpus"] == 8 and out["steps"] == 2
+    # only the collective passed
+    out = copy.deepcopy(base)
+    bench.promote_grid_mode(out, {"modes": {"collective": good, "peer_windows": {"error": "timeout"}}}, 8)
+    assert out["headline_mode"] == "collective" and out["value"] == 20480.0
