@@ -25,7 +25,8 @@ struct Context {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // look-ahead work (panel chain of the Cholesky factorisation)
   // cached device workspace (grown on demand, never shrunk until finalize)
-  void *ws = nullptr;
+  void *ws = nullptr;         // what the stages use (may sit inside a larger allocation, see place_workspace)
+  void *ws_alloc = nullptr;   // what hipFree gets
   size_t ws_bytes = 0;
   int *d_info = nullptr;
 };
@@ -50,9 +51,10 @@ int ensure_init() {
 
 int workspace(size_t bytes, void **p) {
   if (bytes > g_ctx.ws_bytes) {
-    if (g_ctx.ws) EK_HIP_CHECK(hipFree(g_ctx.ws));
-    g_ctx.ws = nullptr; g_ctx.ws_bytes = 0;
-    EK_HIP_CHECK(hipMalloc(&g_ctx.ws, bytes));
+    if (g_ctx.ws_alloc) EK_HIP_CHECK(hipFree(g_ctx.ws_alloc));
+    g_ctx.ws = nullptr; g_ctx.ws_alloc = nullptr; g_ctx.ws_bytes = 0;
+    EK_HIP_CHECK(hipMalloc(&g_ctx.ws_alloc, bytes));
+    g_ctx.ws = g_ctx.ws_alloc;
     g_ctx.ws_bytes = bytes;
   }
   *p = g_ctx.ws;
@@ -71,6 +73,70 @@ struct Arena {
   }
 };
 inline size_t al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+// Placement of a new whole-path workspace.  The HBM-bound symv of the tridiagonalisation runs
+// 1-3 % faster or slower depending on where in HBM the matrix it streams happens to land (DESIGN.md
+// section 5, "run-to-run spread, explained"): nothing about the address tells which.  On some boxes
+// successive allocations alternate between a fast and a slow region, on others the mode changes at
+// sharp multi-GiB boundaries and neighbouring allocations share it.  When the workspace has to grow,
+// two blocks with kPlaceSlack bytes to spare are therefore held at the same time, the first panel of
+// a tridiagonalisation of a synthetic matrix is timed with the arena shifted by 0, 2, 4, ... GiB
+// inside each (the same kernels on the same arrays, ~14 ms per position at N = 16384), and the
+// fastest position is kept; the other block is released.  One-off cost per workspace size and
+// 8 GiB of the 288; EK_HIP_PLACEMENT=0 turns it off.
+constexpr size_t kPlaceStep = (size_t)2 << 30, kPlaceSlack = (size_t)8 << 30;
+int place_workspace(size_t bytes, int n, int ld, size_t work_off) {
+  static int enabled = -1;
+  if (enabled < 0) { const char *e = getenv("EK_HIP_PLACEMENT"); enabled = e ? atoi(e) : 1; }
+  if (!enabled || n < 8192 || bytes > ((size_t)100 << 30)) return 0;      // plain workspace() takes over
+  hipStream_t s = g_ctx.stream;
+  if (g_ctx.ws_alloc) { EK_HIP_CHECK(hipFree(g_ctx.ws_alloc)); }
+  g_ctx.ws = nullptr; g_ctx.ws_alloc = nullptr; g_ctx.ws_bytes = 0;
+  hipEvent_t e0, e1;
+  EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
+  const int old_cols = sytrd_get_max_cols();
+  void *block[2] = {nullptr, nullptr};
+  double best = 1e30;
+  int best_blk = -1;
+  size_t best_off = 0;
+  char msg[512]; int mlen = 0;
+  msg[0] = 0;
+  for (int b = 0; b < 2; ++b) {
+    if (hipMalloc(&block[b], bytes + kPlaceSlack) != hipSuccess) { (void)hipGetLastError(); block[b] = nullptr; break; }
+    for (size_t off = 0; off <= kPlaceSlack; off += kPlaceStep) {
+      char *base = (char *)block[b] + off;
+      double *wA = (double *)base;
+      char *work = base + work_off;                                      // the stage scratch of the arena
+      double *dd = (double *)(base + bytes - 4 * al((size_t)ld * 8));    // any three vectors inside the arena
+      double *de = dd + ld, *dt = de + ld;
+      sytrd_set_max_cols(64);
+      for (int rep = 0; rep < 2; ++rep) {                                // first pass warms up, second is timed
+        (void)hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s);
+        synth_matrix(s, n, 1, wA, ld);
+        (void)hipEventRecord(e0, s);
+        sytrd_lower(s, n, wA, ld, dd, de, dt, nullptr, 0, work);
+        (void)hipEventRecord(e1, s);
+      }
+      sytrd_set_max_cols(old_cols);
+      float ms = 1e30f;
+      if (hipStreamSynchronize(s) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+      else (void)hipGetLastError();
+      if (mlen < 440) mlen += snprintf(msg + mlen, sizeof(msg) - mlen, "%s%.3f", off ? " " : (b ? " | " : ""), ms);
+      if (ms < best) { best = ms; best_blk = b; best_off = off; }
+    }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (best_blk < 0) {                                   // nothing could be allocated with slack
+    for (void *p : block) if (p) (void)hipFree(p);
+    return 0;                                           // workspace() allocates (or reports the failure)
+  }
+  if (block[1 - best_blk]) (void)hipFree(block[1 - best_blk]);
+  g_ctx.ws_alloc = block[best_blk]; g_ctx.ws = (char *)block[best_blk] + best_off; g_ctx.ws_bytes = bytes;
+  if (getenv("EK_HIP_PLACEMENT_VERBOSE"))
+    fprintf(stderr, "[ek_hip] workspace placement: probes in ms (two blocks, shifts of 2 GiB): %s -> block %d shift %zu GiB\n",
+            msg, best_blk, best_off >> 30);
+  return 0;
+}
 
 // device buffers of one host-array call: released on every exit path
 struct DevMem {
@@ -406,8 +472,8 @@ int ek_hip_finalize(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_ctx.ready) return 0;
   (void)hipStreamSynchronize(g_ctx.stream);
-  if (g_ctx.ws) (void)hipFree(g_ctx.ws);
-  g_ctx.ws = nullptr; g_ctx.ws_bytes = 0;
+  if (g_ctx.ws_alloc) (void)hipFree(g_ctx.ws_alloc);
+  g_ctx.ws = nullptr; g_ctx.ws_alloc = nullptr; g_ctx.ws_bytes = 0;
   return 0;
 }
 
@@ -1182,6 +1248,13 @@ int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds) {
   return g_comm.err ? -996 : 0;
 }
 
+// Tuning hook: the tridiagonalisation hooks stop after max_cols columns (-1 = all of them).
+int ek_hip_debug_set_sytrd_maxcols(int max_cols) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  sytrd_set_max_cols(max_cols);
+  return 0;
+}
+
 int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int ldm) {
   if (n < 0) return -1;
   if (ldm < (n > 1 ? n : 1)) return -4;
@@ -1247,8 +1320,13 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   size_t potrf_wb = (problem == 1 && dist) ? al(potrf_dist_work_bytes(n, ld, g_comm.nranks)) : 0;
   if (potrf_rl && al(potrf_rl_work_bytes(n, ld)) > potrf_wb) potrf_wb = al(potrf_rl_work_bytes(n, ld));
   int rc = 0;
-  rc = workspace(4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
-                     4 * al((size_t)ld * 8) + sygst_scr + potrf_wb, &ws);
+  const size_t ws_need = 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
+                         4 * al((size_t)ld * 8) + sygst_scr + potrf_wb;
+  if (ws_need > g_ctx.ws_bytes) {
+    rc = place_workspace(ws_need, n, ld, 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work);
+    if (rc) return rc;
+  }
+  rc = workspace(ws_need, &ws);
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
   double *wA = a.get<double>((size_t)ld * ld);

@@ -187,6 +187,8 @@ void sytrd_team_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t c
 void team_allgatherv(hipStream_t s, int nmem, int rank0, double *const *bufs, const size_t *offs,
                      const size_t *counts, int nranks, void *user);   // rehearsal: nmem == nranks
 
+void sytrd_set_max_cols(int max_cols);   // tuning hooks: stop after this many columns (-1 = all)
+int sytrd_get_max_cols();
 // instrumentation: HIP events around every symv launch (bench.py roofline line)
 void symv_profile_enable(int stride);   // 0 = off, k = time every k-th column's launch
 void symv_profile_collect(double *seconds, long long *launches, double *bytes);

@@ -702,7 +702,8 @@ struct Knobs {
     if (const char *e = getenv("EK_SYMV_G")) G = atoi(e);
   }
 };
-const Knobs &knobs() { static Knobs k; return k; }
+Knobs &knobs_rw() { static Knobs k; return k; }
+const Knobs &knobs() { return knobs_rw(); }
 
 struct Layout {
   int npad, NRB, nch;
@@ -1030,6 +1031,9 @@ void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, co
   for (int m = 0; m < nmem; ++m)
     hipLaunchKernelGGL(put_diag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, mem[m].A, mem[m].lda, mem[m].d);
 }
+
+void sytrd_set_max_cols(int max_cols) { knobs_rw().max_cols = max_cols; }   // tuning hooks only (-1 = all)
+int sytrd_get_max_cols() { return knobs().max_cols; }
 
 void symv_profile_enable(int stride) {
   g_prof.enabled = stride > 0;
