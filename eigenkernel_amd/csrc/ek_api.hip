@@ -84,10 +84,15 @@ inline size_t al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 // inside each (the same kernels on the same arrays, ~14 ms per position at N = 16384), and the
 // fastest position is kept; the other block is released.  One-off cost per workspace size and
 // 8 GiB of the 288; EK_HIP_PLACEMENT=0 turns it off.
-constexpr size_t kPlaceStep = (size_t)2 << 30, kPlaceSlack = (size_t)8 << 30;
 int place_workspace(size_t bytes, int n, int ld, size_t work_off) {
   static int enabled = -1;
-  if (enabled < 0) { const char *e = getenv("EK_HIP_PLACEMENT"); enabled = e ? atoi(e) : 1; }
+  static size_t kPlaceStep = (size_t)2 << 30, kPlaceSlack = (size_t)8 << 30;
+  if (enabled < 0) {
+    const char *e = getenv("EK_HIP_PLACEMENT"); enabled = e ? atoi(e) : 1;
+    if (const char *q = getenv("EK_HIP_PLACE_STEP_MB")) kPlaceStep = (size_t)atoi(q) << 20;     // exploration
+    if (const char *q = getenv("EK_HIP_PLACE_SLACK_GB")) kPlaceSlack = (size_t)atoi(q) << 30;
+    if (kPlaceStep < ((size_t)1 << 20)) kPlaceStep = (size_t)1 << 20;
+  }
   if (!enabled || n < 8192 || bytes > ((size_t)100 << 30)) return 0;      // plain workspace() takes over
   hipStream_t s = g_ctx.stream;
   if (g_ctx.ws_alloc) { EK_HIP_CHECK(hipFree(g_ctx.ws_alloc)); }
@@ -99,11 +104,14 @@ int place_workspace(size_t bytes, int n, int ld, size_t work_off) {
   double best = 1e30;
   int best_blk = -1;
   size_t best_off = 0;
-  char msg[512]; int mlen = 0;
+  char msg[2048]; int mlen = 0;
   msg[0] = 0;
   for (int b = 0; b < 2; ++b) {
     if (hipMalloc(&block[b], bytes + kPlaceSlack) != hipSuccess) { (void)hipGetLastError(); block[b] = nullptr; break; }
-    for (size_t off = 0; off <= kPlaceSlack; off += kPlaceStep) {
+    const size_t npos = kPlaceSlack / kPlaceStep + 1;
+    static const bool reverse = getenv("EK_HIP_PLACE_REVERSE") != nullptr;        // exploration
+    for (size_t ip = 0; ip < npos; ++ip) {
+      const size_t off = (reverse ? npos - 1 - ip : ip) * kPlaceStep;
       char *base = (char *)block[b] + off;
       double *wA = (double *)base;
       char *work = base + work_off;                                      // the stage scratch of the arena
@@ -121,7 +129,7 @@ int place_workspace(size_t bytes, int n, int ld, size_t work_off) {
       float ms = 1e30f;
       if (hipStreamSynchronize(s) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
       else (void)hipGetLastError();
-      if (mlen < 440) mlen += snprintf(msg + mlen, sizeof(msg) - mlen, "%s%.3f", off ? " " : (b ? " | " : ""), ms);
+      if (mlen < 1990) mlen += snprintf(msg + mlen, sizeof(msg) - mlen, "%s%.3f", ip ? " " : (b ? " | " : ""), ms);
       if (ms < best) { best = ms; best_blk = b; best_off = off; }
     }
   }
