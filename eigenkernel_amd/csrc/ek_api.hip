@@ -74,76 +74,80 @@ struct Arena {
 };
 inline size_t al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
-// Placement of a new whole-path workspace.  The HBM-bound symv of the tridiagonalisation runs
-// 1-3 % faster or slower depending on where in HBM the matrix it streams happens to land (DESIGN.md
-// section 5, "run-to-run spread, explained"): nothing about the address tells which.  On some boxes
-// successive allocations alternate between a fast and a slow region, on others the mode changes at
-// sharp multi-GiB boundaries and neighbouring allocations share it.  When the workspace has to grow,
-// two blocks with kPlaceSlack bytes to spare are therefore held at the same time, the first panel of
-// a tridiagonalisation of a synthetic matrix is timed with the arena shifted by 0, 2, 4, ... GiB
-// inside each (the same kernels on the same arrays, ~14 ms per position at N = 16384), and the
-// fastest position is kept; the other block is released.  One-off cost per workspace size and
-// 8 GiB of the 288; EK_HIP_PLACEMENT=0 turns it off.
-int place_workspace(size_t bytes, int n, int ld, size_t work_off) {
+// Placement of the tridiagonalisation's scratch.  The HBM-bound symv runs 2.6 % faster (4.5 % on the
+// largest trailing matrices) or slower depending on where its SCRATCH (x, the panel, the partial
+// sums: 64 MB at N = 16384) lies relative to the matrix it streams: device memory comes in two
+// "colours" of some physical origin (tools/placement_addr.py: every allocation has one, large blocks
+// change it at multi-GiB boundaries), and the launch is fast when matrix and scratch have different
+// colours -- whichever they are -- and slow when they share one.  Nothing about an address tells its
+// colour, so it is measured: when the workspace has been (re)allocated, the first panel of a
+// tridiagonalisation of a synthetic matrix is timed in the matrix's place with the scratch (a) where
+// the arena has it and (b) in up to five small separate allocations, until one is clearly faster
+// than another; that one is kept for all later solves.  ~30 ms per candidate, once per workspace
+// size (it happens in the warm-up solve); EK_HIP_PLACEMENT=0 turns it off.
+struct ScratchChoice {
+  void *buf = nullptr;            // separately allocated scratch in use (nullptr: the arena's own)
+  size_t bytes = 0;
+  const void *for_ws = nullptr;   // the workspace allocation this choice was made for
+  int for_n = 0;
+};
+ScratchChoice g_scratch;
+
+void release_scratch_choice() {
+  if (g_scratch.buf) (void)hipFree(g_scratch.buf);
+  g_scratch = ScratchChoice{};
+}
+
+// returns the scratch to use for the tridiagonalisation of order n on matrix wA (arena_work if nothing better)
+void *choose_sytrd_scratch(int n, int ld, double *wA, void *arena_work, double *vecs, size_t need) {
   static int enabled = -1;
-  static size_t kPlaceStep = (size_t)2 << 30, kPlaceSlack = (size_t)8 << 30;
-  if (enabled < 0) {
-    const char *e = getenv("EK_HIP_PLACEMENT"); enabled = e ? atoi(e) : 1;
-    if (const char *q = getenv("EK_HIP_PLACE_STEP_MB")) kPlaceStep = (size_t)atoi(q) << 20;     // exploration
-    if (const char *q = getenv("EK_HIP_PLACE_SLACK_GB")) kPlaceSlack = (size_t)atoi(q) << 30;
-    if (kPlaceStep < ((size_t)1 << 20)) kPlaceStep = (size_t)1 << 20;
-  }
-  if (!enabled || n < 8192 || bytes > ((size_t)100 << 30)) return 0;      // plain workspace() takes over
+  if (enabled < 0) { const char *e = getenv("EK_HIP_PLACEMENT"); enabled = e ? atoi(e) : 1; }
+  if (!enabled || n < 8192) return arena_work;
+  if (g_scratch.for_ws == g_ctx.ws_alloc && g_scratch.for_n == n && g_scratch.bytes >= need)
+    return g_scratch.buf ? g_scratch.buf : arena_work;
+  release_scratch_choice();
   hipStream_t s = g_ctx.stream;
-  if (g_ctx.ws_alloc) { EK_HIP_CHECK(hipFree(g_ctx.ws_alloc)); }
-  g_ctx.ws = nullptr; g_ctx.ws_alloc = nullptr; g_ctx.ws_bytes = 0;
   hipEvent_t e0, e1;
-  EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return arena_work; }
   const int old_cols = sytrd_get_max_cols();
-  void *block[2] = {nullptr, nullptr};
-  double best = 1e30;
-  int best_blk = -1;
-  size_t best_off = 0;
-  char msg[2048]; int mlen = 0;
-  msg[0] = 0;
-  for (int b = 0; b < 2; ++b) {
-    if (hipMalloc(&block[b], bytes + kPlaceSlack) != hipSuccess) { (void)hipGetLastError(); block[b] = nullptr; break; }
-    const size_t npos = kPlaceSlack / kPlaceStep + 1;
-    static const bool reverse = getenv("EK_HIP_PLACE_REVERSE") != nullptr;        // exploration
-    for (size_t ip = 0; ip < npos; ++ip) {
-      const size_t off = (reverse ? npos - 1 - ip : ip) * kPlaceStep;
-      char *base = (char *)block[b] + off;
-      double *wA = (double *)base;
-      char *work = base + work_off;                                      // the stage scratch of the arena
-      double *dd = (double *)(base + bytes - 4 * al((size_t)ld * 8));    // any three vectors inside the arena
-      double *de = dd + ld, *dt = de + ld;
-      sytrd_set_max_cols(64);
-      for (int rep = 0; rep < 2; ++rep) {                                // first pass warms up, second is timed
-        (void)hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s);
-        synth_matrix(s, n, 1, wA, ld);
-        (void)hipEventRecord(e0, s);
-        sytrd_lower(s, n, wA, ld, dd, de, dt, nullptr, 0, work);
-        (void)hipEventRecord(e1, s);
-      }
-      sytrd_set_max_cols(old_cols);
-      float ms = 1e30f;
-      if (hipStreamSynchronize(s) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
-      else (void)hipGetLastError();
-      if (mlen < 1990) mlen += snprintf(msg + mlen, sizeof(msg) - mlen, "%s%.3f", ip ? " " : (b ? " | " : ""), ms);
-      if (ms < best) { best = ms; best_blk = b; best_off = off; }
+  auto probe = [&](void *work) -> float {
+    sytrd_set_max_cols(64);
+    for (int rep = 0; rep < 2; ++rep) {                                // first pass warms up, second is timed
+      (void)hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s);
+      synth_matrix(s, n, 1, wA, ld);
+      (void)hipEventRecord(e0, s);
+      sytrd_lower(s, n, wA, ld, vecs, vecs + ld, vecs + 2 * (size_t)ld, nullptr, 0, work);
+      (void)hipEventRecord(e1, s);
     }
+    sytrd_set_max_cols(old_cols);
+    float ms = 1e30f;
+    if (hipStreamSynchronize(s) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    else (void)hipGetLastError();
+    return ms;
+  };
+  constexpr int kCand = 6;
+  void *cand[kCand] = {arena_work, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float t[kCand];
+  int ncand = 0, best = 0;
+  float tmin = 1e30f, tmax = 0.f;
+  char msg[256]; int mlen = 0; msg[0] = 0;
+  for (int c = 0; c < kCand; ++c) {
+    if (c > 0 && hipMalloc(&cand[c], need) != hipSuccess) { (void)hipGetLastError(); cand[c] = nullptr; break; }
+    t[c] = probe(cand[c]);
+    ++ncand;
+    if (mlen < 240) mlen += snprintf(msg + mlen, sizeof(msg) - mlen, " %.3f", t[c]);
+    if (t[c] < tmin) { tmin = t[c]; best = c; }
+    if (t[c] > tmax) tmax = t[c];
+    if (tmin < 0.98f * tmax) break;                     // both colours seen: the faster one is known
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (best_blk < 0) {                                   // nothing could be allocated with slack
-    for (void *p : block) if (p) (void)hipFree(p);
-    return 0;                                           // workspace() allocates (or reports the failure)
-  }
-  if (block[1 - best_blk]) (void)hipFree(block[1 - best_blk]);
-  g_ctx.ws_alloc = block[best_blk]; g_ctx.ws = (char *)block[best_blk] + best_off; g_ctx.ws_bytes = bytes;
+  for (int c = 1; c < ncand; ++c) if (c != best && cand[c]) (void)hipFree(cand[c]);
+  g_scratch.buf = best > 0 ? cand[best] : nullptr;
+  g_scratch.bytes = need; g_scratch.for_ws = g_ctx.ws_alloc; g_scratch.for_n = n;
   if (getenv("EK_HIP_PLACEMENT_VERBOSE"))
-    fprintf(stderr, "[ek_hip] workspace placement: probes in ms (two blocks, shifts of 2 GiB): %s -> block %d shift %zu GiB\n",
-            msg, best_blk, best_off >> 30);
-  return 0;
+    fprintf(stderr, "[ek_hip] scratch placement: first-panel probes (ms; first = inside the arena):%s -> %s\n", msg,
+            best ? "a separate allocation" : "the arena's own");
+  return g_scratch.buf ? g_scratch.buf : arena_work;
 }
 
 // device buffers of one host-array call: released on every exit path
@@ -482,6 +486,7 @@ int ek_hip_finalize(void) {
   (void)hipStreamSynchronize(g_ctx.stream);
   if (g_ctx.ws_alloc) (void)hipFree(g_ctx.ws_alloc);
   g_ctx.ws = nullptr; g_ctx.ws_alloc = nullptr; g_ctx.ws_bytes = 0;
+  release_scratch_choice();
   return 0;
 }
 
@@ -1256,6 +1261,35 @@ int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds) {
   return g_comm.err ? -996 : 0;
 }
 
+// Tuning hook: the first max_cols columns of the tridiagonalisation of the synthetic matrix with the
+// matrix, the stage scratch (>= ek_hip_debug_sytrd_work_bytes(n)) and three n-vectors at caller-chosen
+// device addresses (placement experiments).  seconds[0] = time of the last of `reps` passes.
+unsigned long long ek_hip_debug_sytrd_work_bytes(int n) { return (unsigned long long)sytrd_work_bytes(n); }
+int ek_hip_debug_sytrd_at(int n, int max_cols, int reps, double *dA, void *work, double *vecs, double *seconds) {
+  if (n < 1 || !dA || !work || !vecs) return -1;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  hipEvent_t e0, e1;
+  EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
+  const int old_cols = sytrd_get_max_cols();
+  sytrd_set_max_cols(max_cols);
+  for (int r = 0; r < reps; ++r) {
+    EK_HIP_CHECK(hipMemsetAsync(dA, 0, (size_t)ld * ld * 8, s));
+    synth_matrix(s, n, 1, dA, ld);
+    EK_HIP_CHECK(hipEventRecord(e0, s));
+    sytrd_lower(s, n, dA, ld, vecs, vecs + ld, vecs + 2 * (size_t)ld, nullptr, 0, work);
+    EK_HIP_CHECK(hipEventRecord(e1, s));
+  }
+  sytrd_set_max_cols(old_cols);
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  float ms = 0.f; EK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (seconds) *seconds = ms * 1e-3;
+  return 0;
+}
+
 // Tuning hook: the tridiagonalisation hooks stop after max_cols columns (-1 = all of them).
 int ek_hip_debug_set_sytrd_maxcols(int max_cols) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -1330,10 +1364,6 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   int rc = 0;
   const size_t ws_need = 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
                          4 * al((size_t)ld * 8) + sygst_scr + potrf_wb;
-  if (ws_need > g_ctx.ws_bytes) {
-    rc = place_workspace(ws_need, n, ld, 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work);
-    if (rc) return rc;
-  }
   rc = workspace(ws_need, &ws);
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
@@ -1347,6 +1377,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
   double *sscr = (problem == 1) ? a.get<double>(sygst_dbl) : nullptr;
   char *pwork = potrf_wb ? a.get<char>(potrf_wb) : nullptr;
+  // where the tridiagonalisation keeps x, the panel and its partial sums (probed once per workspace)
+  void *sytrd_work = choose_sytrd_scratch(n, ld, wA, work, dd, wb_sytrd);
 
   StageTimer tm;
   const bool timing = stage_seconds && n_stages > 0;
@@ -1408,10 +1440,10 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   }
   mark();                                                              // 3
   if (dist) {
-    const SytrdMember me{wA, ld, dd, de, dt, wV, ld, work, g_comm.rank};
+    const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
     sytrd_lower_dist(s, n, 1, &me, team_exchange(0));
   } else {
-    sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, work);
+    sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
   }
   mark();                                                              // 4
   // eigenvector columns wanted: the first n_vec, or this grid cell's share of them; the D&C
