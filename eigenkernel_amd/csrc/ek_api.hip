@@ -1290,6 +1290,12 @@ int ek_hip_debug_sytrd_at(int n, int max_cols, int reps, double *dA, void *work,
   return 0;
 }
 
+int ek_hip_debug_sytrd_split(void *alt, int mask) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  sytrd_debug_split(alt, mask);
+  return 0;
+}
+
 // Tuning hook: the tridiagonalisation hooks stop after max_cols columns (-1 = all of them).
 int ek_hip_debug_set_sytrd_maxcols(int max_cols) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -187,6 +187,7 @@ void sytrd_team_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t c
 void team_allgatherv(hipStream_t s, int nmem, int rank0, double *const *bufs, const size_t *offs,
                      const size_t *counts, int nranks, void *user);   // rehearsal: nmem == nranks
 
+void sytrd_debug_split(void *alt, int mask);   // placement experiments only
 void sytrd_set_max_cols(int max_cols);   // tuning hooks: stop after this many columns (-1 = all)
 int sytrd_get_max_cols();
 // instrumentation: HIP events around every symv launch (bench.py roofline line)

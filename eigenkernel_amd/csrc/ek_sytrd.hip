@@ -728,6 +728,12 @@ struct Layout {
 
 size_t sytrd_work_bytes(int n) { return Layout(n).total; }
 
+// placement experiments (tools/placement_split.py): sub-buffers selected by mask (1 x, 2 panel,
+// 4 row-part sums, 8 column-part sums, 16 the small rest) are taken from `alt` instead of `work`
+static void *g_split_alt = nullptr;
+static int g_split_mask = 0;
+void sytrd_debug_split(void *alt, int mask) { g_split_alt = alt; g_split_mask = mask; }
+
 void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e, double *tau,
                  double *V, int ldv, void *work) {
   if (n <= 0) return;
@@ -740,6 +746,18 @@ void sytrd_lower(hipStream_t s, int n, double *A, int lda, double *d, double *e,
   b.dotpart = (double *)(w + L.off_dot); b.dottot = (double *)(w + L.off_dtot);
   b.scal = (double *)(w + L.off_scal);
   (void)hipMemsetAsync(work, 0, L.total, s);
+  if (g_split_alt) {   // placement experiments: selected sub-buffers live in a second scratch block
+    char *a = (char *)g_split_alt;
+    (void)hipMemsetAsync(a, 0, L.total, s);
+    if (g_split_mask & 1) b.xbuf = (double *)(a + L.off_x);
+    if (g_split_mask & 2) b.P = (double *)(a + L.off_P);
+    if (g_split_mask & 4) b.ypart = (double *)(a + L.off_y);
+    if (g_split_mask & 8) b.tpart = (double *)(a + L.off_t);
+    if (g_split_mask & 16) {
+      b.vavpart = (double *)(a + L.off_vav); b.normpart = (double *)(a + L.off_norm);
+      b.dotpart = (double *)(a + L.off_dot); b.dottot = (double *)(a + L.off_dtot); b.scal = (double *)(a + L.off_scal);
+    }
+  }
   const int npad = L.npad, NRB = L.NRB;
 
   ColupdArgs c{};
