@@ -82,7 +82,7 @@ inline size_t al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 // colours -- whichever they are -- and slow when they share one.  Nothing about an address tells its
 // colour, so it is measured: when the workspace has been (re)allocated, the first panel of a
 // tridiagonalisation of a synthetic matrix is timed in the matrix's place with the scratch (a) where
-// the arena has it and (b) in up to five small separate allocations, until one is clearly faster
+// the arena has it and (b) in up to three small separate allocations, until one is clearly faster
 // than another; that one is kept for all later solves.  ~30 ms per candidate, once per workspace
 // size (it happens in the warm-up solve); EK_HIP_PLACEMENT=0 turns it off.
 struct ScratchChoice {
@@ -125,8 +125,8 @@ void *choose_sytrd_scratch(int n, int ld, double *wA, void *arena_work, double *
     else (void)hipGetLastError();
     return ms;
   };
-  constexpr int kCand = 6;
-  void *cand[kCand] = {arena_work, nullptr, nullptr, nullptr, nullptr, nullptr};
+  constexpr int kCand = 4;
+  void *cand[kCand] = {arena_work, nullptr, nullptr, nullptr};
   float t[kCand];
   int ncand = 0, best = 0;
   float tmin = 1e30f, tmax = 0.f;
