@@ -1290,6 +1290,26 @@ int ek_hip_debug_sytrd_at(int n, int max_cols, int reps, double *dA, void *work,
   return 0;
 }
 
+// Tuning hook: C = alpha op(A) op(B) + beta C on device arrays at caller-chosen addresses, timed.
+int ek_hip_debug_gemm_at(int transa, int transb, int m, int n, int k, const double *dA, int lda, const double *dB,
+                         int ldb, double beta, double *dC, int ldc, int lower_only, int reps, double *seconds) {
+  if (m < 1 || n < 1 || k < 1 || !dA || !dB || !dC) return -1;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  hipEvent_t e0, e1;
+  EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
+  gemm(s, transa != 0, transb != 0, m, n, k, -1.0, dA, lda, dB, ldb, beta, dC, ldc, lower_only != 0);   // warm-up
+  EK_HIP_CHECK(hipEventRecord(e0, s));
+  for (int r = 0; r < reps; ++r) gemm(s, transa != 0, transb != 0, m, n, k, -1.0, dA, lda, dB, ldb, beta, dC, ldc, lower_only != 0);
+  EK_HIP_CHECK(hipEventRecord(e1, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  float ms = 0.f; EK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (seconds) *seconds = ms * 1e-3 / (reps > 0 ? reps : 1);
+  return 0;
+}
+
 int ek_hip_debug_sytrd_split(void *alt, int mask) {
   std::lock_guard<std::mutex> lk(g_mu);
   sytrd_debug_split(alt, mask);

@@ -105,6 +105,8 @@ def load_library(path=None):
         "ek_hip_debug_set_sytrd_maxcols": (c_int, [c_int]),
         "ek_hip_debug_sytrd_work_bytes": (ctypes.c_ulonglong, [c_int]),
         "ek_hip_debug_sytrd_split": (c_int, [vp, c_int]),
+        "ek_hip_debug_gemm_at": (c_int, [c_int, c_int, c_int, c_int, c_int, vp, c_int, vp, c_int, c_dbl, vp, c_int,
+                                         c_int, c_int, _dp]),
         "ek_hip_debug_sytrd_at": (c_int, [c_int, c_int, c_int, vp, vp, vp, _dp]),
         "ek_hip_debug_reduce_team": (c_int, [c_int, c_int, c_int, _dp]),
         "ek_hip_profile_symv_get": (c_int, [_dp, ctypes.POINTER(ctypes.c_longlong), _dp]),
@@ -134,7 +136,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_sytrd_team", "ek_hip_comm_unique_id", "ek_hip_comm_init", "ek_hip_comm_size", "ek_hip_comm_rank",
     "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device", "ek_hip_debug_sytrd_team", "ek_hip_sygst_team",
     "ek_hip_potrf_team", "ek_hip_debug_reduce_team", "ek_hip_comm_attach_host",
-    "ek_hip_comm_peer_enable", "ek_hip_comm_peer_disable", "ek_hip_debug_set_sytrd_maxcols", "ek_hip_debug_sytrd_work_bytes", "ek_hip_debug_sytrd_at", "ek_hip_debug_sytrd_split",
+    "ek_hip_comm_peer_enable", "ek_hip_comm_peer_disable", "ek_hip_debug_set_sytrd_maxcols", "ek_hip_debug_sytrd_work_bytes", "ek_hip_debug_sytrd_at", "ek_hip_debug_sytrd_split", "ek_hip_debug_gemm_at",
 )
 
 

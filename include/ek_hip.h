@@ -264,6 +264,8 @@ int ek_hip_profile_symv(int enable);
 int ek_hip_debug_sytrd(int n, int ld, int reps, double *seconds);
 unsigned long long ek_hip_debug_sytrd_work_bytes(int n);
 int ek_hip_debug_sytrd_at(int n, int max_cols, int reps, double *dA, void *work, double *vecs, double *seconds);
+int ek_hip_debug_gemm_at(int transa, int transb, int m, int n, int k, const double *dA, int lda, const double *dB,
+                         int ldb, double beta, double *dC, int ldc, int lower_only, int reps, double *seconds);
 int ek_hip_debug_sytrd_split(void *alt, int mask);  /* placement experiments: sub-buffers of the scratch from alt */
 int ek_hip_debug_set_sytrd_maxcols(int max_cols);   /* the hooks stop after max_cols columns (-1: all) */
 int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds);
