@@ -8,3 +8,7 @@ for spec in "256 1 gep" "256 0 sep" "1000 1 gep"; do
   /opt/conda/bin/mpiexec -np 4 oracle/scalapack_path $1 $2 tests/golden/scalapack_synth_$3_n$1_np4.txt > /dev/null
 done
 /opt/conda/bin/mpiexec -np 1 oracle/scalapack_path 256 1 tests/golden/scalapack_synth_gep_n256_np1.txt > /dev/null
+# full-size BASELINE configurations (C2: N=4096 standard; C3/C5: N=16384 generalized), the
+# reference's 2x4 grid for 8 ranks (processes.f90:56-65); 3 s and 5 min on 8 cores
+/opt/conda/bin/mpiexec -np 8 oracle/scalapack_path 4096 0 tests/golden/scalapack_synth_sep_n4096_np8.txt > /dev/null
+/opt/conda/bin/mpiexec -np 8 oracle/scalapack_path 16384 1 tests/golden/scalapack_synth_gep_n16384_np8.txt > /dev/null

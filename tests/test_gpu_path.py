@@ -268,7 +268,8 @@ def test_fortran_host_end_to_end(tmp_path, golden_dir):
     txt = out.stdout
     res_max = float([l for l in txt.splitlines() if l.startswith("residual norm (max):")][0].split(":")[1])
     orth = float([l for l in txt.splitlines() if l.startswith("orthogonality criterion:")][0].split(":")[1])
-    assert res_max <= 1e-14 and orth <= 1e-11
+    # SURVEY.md section 4 probe of the reference build on this case: 4.8e-16 and 5e-15
+    assert res_max <= 2e-15 and orth <= 1e-13
     log = json.load(open(tmp_path / "log.json"))
     assert set(log) == {"setting", "events"} and log["setting"]["dimension"] == 30
     names = {e["name"] for e in log["events"]}

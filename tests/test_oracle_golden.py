@@ -184,3 +184,43 @@ def test_oracle_vs_scalapack_goldens(oracle, golden_dir, name, n, gep):
     w, _, info, _ = oracle.solve(A, B)
     assert info == 0
     assert np.abs(w - w_ref).max() <= n * EPS * np.abs(w_ref).max()
+
+
+def test_full_size_scalapack_fixtures_against_an_independent_lapack(oracle, golden_dir):
+    """The C2 fixture (N=4096 standard, reference library path on the 2x4 grid) against scipy's
+    LAPACK on the same generator; the C3 fixture (N=16384 generalized) is too large for the CPU
+    suite and is checked for shape, order and the generator's spectral range only."""
+    n = 4096
+    w_ref = np.loadtxt(os.path.join(golden_dir, "scalapack_synth_sep_n4096_np8.txt"))
+    assert w_ref.shape == (n,) and np.all(np.diff(w_ref) > 0)
+    w = sl.eigh(oracle.synth_matrix(n, 1), eigvals_only=True)
+    assert np.abs(w - w_ref).max() <= n * EPS * np.abs(w_ref).max()
+    w3 = np.loadtxt(os.path.join(golden_dir, "scalapack_synth_gep_n16384_np8.txt"))
+    assert w3.shape == (16384,) and np.all(np.diff(w3) > 0)
+    assert 0.38 < w3[0] < 0.39 and 2.61 < w3[-1] < 2.63     # SURVEY.md 8(d): GEP spectrum [0.38, 2.63]
+
+
+def test_verifier_mirror_is_pinned_to_the_reference_verifier_probe(oracle, golden_dir):
+    """eigenkernel_amd/verifier.py is the acceptance gate of the GPU suite, so it is pinned itself:
+    on the reference's shipped cases its numbers must land where the reference's own verifier
+    (-c -1 -t 1,n; verifier.f90:75-204, 233-330) printed them for the reference build (SURVEY.md
+    section 4, probe: residual max <= 4.8e-16, orthogonality <= 5.5e-14 over BNZ30 and VCNT400), for
+    the oracle's eigenpairs and for an independent LAPACK's alike (same normalisations: divided by
+    ||A||_F, averaged over n, diagonal zeroed)."""
+    A = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_A.mtx")).to_dense()
+    B = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_BNZ30_B.mtx")).to_dense()
+    for w, Z in (oracle.solve(A, B)[:2], sl.eigh(A, B)):
+        a_norm, ave, mx = eval_residual_norm(A, w, Z, B)
+        assert abs(a_norm - np.sqrt((A * A).sum())) <= 1e-13 * a_norm
+        assert ave <= mx <= 1e-15 and ave >= 1e-17       # probe: 4.8e-16
+        assert 1e-16 <= eval_orthogonality(Z, B) <= 2e-14   # probe, BNZ30: ~5e-15
+    A = read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_VCNT400std_A.mtx")).to_dense()
+    w, Z = oracle.solve(A)[:2]
+    _, ave, mx = eval_residual_norm(A, w, Z)
+    assert ave <= mx <= 1e-15
+    assert 1e-15 <= eval_orthogonality(Z) <= 2e-13          # probe, VCNT400: 5.5e-14
+    # a deliberately wrong pair must move both quantities by the amount the formulas predict
+    Zp = Z.copy(); Zp[:, 0] += 1e-6 * Z[:, 1]
+    _, _, mx_p = eval_residual_norm(A, w, Zp)
+    assert abs(mx_p - 1e-6 * abs(w[1] - w[0]) / np.linalg.norm(A, "fro")) <= 1e-3 * mx_p + 1e-15
+    assert abs(eval_orthogonality(Zp) - np.sqrt(2.0) * 1e-6) <= 1e-8
