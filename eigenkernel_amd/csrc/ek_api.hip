@@ -1121,6 +1121,132 @@ int ek_hip_profile_symv_get(double *seconds, long long *launches, double *algori
   return 0;
 }
 
+// ---- two-stage tridiagonalisation, piece by piece on host arrays (tests and tools; declared in
+// include/ek_hip_debug.h).  Stage 1: A (n x n, lower) -> band (in A) + explicit reflectors V (n x n)
+// + tau; *flag = 0, or the reason the CholeskyQR2 panel factorisation gave up.
+int ek_hip_debug_sy2sb(int n, double *A, int lda, double *V, int ldv, double *tau, int *flag) {
+  if (n < 1) return -1;
+  if (!A || lda < n) return -3;
+  if (!V || ldv < n) return -5;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const size_t wb = sy2sb_work_bytes(n);
+  void *ws;
+  rc = workspace(2 * al((size_t)ld * ld * 8) + al(wb) + al((size_t)ld * 8), &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *dA = a.get<double>((size_t)ld * ld), *dV = a.get<double>((size_t)ld * ld);
+  char *work = a.get<char>(wb);
+  double *dt = a.get<double>(ld);
+  EK_HIP_CHECK(hipMemsetAsync(dA, 0, (size_t)ld * ld * 8, s));
+  EK_HIP_CHECK(hipMemsetAsync(dV, 0, (size_t)ld * ld * 8, s));
+  EK_HIP_CHECK(hipMemsetAsync(dt, 0, (size_t)ld * 8, s));
+  EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, 4 * sizeof(int), s));
+  rc = h2d_matrix(n, n, A, lda, dA, ld, s); if (rc) return rc;
+  sy2sb_lower(s, n, dA, ld, dV, ld, dt, g_ctx.d_info + 2, work);
+  EK_HIP_CHECK(hipGetLastError());
+  rc = d2h_matrix(n, n, dA, ld, A, lda, s); if (rc) return rc;
+  rc = d2h_matrix(n, n, dV, ld, V, ldv, s); if (rc) return rc;
+  if (tau) EK_HIP_CHECK(hipMemcpyAsync(tau, dt, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  int f = 0;
+  EK_HIP_CHECK(hipMemcpyAsync(&f, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  if (flag) *flag = f;
+  return 0;
+}
+
+// Stage 2: the lower band (half bandwidth 64) of A -> d, e; Z (n x ncols, may be null) <- Q2 Z.
+int ek_hip_debug_sb2st(int n, const double *A, int lda, double *d, double *e, double *Z, int ldz, int ncols,
+                       int *flag) {
+  if (n < 1) return -1;
+  if (!A || lda < n) return -3;
+  if (!d || (n > 1 && !e)) return -4;
+  if (ncols < 0 || (ncols > 0 && (!Z || ldz < n))) return -6;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const size_t wb = sb2st_work_bytes(n);
+  void *ws;
+  rc = workspace(2 * al((size_t)ld * ld * 8) + al((size_t)ld * (ncols > 0 ? ncols : 1) * 8) + al(wb) +
+                 2 * al((size_t)ld * 8), &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *dA = a.get<double>((size_t)ld * ld), *dV2 = a.get<double>((size_t)ld * ld);
+  double *dZ = a.get<double>((size_t)ld * (ncols > 0 ? ncols : 1));
+  char *work = a.get<char>(wb);
+  double *dd = a.get<double>(ld), *de = a.get<double>(ld);
+  EK_HIP_CHECK(hipMemsetAsync(dA, 0, (size_t)ld * ld * 8, s));
+  EK_HIP_CHECK(hipMemsetAsync(dV2, 0, (size_t)ld * ld * 8, s));
+  EK_HIP_CHECK(hipMemsetAsync(dd, 0, 2 * al((size_t)ld * 8), s));
+  EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, 4 * sizeof(int), s));
+  rc = h2d_matrix(n, n, A, lda, dA, ld, s); if (rc) return rc;
+  sb2st_lower(s, n, dA, ld, dd, de, dV2, ld, g_ctx.d_info + 2, work);
+  if (ncols > 0) {
+    rc = h2d_matrix(n, ncols, Z, ldz, dZ, ld, s); if (rc) return rc;
+    sb2st_apply_q2(s, n, ncols, dV2, ld, dZ, ld, work);
+    rc = d2h_matrix(n, ncols, dZ, ld, Z, ldz, s); if (rc) return rc;
+  }
+  EK_HIP_CHECK(hipGetLastError());
+  EK_HIP_CHECK(hipMemcpyAsync(d, dd, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  if (n > 1) EK_HIP_CHECK(hipMemcpyAsync(e, de, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, s));
+  int f = 0;
+  EK_HIP_CHECK(hipMemcpyAsync(&f, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  if (flag) *flag = f;
+  return 0;
+}
+
+// Timing of the two-stage pieces on a device-generated synthetic matrix of order n:
+// seconds[0] dense -> band, [1] band -> tridiagonal, [2] Q2 applied to ncols columns, [3] Q1 applied.
+int ek_hip_debug_two_stage_timing(int n, int ncols, int reps, double *seconds, int *flag) {
+  if (n < 3 || ncols < 1 || ncols > n) return -1;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const size_t wb1 = sy2sb_work_bytes(n), wb2 = sb2st_work_bytes(n), wb3 = ormtr_work_bytes(n, ncols);
+  void *ws;
+  rc = workspace(4 * al((size_t)ld * ld * 8) + al(wb1) + al(wb2) + al(wb3) + 3 * al((size_t)ld * 8), &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *dA = a.get<double>((size_t)ld * ld), *dV = a.get<double>((size_t)ld * ld);
+  double *dV2 = a.get<double>((size_t)ld * ld), *dZ = a.get<double>((size_t)ld * ld);
+  char *w1 = a.get<char>(wb1), *w2 = a.get<char>(wb2), *w3 = a.get<char>(wb3);
+  double *dt = a.get<double>(ld), *dd = a.get<double>(ld), *de = a.get<double>(ld);
+  hipEvent_t ev[5];
+  for (auto &e : ev) EK_HIP_CHECK(hipEventCreate(&e));
+  double tot[4] = {0, 0, 0, 0};
+  EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, 4 * sizeof(int), s));
+  for (int r = 0; r < reps; ++r) {
+    EK_HIP_CHECK(hipMemsetAsync(dA, 0, (size_t)ld * ld * 8, s));
+    EK_HIP_CHECK(hipMemsetAsync(dV, 0, (size_t)ld * ld * 8, s));
+    EK_HIP_CHECK(hipMemsetAsync(dV2, 0, (size_t)ld * ld * 8, s));
+    EK_HIP_CHECK(hipMemsetAsync(dt, 0, 3 * al((size_t)ld * 8), s));
+    synth_matrix(s, n, 1, dA, ld);
+    set_matrix(s, n, ncols, 0.0, 1.0, dZ, ld);
+    EK_HIP_CHECK(hipEventRecord(ev[0], s));
+    sy2sb_lower(s, n, dA, ld, dV, ld, dt, g_ctx.d_info + 2, w1);
+    EK_HIP_CHECK(hipEventRecord(ev[1], s));
+    sb2st_lower(s, n, dA, ld, dd, de, dV2, ld, g_ctx.d_info + 2, w2);
+    EK_HIP_CHECK(hipEventRecord(ev[2], s));
+    sb2st_apply_q2(s, n, ncols, dV2, ld, dZ, ld, w2);
+    EK_HIP_CHECK(hipEventRecord(ev[3], s));
+    ormtr_lower(s, n, ncols, dV, ld, dt, dZ, ld, w3);
+    EK_HIP_CHECK(hipEventRecord(ev[4], s));
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    for (int q = 0; q < 4; ++q) { float ms = 0.f; EK_HIP_CHECK(hipEventElapsedTime(&ms, ev[q], ev[q + 1])); tot[q] += ms * 1e-3; }
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  int f = 0;
+  EK_HIP_CHECK(hipMemcpy(&f, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) *flag = f;
+  if (seconds) for (int q = 0; q < 4; ++q) seconds[q] = tot[q] / (reps > 0 ? reps : 1);
+  return 0;
+}
+
 // Tuning hook (not part of the drop-in surface): tridiagonalise a device-generated synthetic
 // matrix of order n held with leading dimension ld, `reps` times; seconds[0] = stage time per
 // repetition.  Honour EK_SYTRD_MAXCOLS to time only the first panels.

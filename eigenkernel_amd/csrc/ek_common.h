@@ -194,6 +194,29 @@ int sytrd_get_max_cols();
 void symv_profile_enable(int stride);   // 0 = off, k = time every k-th column's launch
 void symv_profile_collect(double *seconds, long long *launches, double *bytes);
 
+// ---------------------------------------------------------------- two-stage tridiagonalisation
+// (ek_sy2sb.hip, ek_sb2st.hip): dense -> band (half bandwidth kBandW) on the matrix cores, band ->
+// tridiagonal by bulge chasing, and the back-transformations of both stages.  Used by the whole-path
+// call for large orders in place of sytrd_lower + ormtr_lower; the results contract is the same.
+constexpr int kBandW = 64;
+size_t sy2sb_work_bytes(int n);
+// A (lower, lda multiple of 128, zero padded) -> band in the lower band of A (A(i,j), 0 <= i-j <= 64;
+// the rest of the lower triangle is zeroed except the R factors' upper triangles inside the band).
+// Vall (n x n, ldv; must be zero on entry): explicit reflectors, column j = v_j with its unit entry
+// at row j + 64; tau1[j] (must be zero on entry).  *d_flag (device int, 0 on entry) becomes non-zero if
+// a panel could not be factored by CholeskyQR2 (the caller then falls back to the one-stage path).
+void sy2sb_lower(hipStream_t s, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
+                 int *d_flag, void *work);
+
+size_t sb2st_work_bytes(int n);
+// Band (lower band of A, half bandwidth kBandW) -> d(n), e(n-1) by bulge chasing.  V2 (n x n, ldv2,
+// zero on entry) receives the reflectors (column s = those of sweep s, stacked); *d_flag |= 4 if the
+// persistent kernel had to be abandoned.  work: >= sb2st_work_bytes(n), shared with sb2st_apply_q2.
+void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, double *e, double *V2, int ldv2,
+                 int *d_flag, void *work);
+// Z(:, 0:ncols) <- Q2 Z
+void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2, double *Z, int ldz, void *work);
+
 // ---------------------------------------------------------------- tridiagonal D&C (ek_stedc.hip)
 size_t stedc_work_bytes(int n);
 // d(n), e(n-1) -> eigenvalues ascending in w(n), eigenvectors in Z (n x n, ldz).

@@ -1,0 +1,741 @@
+// ek_sy2sb.hip -- stage 1 of the two-stage tridiagonalisation: dense symmetric -> symmetric band
+// (half bandwidth SBW = 64), A = Q1 Bd Q1^T, entirely on the matrix cores.
+//
+// Together with ek_sb2st.hip (band -> tridiagonal by bulge chasing, and the back-transformation of
+// its reflectors) this replaces the ONE-stage PDSYTRD of solver_scalapack_all.f90:59 inside the
+// whole-path call for large orders.  Why: the one-stage reduction reads the trailing matrix once
+// per Householder column (4 n^3 / 3 bytes, HBM-bound: 0.73 s of the 1.8 s solve at N = 16384 even at
+// the full 8 TB/s); the two-stage form reads it once per PANEL of 64 columns and does all O(n^3)
+// work as GEMM-shaped products.  The results contract of the path (eigenvalues, eigenvectors) is
+// unchanged; the stage-level entry ek_hip_sytrd keeps the one-stage PDSYTRD semantics.
+//
+// Per panel p (columns c0 = 64 p .. c0+63, rows r0 = c0+64 .. n-1, m = n - r0):
+//   1. panel factorisation  P = A(r0:n, c0:c0+64) = Q R  with Q = I - V T V^T:
+//        m > 192 : CholeskyQR2 (two Gram + triangular-solve passes: everything is a tall-skinny
+//                  GEMM) followed by Householder reconstruction (Ballard et al. 2014: an LU of the
+//                  top 64x64 block of Q - S without pivoting gives V, T and the signs S), checked on
+//                  the device (Cholesky pivots, ||Q1^T Q1 - I||): a panel CholeskyQR2 cannot handle
+//                  (rank deficient / cond > 1e7) raises *d_flag and the caller falls back to the
+//                  one-stage path;
+//        m <= 192: Householder QR of the panel inside one workgroup's LDS (handles any rank).
+//   2. Y = A22 V            (SYMM on the lower triangle, split-K partial sums)
+//   3. W = Y T - 1/2 V (T^T V^T Y T)
+//   4. A22 -= W V^T + V W^T (one GEMM with K = 128 on the image [W | V | W])
+// The band is left in the lower band of A, R (with the signs of the reconstruction) in the panel.
+#include "ek_common.h"
+
+#include <cstdlib>
+
+namespace ek {
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int SB = kBandW;   // 64: band half-width = panel width
+constexpr int LD = 66;       // leading dimension of 64x64 LDS images, row-major s[r * LD + c]
+constexpr int IMG = SB * LD; // doubles per image
+constexpr int CH = 128;      // rows per workgroup of the tall-skinny kernels (two 64-row slabs)
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS operations have completed
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------- 64x64 building blocks in LDS
+// C = op(A) op(B), all 64x64 LDS images, on the matrix cores, by the 4 waves of the workgroup:
+// wave w owns rows 16 w .. 16 w + 15 of C.  Callers synchronise before and after.
+// out_g != nullptr: C goes to global memory (column-major, ld 64), row i scaled by rs[i] if rs.
+__device__ __forceinline__ void mm64(const double *sA, bool ta, const double *sB, bool tb, double *sC,
+                                     double *out_g = nullptr, const double *rs = nullptr) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int i0 = 16 * wave;
+  double4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < SB; kk += 4) {
+    const double x = ta ? sA[(kk + l4) * LD + i0 + l15] : sA[(i0 + l15) * LD + kk + l4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const double y = tb ? sB[(16 * jt + l15) * LD + kk + l4] : sB[(kk + l4) * LD + 16 * jt + l15];
+      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[jt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + l4 + 4 * r, j = 16 * jt + l15;
+      if (out_g) out_g[i + SB * j] = rs ? rs[i] * acc[jt][r] : acc[jt][r];
+      else sC[i * LD + j] = acc[jt][r];
+    }
+}
+
+// Wave 0: upper Cholesky factor in place, G = R^T R (row j of R from rows 0..j-1: lane = column).
+// Returns false (all lanes) when a pivot is not positive.
+__device__ __forceinline__ bool chol64_upper(double *sG, int lane) {
+  bool ok = true;
+  for (int j = 0; j < SB; ++j) {
+    double acc = sG[j * LD + lane];
+    for (int k = 0; k < j; ++k) acc -= sG[k * LD + j] * sG[k * LD + lane];
+    double d = __shfl(acc, j, 64);
+    if (!(d > 0.0) || !(d < 1.7e308)) { ok = false; d = 1.0; }
+    const double rjj = sqrt(d);
+    if (lane >= j) sG[j * LD + lane] = (lane == j) ? rjj : acc / rjj;
+    wave_sync();
+  }
+  for (int r = 1; r < SB; ++r)
+    if (lane < r) sG[r * LD + lane] = 0.0;
+  wave_sync();
+  return ok;
+}
+
+// Wave 0: X = R^-1 for upper triangular R (only its upper triangle is read).  sX must be zero.
+__device__ __forceinline__ void triinv64_upper(const double *sR, double *sX, int lane) {
+  for (int i = SB - 1; i >= 0; --i) {
+    double acc = 0.0;
+    for (int k = i + 1; k < SB; ++k) acc += sR[i * LD + k] * sX[k * LD + lane];   // X(k, c) = 0 for k > c
+    const double rii = sR[i * LD + i];
+    if (lane >= i) sX[i * LD + lane] = (lane == i) ? 1.0 / rii : -acc / rii;
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------- tall-skinny passes over a panel
+struct PanelArgs {
+  int m;                    // rows of the panel
+  const double *src; int lds_;   // source (m x 64, column-major)
+  const double *M;          // 64x64 multiplier (column-major, ld 64) when MUL
+  double *dst; int ldd;     // destination of src * M when MUL (may be null)
+  double *Gpart;            // one 64x64 partial Gram (of the OUTPUT rows) per workgroup when GRAM
+  // FINAL pass (the reflectors of the panel): extra outputs
+  const double *L1;         // top 64x64 block of V (column-major, ld 64)
+  const double *Rband;      // S R, upper triangular (column-major, ld 64)
+  double *Vall; int ldv;    // explicit reflector matrix of the back-transformation, at (r0, c0)
+  double *Apanel; int lda;  // the panel inside A, at (r0, c0)
+  double *Vimg; int ldi;    // [W | V | W] image: V goes to columns 64..127
+};
+
+// out slab (64 x 64, LDS, row-major) = in slab * M^T-image; see mm64 for the operand convention
+__device__ __forceinline__ void slab_mul(const double *sS, const double *sMT, double *sO) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int i0 = 16 * wave;
+  double4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < SB; kk += 4) {
+    const double x = sS[(i0 + l15) * LD + kk + l4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, sMT[(16 * jt + l15) * LD + kk + l4], acc[jt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sO[(i0 + l4 + 4 * r) * LD + 16 * jt + l15] = acc[jt][r];
+}
+
+// G(i, j) += sum_r X(r, i) Y(r, j) over the 64 rows of two LDS slabs; wave w owns rows 16 w .. of G
+__device__ __forceinline__ void slab_gram(const double *sX, const double *sY, double4_t (&acc)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+  for (int kk = 0; kk < SB; kk += 4) {
+    const double x = sX[(kk + l4) * LD + 16 * wave + l15];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, sY[(kk + l4) * LD + 16 * jt + l15], acc[jt], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void store_gram(const double4_t (&acc)[4], double *G) {
+  // G(i, j) with i = 16 wave + l4 + 4 r, j = 16 jt + l15, stored at j + 64 i (lanes contiguous)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[(16 * jt + l15) + SB * (16 * wave + l4 + 4 * r)] = acc[jt][r];
+}
+
+// MODE 0: Gram of src.  MODE 1: dst = src M, Gram of dst.  MODE 2: final pass (V = src M below the
+// top block, L1 in it) with the writes of the reflectors.
+template <int MODE>
+__global__ __launch_bounds__(256) void panel_kernel(PanelArgs p) {
+  __shared__ double sS[IMG], sO[IMG], sMT[MODE ? IMG : 1];
+  const int t = threadIdx.x, r = t & 63, cg = t >> 6;
+  if (MODE) {
+    for (int idx = t; idx < SB * SB; idx += 256) {
+      const int k = idx & 63, j = idx >> 6;
+      sMT[j * LD + k] = p.M[k + SB * j];
+    }
+  }
+  double4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int slab = 0; slab < CH / SB; ++slab) {
+    const int row0 = blockIdx.x * CH + slab * SB;
+    if (row0 >= p.m) break;
+    const int row = row0 + r;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int col = 16 * cg + c;
+      sS[r * LD + col] = (row < p.m) ? p.src[(size_t)row + (size_t)col * p.lds_] : 0.0;
+    }
+    __syncthreads();
+    const double *sOut = sS;
+    if (MODE) {
+      slab_mul(sS, sMT, sO);
+      __syncthreads();
+      sOut = sO;
+    }
+    if (MODE == 1 && p.dst && row < p.m) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int col = 16 * cg + c;
+        p.dst[(size_t)row + (size_t)col * p.ldd] = sO[r * LD + col];
+      }
+    }
+    if (MODE == 2 && row < p.m) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int col = 16 * cg + c;
+        double v = sO[r * LD + col], a = 0.0;
+        if (row0 == 0) {          // top block: V = L1 (unit lower triangular), panel = S R (upper)
+          v = (r > col) ? p.L1[r + SB * col] : (r == col ? 1.0 : 0.0);
+          a = (r <= col) ? p.Rband[r + SB * col] : 0.0;
+        }
+        p.Vall[(size_t)row + (size_t)col * p.ldv] = v;
+        p.Vimg[(size_t)row + (size_t)(SB + col) * p.ldi] = v;
+        p.Apanel[(size_t)row + (size_t)col * p.lda] = a;
+      }
+    }
+    if (MODE != 2) slab_gram(sOut, sOut, acc);
+  }
+  if (MODE != 2) store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
+}
+
+// sum of `npart` 64x64 partials in a fixed order: grid 16 x 256 threads
+__global__ __launch_bounds__(256) void reduce_parts_kernel(int npart, const double *__restrict__ part,
+                                                           double *__restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int p = 0;
+  for (; p + 3 < npart; p += 4) {
+    a0 += part[(size_t)p * 4096 + e]; a1 += part[(size_t)(p + 1) * 4096 + e];
+    a2 += part[(size_t)(p + 2) * 4096 + e]; a3 += part[(size_t)(p + 3) * 4096 + e];
+  }
+  for (; p < npart; ++p) a0 += part[(size_t)p * 4096 + e];
+  out[e] = (a0 + a1) + (a2 + a3);
+}
+
+// first CholeskyQR pass: G (64x64, symmetric, stored j + 64 i) -> R1 (column-major) and R1^-1
+__global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G, double *__restrict__ R,
+                                                   double *__restrict__ Rinv, int *flag) {
+  __shared__ double sA[IMG], sB[IMG];
+  const int t = threadIdx.x, lane = t & 63;
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int j = idx & 63, i = idx >> 6;
+    sA[i * LD + j] = G[idx];
+    sB[i * LD + j] = 0.0;
+  }
+  __syncthreads();
+  if (t < 64) {
+    if (!chol64_upper(sA, lane) && lane == 0) atomicExch(flag, 1);
+    triinv64_upper(sA, sB, lane);
+  }
+  __syncthreads();
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    R[idx] = sA[i * LD + j];
+    Rinv[idx] = sB[i * LD + j];
+  }
+}
+
+// second pass + Householder reconstruction.  In: G2 = Qt^T Qt, the top 64 rows of Qt, R1.
+// Out: M2 = R2^-1 U^-1, T, L1, Rband = S R2 R1, tau.
+struct HrArgs {
+  const double *G2; const double *Qt; int ldq; const double *R1;
+  double *M2, *T, *L1, *Rband, *tau;
+  int *flag;
+};
+__global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
+  extern __shared__ double smem[];
+  double *sA = smem, *sB = smem + IMG, *sC = smem + 2 * IMG, *sD = smem + 3 * IMG;
+  __shared__ double s_sign[SB];
+  __shared__ double s_red[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // G2 and its distance from the identity: the loss of orthogonality of the first pass
+  double dev = 0.0;
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int j = idx & 63, i = idx >> 6;
+    const double g = p.G2[idx];
+    sA[i * LD + j] = g;
+    sB[i * LD + j] = 0.0;
+    const double e = fabs(g - (i == j ? 1.0 : 0.0));
+    dev = (e > dev || e != e) ? e : dev;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(dev, o, 64); dev = (y > dev || y != y) ? y : dev; }
+  if (lane == 0) s_red[wave] = dev;
+  __syncthreads();
+  if (t == 0) {
+    double dmax = 0.0;
+    for (int w = 0; w < 4; ++w) dmax = (s_red[w] > dmax || s_red[w] != s_red[w]) ? s_red[w] : dmax;
+    if (!(dmax <= 0.25)) atomicExch(p.flag, 2);
+  }
+  if (t < 64) {
+    if (!chol64_upper(sA, lane) && lane == 0) atomicExch(p.flag, 1);   // sA = R2
+    triinv64_upper(sA, sB, lane);                                       // sB = R2^-1
+  }
+  for (int idx = t; idx < SB * SB; idx += 256) {                        // sC = top block of Qt
+    const int i = idx & 63, j = idx >> 6;
+    sC[i * LD + j] = p.Qt[(size_t)i + (size_t)j * p.ldq];
+  }
+  __syncthreads();
+  mm64(sC, false, sB, false, sD);                                       // sD = Q top = Qt_top R2^-1
+  __syncthreads();
+  if (t < 64) {
+    // LU of (Q_top - S) without pivoting, S(j,j) = -sign(pivot) so that |pivot| >= 1 (in place:
+    // strictly lower = L1, upper = U)
+    for (int j = 0; j < SB; ++j) {
+      double acc = sD[j * LD + lane];
+      for (int k = 0; k < j; ++k) acc -= sD[j * LD + k] * sD[k * LD + lane];
+      double piv = __shfl(acc, j, 64);
+      const double sj = (piv >= 0.0) ? -1.0 : 1.0;
+      piv -= sj;
+      if (lane == j) { acc = piv; s_sign[j] = sj; }
+      if (lane >= j) sD[j * LD + lane] = acc;
+      wave_sync();
+      double accl = sD[lane * LD + j];
+      for (int k = 0; k < j; ++k) accl -= sD[lane * LD + k] * sD[k * LD + j];
+      if (lane > j) sD[lane * LD + j] = accl / piv;
+      wave_sync();
+    }
+    // T = -U S L1^-T, by rows: L1 t^T = c^T; kept transposed (sC(j, i) = T(i, j)), lane = i
+    for (int j = 0; j < SB; ++j) {
+      double acc = (lane <= j) ? -sD[lane * LD + j] * s_sign[j] : 0.0;
+      for (int k = 0; k < j; ++k) acc -= sD[j * LD + k] * sC[k * LD + lane];
+      sC[j * LD + lane] = acc;
+      wave_sync();
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    p.T[idx] = sC[j * LD + i];
+    p.L1[idx] = (i > j) ? sD[i * LD + j] : (i == j ? 1.0 : 0.0);
+    if (i == j) p.tau[i] = sC[i * LD + i];
+  }
+  __syncthreads();
+  for (int idx = t; idx < IMG; idx += 256) sC[idx] = 0.0;
+  __syncthreads();
+  if (t < 64) triinv64_upper(sD, sC, lane);                             // sC = U^-1
+  __syncthreads();
+  mm64(sB, false, sC, false, nullptr, p.M2);                            // M2 = R2^-1 U^-1
+  __syncthreads();
+  for (int idx = t; idx < SB * SB; idx += 256) {                        // sC = R1
+    const int i = idx & 63, j = idx >> 6;
+    sC[i * LD + j] = p.R1[idx];
+  }
+  __syncthreads();
+  mm64(sA, false, sC, false, nullptr, p.Rband, s_sign);                 // S R2 R1
+}
+
+// ---------------------------------------------------------------- panel with few rows: Householder
+// QR inside one workgroup (any rank, any m <= 256).  Same outputs as the CholeskyQR2 chain.
+struct SmallArgs {
+  int m;
+  double *Apanel; int lda; double *Vall; int ldv; double *Vimg; int ldi;
+  double *T, *tau;
+};
+constexpr int SMALL_MAX = 192;
+__global__ __launch_bounds__(256) void house_small_kernel(SmallArgs p) {
+  extern __shared__ double smem[];
+  double *sP = smem;                       // m x 64 panel, row-major (LD)
+  double *sT = smem + SMALL_MAX * LD;      // T, row-major
+  __shared__ double s_tau[SB], s_g[SB], s_red[8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = p.m;
+  for (int idx = t; idx < SMALL_MAX * SB; idx += 256) {
+    const int r = idx % SMALL_MAX, c = idx / SMALL_MAX;
+    sP[r * LD + c] = (r < m) ? p.Apanel[(size_t)r + (size_t)c * p.lda] : 0.0;
+  }
+  for (int idx = t; idx < IMG; idx += 256) sT[idx] = 0.0;
+  __syncthreads();
+  for (int j = 0; j < SB; ++j) {
+    double tau = 0.0;
+    if (j < m - 1) {
+      // DLARFG on x = P(j:m, j)
+      double ssq = 0.0;
+      for (int r = j + 1 + t; r < m; r += 256) { const double x = sP[r * LD + j]; ssq += x * x; }
+      for (int o = 32; o > 0; o >>= 1) ssq += __shfl_down(ssq, o, 64);
+      if (lane == 0) s_red[wave] = ssq;
+      __syncthreads();
+      ssq = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+      const double alpha = sP[j * LD + j];
+      __syncthreads();
+      if (ssq != 0.0) {
+        const double beta = -copysign(hypot(alpha, sqrt(ssq)), alpha);
+        tau = (beta - alpha) / beta;
+        const double scale = 1.0 / (alpha - beta);
+        for (int r = j + 1 + t; r < m; r += 256) sP[r * LD + j] *= scale;
+        if (t == 0) sP[j * LD + j] = beta;
+      }
+      __syncthreads();
+      // apply H_j to the columns c > j: one thread per column
+      if (tau != 0.0 && t > j && t < SB) {
+        double w = sP[j * LD + t];
+        for (int r = j + 1; r < m; ++r) w += sP[r * LD + j] * sP[r * LD + t];
+        w *= tau;
+        sP[j * LD + t] -= w;
+        for (int r = j + 1; r < m; ++r) sP[r * LD + t] -= w * sP[r * LD + j];
+      }
+    }
+    if (t == 0) s_tau[j] = tau;
+    __syncthreads();
+  }
+  // T (DLARFT, forward columnwise): T(i,i) = tau_i, T(0:i, i) = -tau_i T(0:i,0:i) (V^T v_i)
+  for (int i = 0; i < SB; ++i) {
+    const double ti = s_tau[i];
+    if (t < i) {
+      double g = (i < m) ? sP[i * LD + t] : 0.0;          // v_t(i) * v_i(i) with v_i(i) = 1 (row i < m)
+      for (int r = i + 1; r < m; ++r) g += sP[r * LD + t] * sP[r * LD + i];
+      s_g[t] = g;
+    }
+    __syncthreads();
+    if (t < i) {
+      double a = 0.0;
+      for (int l = t; l < i; ++l) a += sT[t * LD + l] * s_g[l];
+      sT[t * LD + i] = -ti * a;
+    } else if (t == i) sT[i * LD + i] = ti;
+    __syncthreads();
+  }
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    p.T[idx] = sT[i * LD + j];
+    if (i == j) p.tau[i] = s_tau[i];
+  }
+  for (int idx = t; idx < m * SB; idx += 256) {
+    const int r = idx % m, c = idx / m;
+    const double x = sP[r * LD + c];
+    // reflector c exists for c < m - 1 (else v = 0: the column of V is empty, tau = 0)
+    const double v = (c < m - 1) ? ((r > c) ? x : (r == c ? 1.0 : 0.0)) : 0.0;
+    p.Vall[(size_t)r + (size_t)c * p.ldv] = v;
+    p.Vimg[(size_t)r + (size_t)(SB + c) * p.ldi] = v;
+    p.Apanel[(size_t)r + (size_t)c * p.lda] = (r <= c || c >= m - 1) ? x : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------- Y = A22 V on the lower triangle
+// Workgroup (rb, ks): rows 128 rb .. of Ypart[ks] = sum over the K tiles kt of its split of
+// tile(rb, kt) V(kt rows), where tile(rb, kt) is read as stored for kt < rb, transposed from
+// tile(kt, rb) for kt > rb, and mixed on the diagonal: every tile of the lower triangle is read
+// twice per panel (once by its row's workgroups, once by its column's), never the upper triangle.
+struct SymmArgs {
+  int m; const double *A; int lda;      // A22 (m x m, lower)
+  const double *V; int ldv;             // m x 64
+  double *Ypart; int ldy; long long sY; // per split: m x 64
+  int T, tiles_per_split;
+};
+constexpr int BK = 16, MC_LD = 128 + 16, KC_LD = BK + 1;
+constexpr int A_TILE = (BK * MC_LD > 128 * KC_LD) ? BK * MC_LD : 128 * KC_LD;
+constexpr int V_LD = BK + 1;            // V slab: 64 x 16, K-contiguous image s[n][17]
+
+__global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
+  __shared__ double sA[A_TILE], sV[SB * V_LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int rb = blockIdx.x, ks = blockIdx.y;
+  const int kt0 = ks * p.tiles_per_split;
+  int kt1 = kt0 + p.tiles_per_split; if (kt1 > p.T) kt1 = p.T;
+  const int m0 = rb * 128;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+  double4_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double ra[8], rv[4];
+  // element (x, k) of the operand slab [m0 + x, kg] with kg = global k index
+  auto load_a = [&](int kt, int k0) {
+    const int mode = (kt < rb) ? 0 : (kt > rb ? 1 : 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = t + 256 * i;
+      int x, k;
+      if (mode == 1) { k = idx & 15; x = idx >> 4; } else { x = idx & 127; k = idx >> 7; }
+      const int gx = m0 + x, gk = kt * 128 + k0 + k;
+      double v = 0.0;
+      if (gx < p.m && gk < p.m) {
+        const bool low = (mode == 0) || (mode == 2 && gx >= gk);
+        v = low ? p.A[(size_t)gx + (size_t)gk * p.lda] : p.A[(size_t)gk + (size_t)gx * p.lda];
+      }
+      ra[i] = v;
+    }
+  };
+  auto load_v = [&](int kt, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + 256 * i, k = idx & 15, nn = idx >> 4;
+      const int gk = kt * 128 + k0 + k;
+      rv[i] = (gk < p.m) ? p.V[(size_t)gk + (size_t)nn * p.ldv] : 0.0;
+    }
+  };
+  if (kt0 < kt1) { load_a(kt0, 0); load_v(kt0, 0); }
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool kc = kt > rb;     // K-contiguous image of the A slab (transposed tile)
+    for (int k0 = 0; k0 < 128; k0 += BK) {
+      if (kt * 128 + k0 >= p.m) break;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = t + 256 * i;
+        if (kc) { const int k = idx & 15, x = idx >> 4; sA[x * KC_LD + k] = ra[i]; }
+        else    { const int x = idx & 127, k = idx >> 7; sA[k * MC_LD + x] = ra[i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int idx = t + 256 * i, k = idx & 15, nn = idx >> 4; sV[nn * V_LD + k] = rv[i]; }
+      __syncthreads();
+      // next slab (possibly of the next tile) in flight during the MFMAs
+      int nkt = kt, nk0 = k0 + BK;
+      if (nk0 >= 128 || kt * 128 + nk0 >= p.m) { nkt = kt + 1; nk0 = 0; }
+      if (nkt < kt1 && nkt * 128 + nk0 < p.m) { load_a(nkt, nk0); load_v(nkt, nk0); }
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 4) {
+        double fa[4], fb[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int x = wm + i * 16 + l15, k = kk + l4;
+          fa[i] = kc ? sA[x * KC_LD + k] : sA[k * MC_LD + x];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fb[i] = sV[(wn + i * 16 + l15) * V_LD + kk + l4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+      }
+    }
+  }
+  double *Y = p.Ypart + (size_t)ks * p.sY;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int mrow = m0 + wm + mi * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = wn + ni * 16 + l4 + 4 * r;
+        if (mrow < p.m) Y[(size_t)mrow + (size_t)nn * p.ldy] = acc[ni][mi][r];
+      }
+    }
+}
+
+// Y = sum of the split-K partials (kept), Gp = V_chunk^T Y_chunk per workgroup
+struct YredArgs {
+  int m, nsplit;
+  const double *Ypart; int ldy; long long sY;
+  double *Y;                 // m x 64, ld = ldy
+  const double *V; int ldv;
+  double *Gpart;
+};
+__global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
+  __shared__ double sY[IMG], sV[IMG];
+  const int t = threadIdx.x, r = t & 63, cg = t >> 6;
+  double4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int slab = 0; slab < CH / SB; ++slab) {
+    const int row0 = blockIdx.x * CH + slab * SB;
+    if (row0 >= p.m) break;
+    const int row = row0 + r;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int col = 16 * cg + c;
+      double y = 0.0, v = 0.0;
+      if (row < p.m) {
+        for (int s = 0; s < p.nsplit; ++s) y += p.Ypart[(size_t)s * p.sY + (size_t)row + (size_t)col * p.ldy];
+        p.Y[(size_t)row + (size_t)col * p.ldy] = y;
+        v = p.V[(size_t)row + (size_t)col * p.ldv];
+      }
+      sY[r * LD + col] = y; sV[r * LD + col] = v;
+    }
+    __syncthreads();
+    slab_gram(sV, sY, acc);
+  }
+  store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
+}
+
+// G = sum of the partials of V^T Y; Mw = [T ; -1/2 T^T G T] (128 x 64, column-major ld 128)
+__global__ __launch_bounds__(256) void wmat_kernel(int npart, const double *__restrict__ Gpart,
+                                                   const double *__restrict__ T, double *__restrict__ Mw) {
+  __shared__ double sG[IMG], sT[IMG], sX[IMG];
+  const int t = threadIdx.x;
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    // partials are stored (j + 64 i) = G(i, j)
+    double a0 = 0.0, a1 = 0.0;
+    int q = 0;
+    for (; q + 1 < npart; q += 2) { a0 += Gpart[(size_t)q * 4096 + idx]; a1 += Gpart[(size_t)(q + 1) * 4096 + idx]; }
+    if (q < npart) a0 += Gpart[(size_t)q * 4096 + idx];
+    const int j = idx & 63, i = idx >> 6;
+    sG[i * LD + j] = a0 + a1;
+    const double tv = T[idx];                 // column-major: idx = i' + 64 j'
+    sT[(idx & 63) * LD + (idx >> 6)] = tv;
+    Mw[(idx & 63) + 128 * (idx >> 6)] = tv;
+  }
+  __syncthreads();
+  mm64(sG, false, sT, false, sX);             // X = G T
+  __syncthreads();
+  mm64(sT, true, sX, false, sG);              // S' = T^T X
+  __syncthreads();
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    Mw[64 + i + 128 * j] = -0.5 * sG[i * LD + j];
+  }
+}
+
+// W = [Y | V] Mw, written to columns 0..63 and 128..191 of the image [W | V | W]
+struct WArgs {
+  int m;
+  const double *Y; int ldy; const double *V; int ldv; const double *Mw;
+  double *Vimg; int ldi;
+};
+__global__ __launch_bounds__(256) void w_kernel(WArgs p) {
+  __shared__ double sS[IMG], sM1[IMG], sM2[IMG];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4, r = t & 63, cg = t >> 6;
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int k = idx & 63, j = idx >> 6;
+    sM1[j * LD + k] = p.Mw[k + 128 * j];
+    sM2[j * LD + k] = p.Mw[64 + k + 128 * j];
+  }
+  for (int slab = 0; slab < CH / SB; ++slab) {
+    const int row0 = blockIdx.x * CH + slab * SB;
+    if (row0 >= p.m) break;
+    const int row = row0 + r, i0 = 16 * wave;
+    double4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int pass = 0; pass < 2; ++pass) {
+      const double *src = pass ? p.V : p.Y;
+      const int lds_ = pass ? p.ldv : p.ldy;
+      const double *sM = pass ? sM2 : sM1;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int col = 16 * cg + c;
+        sS[r * LD + col] = (row < p.m) ? src[(size_t)row + (size_t)col * lds_] : 0.0;
+      }
+      __syncthreads();
+      for (int kk = 0; kk < SB; kk += 4) {
+        const double x = sS[(i0 + l15) * LD + kk + l4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+          acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, sM[(16 * jt + l15) * LD + kk + l4], acc[jt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sS[(i0 + l4 + 4 * q) * LD + 16 * jt + l15] = acc[jt][q];
+    __syncthreads();
+    if (row < p.m) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int col = 16 * cg + c;
+        const double w = sS[r * LD + col];
+        p.Vimg[(size_t)row + (size_t)col * p.ldi] = w;
+        p.Vimg[(size_t)row + (size_t)(2 * SB + col) * p.ldi] = w;
+      }
+    }
+  }
+}
+
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct Layout {
+  int mpad, nparts, maxsplit;
+  size_t off_img, off_qt, off_y, off_ypart, off_gpart, off_small, total;
+  explicit Layout(int n) {
+    mpad = round_up(n > 0 ? n : 1, 128);
+    nparts = mpad / CH + 1;
+    maxsplit = 8;
+    size_t o = 0;
+    off_img = o; o += al256((size_t)mpad * 3 * SB * 8);
+    off_qt = o; o += al256((size_t)mpad * SB * 8);
+    off_y = o; o += al256((size_t)mpad * SB * 8);
+    off_ypart = o; o += al256((size_t)maxsplit * mpad * SB * 8);
+    off_gpart = o; o += al256((size_t)nparts * SB * SB * 8);
+    off_small = o; o += al256((size_t)16 * SB * SB * 8);
+    total = o;
+  }
+};
+
+}  // namespace
+
+size_t sy2sb_work_bytes(int n) { return Layout(n).total; }
+
+void sy2sb_lower(hipStream_t s, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
+                 int *d_flag, void *work) {
+  if (n <= 2) return;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)hr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * IMG * (int)sizeof(double));
+    (void)hipFuncSetAttribute((const void *)house_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (SMALL_MAX * LD + IMG) * (int)sizeof(double));
+    attr = true;
+  }
+  const Layout L(n);
+  char *w = (char *)work;
+  double *Vimg = (double *)(w + L.off_img), *Qt = (double *)(w + L.off_qt), *Y = (double *)(w + L.off_y);
+  double *Ypart = (double *)(w + L.off_ypart), *Gpart = (double *)(w + L.off_gpart);
+  double *sm = (double *)(w + L.off_small);
+  double *Gred = sm, *R1 = sm + 4096, *R1inv = sm + 2 * 4096, *M2 = sm + 3 * 4096, *Tm = sm + 4 * 4096,
+         *L1 = sm + 5 * 4096, *Rband = sm + 6 * 4096, *Mw = sm + 7 * 4096 /* 2 x 4096 */;
+  const int ldi = L.mpad;
+  for (int c0 = 0; ; c0 += SB) {
+    const int r0 = c0 + SB, m = n - r0;
+    if (m < 2) break;
+    double *Ap = A + (size_t)r0 + (size_t)c0 * lda;
+    double *Vp = Vall + (size_t)r0 + (size_t)c0 * ldv;
+    const int nch = ceil_div(m, CH);
+    if (m <= SMALL_MAX) {
+      SmallArgs sa{m, Ap, lda, Vp, ldv, Vimg, ldi, Tm, tau1 + c0};
+      hipLaunchKernelGGL(house_small_kernel, dim3(1), dim3(256), (SMALL_MAX * LD + IMG) * sizeof(double), s, sa);
+    } else {
+      PanelArgs pa{};
+      pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = Gpart;
+      hipLaunchKernelGGL(panel_kernel<0>, dim3(nch), dim3(256), 0, s, pa);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, s, nch, Gpart, Gred);
+      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, s, Gred, R1, R1inv, d_flag);
+      pa.M = R1inv; pa.dst = Qt; pa.ldd = L.mpad;
+      hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, s, pa);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, s, nch, Gpart, Gred);
+      HrArgs ha{Gred, Qt, L.mpad, R1, M2, Tm, L1, Rband, tau1 + c0, d_flag};
+      hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), s, ha);
+      PanelArgs pf{};
+      pf.m = m; pf.src = Qt; pf.lds_ = L.mpad; pf.M = M2; pf.L1 = L1; pf.Rband = Rband;
+      pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vimg = Vimg; pf.ldi = ldi;
+      hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, s, pf);
+    }
+    // Y = A22 V, split over K so that the launch fills the chip
+    double *A22 = A + (size_t)r0 + (size_t)r0 * lda;
+    const double *V = Vimg + (size_t)SB * ldi;
+    const int T = ceil_div(m, 128);
+    int nsplit = (T >= 256) ? 2 : ceil_div(512, T);
+    if (nsplit > L.maxsplit) nsplit = L.maxsplit;
+    if (nsplit > T) nsplit = T;
+    const int tps = ceil_div(T, nsplit);
+    nsplit = ceil_div(T, tps);
+    SymmArgs sy{m, A22, lda, V, ldi, Ypart, L.mpad, (long long)L.mpad * SB, T, tps};
+    hipLaunchKernelGGL(symm_lower_kernel, dim3(T, nsplit), dim3(256), 0, s, sy);
+    YredArgs ya{m, nsplit, Ypart, L.mpad, (long long)L.mpad * SB, Y, V, ldi, Gpart};
+    hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
+    hipLaunchKernelGGL(wmat_kernel, dim3(1), dim3(256), 0, s, nch, Gpart, Tm, Mw);
+    WArgs wa{m, Y, L.mpad, V, ldi, Mw, Vimg, ldi};
+    hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
+    // A22 -= W V^T + V W^T = [W | V] [V | W]^T, lower triangle
+    gemm(s, false, true, m, m, 2 * SB, -1.0, Vimg, ldi, Vimg + (size_t)SB * ldi, ldi, 1.0, A22, lda, true);
+  }
+}
+
+}  // namespace ek

@@ -110,6 +110,9 @@ def load_library(path=None):
         "ek_hip_debug_sytrd_at": (c_int, [c_int, c_int, c_int, vp, vp, vp, _dp]),
         "ek_hip_debug_reduce_team": (c_int, [c_int, c_int, c_int, _dp]),
         "ek_hip_profile_symv_get": (c_int, [_dp, ctypes.POINTER(ctypes.c_longlong), _dp]),
+        "ek_hip_debug_sy2sb": (c_int, [c_int, _dp, c_int, _dp, c_int, _dp, _ip]),
+        "ek_hip_debug_sb2st": (c_int, [c_int, _dp, c_int, _dp, _dp, _dp, c_int, c_int, _ip]),
+        "ek_hip_debug_two_stage_timing": (c_int, [c_int, c_int, c_int, _dp, _ip]),
     }
     for name, (res, args) in sigs.items():
         try:
