@@ -264,6 +264,17 @@ void rccl_allgatherv(hipStream_t s, int nmem, int, double *const *bufs, const si
 
 constexpr int kPotrfRlMin = 1024;
 
+// Orders from which the whole-path call tridiagonalises in two stages (dense -> band on the matrix
+// cores, band -> tridiagonal by bulge chasing; ek_sy2sb.hip, ek_sb2st.hip) instead of the one-stage
+// Householder reduction.  EK_HIP_TWO_STAGE_MIN overrides (0 = never); ek_hip_debug_set_two_stage too.
+int g_two_stage_min = -1;
+int two_stage_min() {
+  if (g_two_stage_min >= 0) return g_two_stage_min;
+  static int env = -2;
+  if (env == -2) { const char *e = getenv("EK_HIP_TWO_STAGE_MIN"); env = e ? atoi(e) : -1; }
+  return env >= 0 ? env : 3072;
+}
+
 // From how many ranks on the Cholesky factor and the reduction to standard form are distributed
 // as well (below that their replicated forms are cheaper); EK_HIP_DIST_MIN_RANKS overrides (tests).
 int dist_min_ranks() {
@@ -1199,6 +1210,8 @@ int ek_hip_debug_sb2st(int n, const double *A, int lda, double *d, double *e, do
   return 0;
 }
 
+int ek_hip_debug_set_two_stage(int min_order) { g_two_stage_min = min_order; return 0; }   // -1: default
+
 // Timing of the two-stage pieces on a device-generated synthetic matrix of order n:
 // seconds[0] dense -> band, [1] band -> tridiagonal, [2] Q2 applied to ncols columns, [3] Q1 applied.
 int ek_hip_debug_two_stage_timing(int n, int ncols, int reps, double *seconds, int *flag) {
@@ -1514,8 +1527,14 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   size_t potrf_wb = (problem == 1 && dist) ? al(potrf_dist_work_bytes(n, ld, g_comm.nranks)) : 0;
   if (potrf_rl && al(potrf_rl_work_bytes(n, ld)) > potrf_wb) potrf_wb = al(potrf_rl_work_bytes(n, ld));
   int rc = 0;
+  // two-stage tridiagonalisation: one more matrix for the reflectors of the bulge chasing, a copy of
+  // the reduced matrix for the (rare) fall-back to the one-stage path, and the stages' own scratch
+  const int ts_min = two_stage_min();
+  const bool two_stage = !dist && ts_min > 0 && n >= ts_min && n >= 3;
+  const size_t wb_sy2sb = two_stage ? al(sy2sb_work_bytes(n)) : 0, wb_sb2st = two_stage ? al(sb2st_work_bytes(n)) : 0;
   const size_t ws_need = 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
-                         4 * al((size_t)ld * 8) + sygst_scr + potrf_wb;
+                         4 * al((size_t)ld * 8) + sygst_scr + potrf_wb +
+                         (two_stage ? 2 * mat + wb_sy2sb + wb_sb2st + al((size_t)ld * 8) : 0);
   rc = workspace(ws_need, &ws);
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
@@ -1529,8 +1548,13 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
   double *sscr = (problem == 1) ? a.get<double>(sygst_dbl) : nullptr;
   char *pwork = potrf_wb ? a.get<char>(potrf_wb) : nullptr;
+  double *wV2 = two_stage ? a.get<double>((size_t)ld * ld) : nullptr;
+  double *wA0 = two_stage ? a.get<double>((size_t)ld * ld) : nullptr;
+  char *work_sy2sb = two_stage ? a.get<char>(wb_sy2sb) : nullptr;
+  char *work_sb2st = two_stage ? a.get<char>(wb_sb2st) : nullptr;
+  double *dt1 = two_stage ? a.get<double>(ld) : nullptr;
   // where the tridiagonalisation keeps x, the panel and its partial sums (probed once per workspace)
-  void *sytrd_work = choose_sytrd_scratch(n, ld, wA, work, dd, wb_sytrd);
+  void *sytrd_work = two_stage ? (void *)work : choose_sytrd_scratch(n, ld, wA, work, dd, wb_sytrd);
 
   StageTimer tm;
   const bool timing = stage_seconds && n_stages > 0;
@@ -1591,9 +1615,29 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     }
   }
   mark();                                                              // 3
+  bool two_stage_done = false;
   if (dist) {
     const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
     sytrd_lower_dist(s, n, 1, &me, team_exchange(0));
+  } else if (two_stage) {
+    // dense -> band -> tridiagonal.  The panel factorisation of the first stage is CholeskyQR2 with a
+    // device-side check; a matrix it cannot handle (rank-deficient or very ill-conditioned panels,
+    // e.g. an input that is already banded) takes the one-stage path from a copy instead.
+    EK_HIP_CHECK(hipMemcpyAsync(wA0, wA, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
+    EK_HIP_CHECK(hipMemsetAsync(wV2, 0, (size_t)ld * ld * 8, s));
+    EK_HIP_CHECK(hipMemsetAsync(dt1, 0, (size_t)ld * 8, s));
+    sy2sb_lower(s, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
+    sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st);
+    int flag = 0;
+    EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    if (flag == 0) two_stage_done = true;
+    else {
+      EK_HIP_CHECK(hipMemcpyAsync(wA, wA0, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
+      EK_HIP_CHECK(hipMemsetAsync(wV, 0, (size_t)ld * ld * 8, s));
+      EK_HIP_CHECK(hipMemsetAsync(dd, 0, 3 * al((size_t)ld * 8), s));
+      sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
+    }
   } else {
     sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
   }
@@ -1605,7 +1649,12 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick);
   mark();                                                              // 5
   double *zc = wZ;
-  ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work);
+  if (two_stage_done) {
+    sb2st_apply_q2(s, n, nc_loc, wV2, ld, zc, ld, work_sb2st);
+    ormtr_lower(s, n, nc_loc, wV, ld, dt1, zc, ld, work);
+  } else {
+    ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work);
+  }
   mark();                                                              // 6
   if (problem == 1) trsm_llt(s, n, nc_loc, wB, ld, dInv, zc, ld, twork);
   mark();                                                              // 7

@@ -77,19 +77,28 @@ struct ChaseArgs {
   double *tau2; int ldt;
   unsigned *prog;        // [nsweeps] tasks completed per sweep
   unsigned *ctl;         // [0] ticket, [1] abort
+  int extra;             // extra distance (tasks) a sweep keeps from its predecessor beyond the 3 it must
+  long long *prof;       // optional: [0..5] shader cycles per phase of a task summed over workgroup 0's tasks, [6] tasks
 };
 
 constexpr unsigned kSpinLimit = 1u << 22;
 
+// Per task the workgroup synchronises three times; the progress word of task k-1 is published in
+// the middle of task k (its stores have drained by then: nobody stalls on the write-through), and
+// the gate of task k+1 is looked at without blocking while task k computes, so that its blocks are
+// already in flight when the task starts.
 __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
-  __shared__ double s_v[SB], s_w[SB], s_z[SB];
-  __shared__ double s_p[4][SB];
+  __shared__ double s_v[SB];
+  __shared__ double s_p[4][SB], s_q[4][SB];
   __shared__ double s_t[4][16 * 65];
   __shared__ double s_D[SB * DLD];
+  __shared__ double s_z[SB];
   __shared__ double s_tau;
-  __shared__ int s_sweep, s_ok;
+  __shared__ int s_sweep, s_ok, s_gate;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n = p.n;
+  const int c0w = 16 * wave;                               // this wave's columns of a block
+  const bool immediate = p.extra < 0;                      // publish every task at its end, no look-ahead
   double *AB = p.AB;
   while (true) {
     __syncthreads();
@@ -99,42 +108,50 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
     if (s >= p.nsweeps) break;
     const int K = (n - 3 - s) / SB + 1;
     const int Kprev = (s > 0) ? (n - 2 - s) / SB + 1 : 0;
-    double bp[16];
+    double bp[16], dl[16], bk[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) bp[j] = 0.0;
+    for (int j = 0; j < 16; ++j) { bp[j] = 0.0; dl[j] = 0.0; bk[j] = 0.0; }
+    bool have_pf = false;
     for (int k = 0; k < K; ++k) {
-      // ---- wait until sweep s-1 is far enough ahead
-      if (t == 0) {
-        int ok = 1;
-        if (s > 0) {
-          const unsigned need = (unsigned)((k + 3 < Kprev) ? k + 3 : Kprev);
-          unsigned spins = 0;
-          while (__hip_atomic_load(&p.prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63u) == 0u &&
-                (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-              ok = 0; break;
-            }
-          }
-        }
-        if (!ok) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ok = ok;
-      }
-      __syncthreads();
-      if (!s_ok) return;
       const int i0 = s + 1 + k * SB;                       // first index of I_k
       const int L = (n - i0 < SB) ? n - i0 : SB;           // its length (>= 2)
-      const int i1 = i0 + SB;                              // first index of I_{k+1}
-      int L1 = n - i1; if (L1 > SB) L1 = SB; if (L1 < 0) L1 = 0;
-      const int c0w = 16 * wave;                           // this wave's columns of a block
-      // ---- prefetch D_k (lower part of row `lane`) and B_k (row `lane`)
-      double dl[16], bk[16];
+      int L1 = n - i0 - SB; if (L1 > SB) L1 = SB; if (L1 < 0) L1 = 0;
+      long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
+      const bool prof = p.prof && blockIdx.x == 0 && t == 0;
+      if (prof) tc0 = clock64();
+      if (!have_pf) {
+        // ---- blocking wait until sweep s-1 is far enough ahead, then fetch D_k and B_k
+        if (t == 0) {
+          int ok = 1;
+          if (s > 0) {
+            const int ex = immediate ? 0 : p.extra;
+            const unsigned need = (unsigned)((k + 3 + ex < Kprev) ? k + 3 + ex : Kprev);
+            unsigned spins = 0;
+            while (__hip_atomic_load(&p.prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+              __builtin_amdgcn_s_sleep(1);
+              if ((++spins & 63u) == 0u &&
+                  (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                ok = 0; break;
+              }
+            }
+          }
+          if (!ok) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) return;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int c = c0w + j;
-        dl[j] = (lane < L && c <= lane) ? ld_sc1(AB + (size_t)(lane - c) + (size_t)(i0 + c) * LDAB) : 0.0;
-        bk[j] = (lane < L1 && c < L) ? ld_sc1(AB + (size_t)(SB + lane - c) + (size_t)(i0 + c) * LDAB) : 0.0;
+        for (int j = 0; j < 16; ++j) {
+          const int c = c0w + j;
+          dl[j] = (lane < L && c <= lane) ? ld_sc1(AB + (size_t)(lane - c) + (size_t)(i0 + c) * LDAB) : 0.0;
+          bk[j] = (lane < L1 && c < L) ? ld_sc1(AB + (size_t)(SB + lane - c) + (size_t)(i0 + c) * LDAB) : 0.0;
+        }
       }
+      if (prof) tc1 = clock64();
+      // a first, non-blocking look at the gate of task k+1 (the value arrives while this task computes)
+      unsigned gate_val = 0;
+      if (t == 0 && s > 0 && k + 1 < K)
+        gate_val = __hip_atomic_load(&p.prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // ---- (a) the reflector: x = A(I_k, s) for k = 0, else the first column of B_{k-1}
       if (wave == 0) {
         double x = 0.0;
@@ -146,7 +163,7 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
         const double alpha0 = __shfl(x, 0, 64);
         double beta = alpha0, tau = 0.0, scale = 0.0;
         if (ssq != 0.0) {
-          beta = -copysign(hypot(alpha0, sqrt(ssq)), alpha0);
+          beta = -copysign(sqrt(alpha0 * alpha0 + ssq), alpha0);   // the path keeps |A| within 1e+-90
           tau = (beta - alpha0) / beta;
           scale = 1.0 / (alpha0 - beta);
         }
@@ -158,7 +175,8 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
         if (k == 0) { if (lane < L) st_sc1(AB + (size_t)(1 + lane) + (size_t)s * LDAB, xnew); }
         else bp[0] = xnew;
       }
-      __syncthreads();
+      __syncthreads();                                                       // #1
+      if (prof) tc2 = clock64();
       const double tau = s_tau;
       const double v_r = s_v[lane];
       double vc[16];
@@ -190,41 +208,63 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
           if (lane < L) st_sc1(AB + (size_t)(SB + lane - c) + (size_t)(ip + c) * LDAB, bp[j]);
         }
       }
-      // ---- (c) D_k <- H D_k H
+      // ---- D_k as a full symmetric image
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int c = c0w + j;
         if (c <= lane) { s_D[lane * DLD + c] = dl[j]; s_D[c * DLD + lane] = dl[j]; }
       }
-      __syncthreads();
+      // everything task k-1 stored (and the blocks of this task) has arrived: its progress can be told
+      if (k > 0 && !immediate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                                       // #2
+      if (prof) tc3 = clock64();
+      if (t == 0 && k > 0 && !immediate)
+        __hip_atomic_store(&p.prog[s], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // ---- partial sums of p = D v and q = B_k v
       double dd[16];
-      double part = 0.0;
+      {
+        double pp = 0.0, qq = 0.0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { dd[j] = s_D[lane * DLD + c0w + j]; part += dd[j] * vc[j]; }
-      s_p[wave][lane] = part;
-      __syncthreads();
+        for (int j = 0; j < 16; ++j) { dd[j] = s_D[lane * DLD + c0w + j]; pp += dd[j] * vc[j]; qq += bk[j] * vc[j]; }
+        s_p[wave][lane] = pp; s_q[wave][lane] = qq;
+      }
+      if (t == 0) {
+        const unsigned need = (unsigned)((k + 4 + p.extra < Kprev) ? k + 4 + p.extra : Kprev);
+        s_gate = !immediate && (k + 1 < K) && (s == 0 || gate_val >= need);
+      }
+      __syncthreads();                                                       // #3
+      if (prof) tc4 = clock64();
+      // ---- blocks of task k+1 into flight if its gate is already open
+      const bool gate = s_gate != 0;
+      double ndl[16], nbk[16];
+      if (gate) {
+        const int j0 = i0 + SB;
+        const int Ln = (n - j0 < SB) ? n - j0 : SB;
+        int L1n = n - j0 - SB; if (L1n > SB) L1n = SB; if (L1n < 0) L1n = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int c = c0w + j;
+          ndl[j] = (lane < Ln && c <= lane) ? ld_sc1(AB + (size_t)(lane - c) + (size_t)(j0 + c) * LDAB) : 0.0;
+          nbk[j] = (lane < L1n && c < Ln) ? ld_sc1(AB + (size_t)(SB + lane - c) + (size_t)(j0 + c) * LDAB) : 0.0;
+        }
+      }
+      // ---- (c) D_k <- H D_k H
       const double p_r = tau * ((s_p[0][lane] + s_p[1][lane]) + (s_p[2][lane] + s_p[3][lane]));
       double dot = p_r * v_r;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) dot += __shfl_xor(dot, o, 64);
-      const double w_r = p_r - 0.5 * tau * dot * v_r;
-      if (wave == 0) s_w[lane] = w_r;
-      __syncthreads();
+      const double alpha = -0.5 * tau * dot;
+      const double w_r = p_r + alpha * v_r;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int c = c0w + j;
-        dd[j] -= v_r * s_w[c] + w_r * vc[j];
+        const double w_c = tau * ((s_p[0][c] + s_p[1][c]) + (s_p[2][c] + s_p[3][c])) + alpha * vc[j];
+        dd[j] -= v_r * w_c + w_r * vc[j];
         if (c <= lane && lane < L) st_sc1(AB + (size_t)(lane - c) + (size_t)(i0 + c) * LDAB, dd[j]);
       }
       // ---- (d) B_k <- B_k H (rows I_{k+1}, columns I_k); carried to the next task in registers
       if (L1 > 0) {
-        double q = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) q += bk[j] * vc[j];
-        __syncthreads();                                   // s_p is reused
-        s_p[wave][lane] = q;
-        __syncthreads();
-        const double q_r = tau * ((s_p[0][lane] + s_p[1][lane]) + (s_p[2][lane] + s_p[3][lane]));
+        const double q_r = tau * ((s_q[0][lane] + s_q[1][lane]) + (s_q[2][lane] + s_q[3][lane]));
 #pragma unroll
         for (int j = 0; j < 16; ++j) bp[j] = bk[j] - q_r * vc[j];
         if (k == K - 1) {                                  // no further task in this sweep: store it now
@@ -235,18 +275,34 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
           }
         }
       }
-      // ---- publish: all stores of the task have completed before the progress word moves
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (t == 0) __hip_atomic_store(&p.prog[s], (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prof) {
+        const long long tc5 = clock64();
+        p.prof[0] += tc1 - tc0; p.prof[1] += tc2 - tc1; p.prof[2] += tc3 - tc2; p.prof[3] += tc4 - tc3;
+        p.prof[4] += tc5 - tc4; p.prof[6] += 1;
+      }
+      have_pf = gate;
+      if (gate) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { dl[j] = ndl[j]; bk[j] = nbk[j]; }
+      }
+      if (immediate && k + 1 < K) {        // tell the follower at once (the last task is told below)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(&p.prog[s], (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
+    // ---- the last task of the sweep: publish once its stores have completed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&p.prog[s], (unsigned)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-// ------------------------------------------------------------------------ Q2: T factors
+// ------------------------------------------------------------------------ Q2: compact-WY factors
 constexpr int QG = 32;                 // sweeps per compact-WY block
 constexpr int QR = QG + SB;            // rows of a block's window (95 used, 96 with padding)
 constexpr int QVLD = QG + 1;           // LDS leading dimension of the V image (row-major)
+constexpr int QREC = 2 * QR * QG;      // doubles per group record: V (96 x 32, column-major), then V T
 
 struct Q2Geom {
   int n, nsweeps, nS, kmax;            // kmax: groups per block of sweeps (uniform index S * kmax + k)
@@ -266,17 +322,22 @@ __device__ __forceinline__ double q2_v_entry(const Q2Geom &g, const double *__re
   return V2[(size_t)row + (size_t)s * ldv2];
 }
 
+// One wave per group: T (DLARFT, forward columnwise) from the reflectors and their tau, then the
+// record [V | V T] the application streams.
 __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *__restrict__ V2, int ldv2,
                                                         const double *__restrict__ tau2, int ldt,
-                                                        double *__restrict__ Tall) {
+                                                        double *__restrict__ Rec) {
   __shared__ double sV[QR * QVLD];
   __shared__ double sT[QG * QVLD];
   __shared__ double s_g[QG];
   const int S = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
   if (k >= q2_groups_of_block(g.n, S)) return;
+  double *rec = Rec + ((size_t)S * g.kmax + k) * QREC;
   for (int idx = lane; idx < QR * QG; idx += 64) {
     const int rr = idx % QR, i = idx / QR;
-    sV[rr * QVLD + i] = q2_v_entry(g, V2, ldv2, S, k, rr, i);
+    const double v = q2_v_entry(g, V2, ldv2, S, k, rr, i);
+    sV[rr * QVLD + i] = v;
+    rec[idx] = v;
   }
   for (int idx = lane; idx < QG * QVLD; idx += 64) sT[idx] = 0.0;
   wave_sync();
@@ -285,9 +346,16 @@ __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *
     const bool exists = s < g.nsweeps && s + 1 + k * SB <= g.n - 2;
     const double ti = exists ? tau2[(size_t)k + (size_t)s * ldt] : 0.0;
     if (lane < i) {                              // g_a = v_a^T v_i over the common rows [i, a + SB)
-      double acc = 0.0;
-      for (int rr = i; rr < lane + SB; ++rr) acc += sV[rr * QVLD + lane] * sV[rr * QVLD + i];
-      s_g[lane] = acc;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int rr = i;
+      for (; rr + 3 < lane + SB; rr += 4) {
+        a0 += sV[rr * QVLD + lane] * sV[rr * QVLD + i];
+        a1 += sV[(rr + 1) * QVLD + lane] * sV[(rr + 1) * QVLD + i];
+        a2 += sV[(rr + 2) * QVLD + lane] * sV[(rr + 2) * QVLD + i];
+        a3 += sV[(rr + 3) * QVLD + lane] * sV[(rr + 3) * QVLD + i];
+      }
+      for (; rr < lane + SB; ++rr) a0 += sV[rr * QVLD + lane] * sV[rr * QVLD + i];
+      s_g[lane] = (a0 + a1) + (a2 + a3);
     }
     wave_sync();
     if (lane < i) {
@@ -297,98 +365,117 @@ __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *
     } else if (lane == i) sT[i * QVLD + i] = ti;
     wave_sync();
   }
-  double *T = Tall + ((size_t)S * g.kmax + k) * QG * QG;
-  for (int idx = lane; idx < QG * QG; idx += 64) T[idx] = sT[(idx % QG) * QVLD + idx / QG];   // column-major
+  // V T: row rr of the product by lane rr (and rr + 64)
+  for (int rr = lane; rr < QR; rr += 64) {
+    double vrow[QG];
+#pragma unroll
+    for (int l = 0; l < QG; ++l) vrow[l] = sV[rr * QVLD + l];
+    for (int j = 0; j < QG; ++j) {
+      double a = 0.0;
+#pragma unroll
+      for (int l = 0; l < QG; ++l) a += vrow[l] * sT[l * QVLD + j];     // T upper triangular: zeros below
+      rec[QR * QG + rr + QR * j] = a;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------ Q2: application
-// Workgroup = QNC columns of Z; per block of sweeps S (descending) and k (ascending):
-//   W1 = V^T Zw,  W2 = T W1,  Zw -= V W2      on the window Zw = Z(o : o+96, columns)
-constexpr int QNC = 32;
-constexpr int QZLD = QNC + 2;          // LDS window, row-major
+// Workgroup (512 threads) = QNC columns of Z.  For a block of sweeps S the windows of consecutive k
+// slide down the rows by 64: window k = chunk k (64 rows from S*32 + 1 + 64 k) + the first 32 rows
+// of chunk k+1.  Two chunks live in LDS; chunk k+2 and the record of group k+1 are in flight in
+// registers while group k is applied:  W1 = V^T Zw  (32 x 64),  Zw -= (V T) W1.
+constexpr int QNC = 64;
+constexpr int QZLD = QNC + 2;          // LDS chunk, row-major
 constexpr int QWLD = QNC + 2;
 
 struct Q2ApplyArgs {
   Q2Geom g;
-  const double *V2; int ldv2;
-  const double *Tall;
+  const double *Rec;
   double *Z; int ldz; int ncols;
 };
 
-__global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
-  __shared__ double sZ[QR * QZLD];
-  __shared__ double sV[QR * QVLD];
-  __shared__ double sT[QG * QVLD];
-  __shared__ double sW1[QG * QWLD], sW2[QG * QWLD];
+__global__ __launch_bounds__(512) void q2_apply_kernel(Q2ApplyArgs p) {
+  extern __shared__ double q2smem[];
+  double *sZ = q2smem;                                  // 2 chunks x 64 rows x QZLD
+  double *sV = sZ + 2 * SB * QZLD;                      // 96 x QVLD
+  double *sVT = sV + QR * QVLD;
+  double *sW1 = sVT + QR * QVLD;                        // 32 x QWLD
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int col0 = blockIdx.x * QNC;
   const int n = p.g.n;
-  double vreg[12], treg[4];
-  auto fetch = [&](int S, int k) {       // operands of group (S, k) into registers
+  double rreg[12], zreg[8];
+  auto fetch_rec = [&](int S, int k) {
+    const double *rec = p.Rec + ((size_t)S * p.g.kmax + k) * QREC;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) rreg[q] = rec[t + 512 * q];
+  };
+  auto put_rec = [&]() {
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
-      const int idx = t + 256 * q, rr = idx % QR, i = idx / QR;
-      vreg[q] = q2_v_entry(p.g, p.V2, p.ldv2, S, k, rr, i);
+      const int idx = t + 512 * q, half = idx / (QR * QG), e = idx % (QR * QG), rr = e % QR, i = e / QR;
+      (half ? sVT : sV)[rr * QVLD + i] = rreg[q];
     }
-    const double *T = p.Tall + ((size_t)S * p.g.kmax + k) * QG * QG;
+  };
+  // chunk j of the pass over block S: rows S*QG + 1 + 64 j ..; thread -> (row = t & 63, 8 columns t >> 6 + 8 q)
+  auto fetch_chunk = [&](int S, int j) {
+    const int row = S * QG + 1 + SB * j + (t & 63);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) treg[q] = T[t + 256 * q];
+    for (int q = 0; q < 8; ++q) {
+      const int col = col0 + (t >> 6) + 8 * q;
+      zreg[q] = (row < n && col < p.ncols) ? p.Z[(size_t)row + (size_t)col * p.ldz] : 0.0;
+    }
+  };
+  auto put_chunk = [&](int slot) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sZ[(slot * SB + (t & 63)) * QZLD + (t >> 6) + 8 * q] = zreg[q];
+  };
+  auto store_chunk = [&](int S, int j, int slot) {
+    const int row = S * QG + 1 + SB * j + (t & 63);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int col = col0 + (t >> 6) + 8 * q;
+      if (row < n && col < p.ncols) p.Z[(size_t)row + (size_t)col * p.ldz] = sZ[(slot * SB + (t & 63)) * QZLD + (t >> 6) + 8 * q];
+    }
   };
   for (int S = p.g.nS - 1; S >= 0; --S) {
     const int KS = q2_groups_of_block(n, S);
-    if (KS > 0) fetch(S, 0);
+    if (KS <= 0) continue;
+    __syncthreads();
+    fetch_chunk(S, 0); put_chunk(0);
+    fetch_chunk(S, 1); put_chunk(1);
+    fetch_rec(S, 0);
     for (int k = 0; k < KS; ++k) {
-      const int o = S * QG + 1 + k * SB;
+      const int s0 = k & 1, s1 = s0 ^ 1;              // slots of chunk k and chunk k+1
+      put_rec();
       __syncthreads();
-      // operands -> LDS; window of Z -> LDS
-#pragma unroll
-      for (int q = 0; q < 12; ++q) { const int idx = t + 256 * q, rr = idx % QR, i = idx / QR; sV[rr * QVLD + i] = vreg[q]; }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const int idx = t + 256 * q; sT[(idx % QG) * QVLD + idx / QG] = treg[q]; }
-      for (int idx = t; idx < QR * QNC; idx += 256) {
-        const int rr = idx % QR, c = idx / QR, row = o + rr, col = col0 + c;
-        sZ[rr * QZLD + c] = (row < n && col < p.ncols) ? p.Z[(size_t)row + (size_t)col * p.ldz] : 0.0;
-      }
-      __syncthreads();
-      if (k + 1 < KS) fetch(S, k + 1);
-      // W1 (32 x 32) = V^T Zw: wave -> one 16x16 tile
-      {
+      if (k + 1 < KS) { fetch_rec(S, k + 1); fetch_chunk(S, k + 2); }
+      // window row rr -> LDS row
+      auto zrow = [&](int rr) { return (rr < SB) ? (s0 * SB + rr) : (s1 * SB + rr - SB); };
+      {   // W1 (32 x 64) = V^T Zw: 2 x 4 tiles, one per wave
         const int it = wave & 1, jt = wave >> 1;
         double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
         for (int kk = 0; kk < QR; kk += 4)
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(kk + l4) * QVLD + 16 * it + l15],
-                                                     sZ[(kk + l4) * QZLD + 16 * jt + l15], acc, 0, 0, 0);
+                                                     sZ[zrow(kk + l4) * QZLD + 16 * jt + l15], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) sW1[(16 * it + l4 + 4 * r) * QWLD + 16 * jt + l15] = acc[r];
       }
       __syncthreads();
-      // W2 = T W1
-      {
-        const int it = wave & 1, jt = wave >> 1;
-        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-        for (int kk = 0; kk < QG; kk += 4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sT[(16 * it + l15) * QVLD + kk + l4],
-                                                     sW1[(kk + l4) * QWLD + 16 * jt + l15], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sW2[(16 * it + l4 + 4 * r) * QWLD + 16 * jt + l15] = acc[r];
-      }
-      __syncthreads();
-      // Zw -= V W2: 6 x 2 tiles, 3 per wave
+      // Zw -= (V T) W1: 6 x 4 tiles, three per wave
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int tile = wave * 3 + q, it = tile % 6, jt = tile / 6;
         double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
         for (int kk = 0; kk < QG; kk += 4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(16 * it + l15) * QVLD + kk + l4],
-                                                     sW2[(kk + l4) * QWLD + 16 * jt + l15], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sVT[(16 * it + l15) * QVLD + kk + l4],
+                                                     sW1[(kk + l4) * QWLD + 16 * jt + l15], acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sZ[(16 * it + l4 + 4 * r) * QZLD + 16 * jt + l15] -= acc[r];
+        for (int r = 0; r < 4; ++r) sZ[zrow(16 * it + l4 + 4 * r) * QZLD + 16 * jt + l15] -= acc[r];
       }
       __syncthreads();
-      for (int idx = t; idx < QR * QNC; idx += 256) {
-        const int rr = idx % QR, c = idx / QR, row = o + rr, col = col0 + c;
-        if (row < n && col < p.ncols) p.Z[(size_t)row + (size_t)col * p.ldz] = sZ[rr * QZLD + c];
-      }
+      store_chunk(S, k, s0);                           // chunk k is final for this block of sweeps
+      if (k + 1 < KS) put_chunk(s0);                   // chunk k+2 takes its slot
+      else store_chunk(S, k + 1, s1);
     }
   }
 }
@@ -410,7 +497,7 @@ struct Layout {
     off_tau = o; o += al256((size_t)ldt * (nsweeps + 1) * 8);
     off_prog = o; o += al256((size_t)(nsweeps + 1) * 4);
     off_ctl = o; o += 256;
-    off_T = o; o += al256((size_t)nS * kmax * QG * QG * 8);
+    off_T = o; o += al256((size_t)nS * kmax * QREC * 8);
     total = o;
   }
 };
@@ -434,15 +521,25 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
   (void)hipMemsetAsync(prog, 0, (size_t)(L.nsweeps + 1) * 4 + 0, s);
   (void)hipMemsetAsync(ctl, 0, 256, s);
   if (L.nsweeps > 0) {
-    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl};
+    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, -1, nullptr};
+    if (getenv("EK_SB2ST_PROF")) { c.prof = (long long *)(ctl + 16); }
+    if (const char *ev = getenv("EK_SB2ST_EXTRA")) c.extra = atoi(ev);
     // enough workgroups for the pipeline (a sweep can start three tasks behind its predecessor)
-    int nwg = n / (3 * SB) + 8;
+    int nwg = n / ((3 + (c.extra > 0 ? c.extra : 0)) * SB) + 8;
     if (nwg > 256) nwg = 256;
     if (nwg > L.nsweeps) nwg = L.nsweeps;
     if (const char *ev = getenv("EK_SB2ST_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
     hipLaunchKernelGGL(chase_kernel, dim3(nwg), dim3(256), 0, s, c);
   }
   hipLaunchKernelGGL(unpack_de_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, AB, d, e);
+  if (getenv("EK_SB2ST_PROF")) {
+    long long h[8];
+    (void)hipMemcpyAsync(h, ctl + 16, sizeof(h), hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    fprintf(stderr, "[sb2st prof] tasks %lld; cycles per task: gate+loads %.0f, reflector %.0f, left-apply+fill %.0f, "
+            "partials %.0f, updates %.0f\n", h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6],
+            (double)h[3] / h[6], (double)h[4] / h[6]);
+  }
   hipLaunchKernelGGL(forward_abort_kernel, dim3(1), dim3(1), 0, s, ctl, d_flag);   // abort word -> caller's flag
 }
 
@@ -452,11 +549,14 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   const Layout L(n);
   char *w = (char *)work;
   const double *tau2 = (const double *)(w + L.off_tau);
-  double *Tall = (double *)(w + L.off_T);
+  double *Rec = (double *)(w + L.off_T);
   Q2Geom g{n, L.nsweeps, L.nS, L.kmax};
-  hipLaunchKernelGGL(q2_tfactor_kernel, dim3(L.kmax, L.nS), dim3(64), 0, s, g, V2, ldv2, tau2, L.ldt, Tall);
-  Q2ApplyArgs a{g, V2, ldv2, Tall, Z, ldz, ncols};
-  hipLaunchKernelGGL(q2_apply_kernel, dim3(ceil_div(ncols, QNC)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(q2_tfactor_kernel, dim3(L.kmax, L.nS), dim3(64), 0, s, g, V2, ldv2, tau2, L.ldt, Rec);
+  constexpr size_t lds = (size_t)(2 * SB * QZLD + 2 * QR * QVLD + QG * QWLD) * sizeof(double);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)q2_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  Q2ApplyArgs a{g, Rec, Z, ldz, ncols};
+  hipLaunchKernelGGL(q2_apply_kernel, dim3(ceil_div(ncols, QNC)), dim3(512), lds, s, a);
 }
 
 }  // namespace ek

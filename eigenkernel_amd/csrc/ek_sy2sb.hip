@@ -70,13 +70,28 @@ __device__ __forceinline__ void mm64(const double *sA, bool ta, const double *sB
     }
 }
 
+// sum_{k in [k0, k1)} a(k) b(k) with eight independent partial sums: the LDS reads of eight terms are
+// in flight together (the plain loop waits for every pair of reads: 50 cycles per term)
+template <typename FA, typename FB>
+__device__ __forceinline__ double dot8(int k0, int k1, FA a, FB b) {
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, c4 = 0.0, c5 = 0.0, c6 = 0.0, c7 = 0.0;
+  int k = k0;
+  for (; k + 7 < k1; k += 8) {
+    const double x0 = a(k), x1 = a(k + 1), x2 = a(k + 2), x3 = a(k + 3), x4 = a(k + 4), x5 = a(k + 5), x6 = a(k + 6), x7 = a(k + 7);
+    const double y0 = b(k), y1 = b(k + 1), y2 = b(k + 2), y3 = b(k + 3), y4 = b(k + 4), y5 = b(k + 5), y6 = b(k + 6), y7 = b(k + 7);
+    c0 += x0 * y0; c1 += x1 * y1; c2 += x2 * y2; c3 += x3 * y3; c4 += x4 * y4; c5 += x5 * y5; c6 += x6 * y6; c7 += x7 * y7;
+  }
+  for (; k < k1; ++k) c0 += a(k) * b(k);
+  return ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
+}
+
 // Wave 0: upper Cholesky factor in place, G = R^T R (row j of R from rows 0..j-1: lane = column).
 // Returns false (all lanes) when a pivot is not positive.
 __device__ __forceinline__ bool chol64_upper(double *sG, int lane) {
   bool ok = true;
   for (int j = 0; j < SB; ++j) {
-    double acc = sG[j * LD + lane];
-    for (int k = 0; k < j; ++k) acc -= sG[k * LD + j] * sG[k * LD + lane];
+    const double acc = sG[j * LD + lane] -
+        dot8(0, j, [&](int k) { return sG[k * LD + j]; }, [&](int k) { return sG[k * LD + lane]; });
     double d = __shfl(acc, j, 64);
     if (!(d > 0.0) || !(d < 1.7e308)) { ok = false; d = 1.0; }
     const double rjj = sqrt(d);
@@ -92,8 +107,8 @@ __device__ __forceinline__ bool chol64_upper(double *sG, int lane) {
 // Wave 0: X = R^-1 for upper triangular R (only its upper triangle is read).  sX must be zero.
 __device__ __forceinline__ void triinv64_upper(const double *sR, double *sX, int lane) {
   for (int i = SB - 1; i >= 0; --i) {
-    double acc = 0.0;
-    for (int k = i + 1; k < SB; ++k) acc += sR[i * LD + k] * sX[k * LD + lane];   // X(k, c) = 0 for k > c
+    const double acc = dot8(i + 1, SB, [&](int k) { return sR[i * LD + k]; },
+                            [&](int k) { return sX[k * LD + lane]; });            // X(k, c) = 0 for k > c
     const double rii = sR[i * LD + i];
     if (lane >= i) sX[i * LD + lane] = (lane == i) ? 1.0 / rii : -acc / rii;
     wave_sync();
@@ -255,6 +270,7 @@ struct HrArgs {
   const double *G2; const double *Qt; int ldq; const double *R1;
   double *M2, *T, *L1, *Rband, *tau;
   int *flag;
+  long long *prof;   // optional: shader cycles per phase
 };
 __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   extern __shared__ double smem[];
@@ -262,6 +278,9 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   __shared__ double s_sign[SB];
   __shared__ double s_red[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  long long tc[10]; int nt = 0;
+  const bool prof = p.prof && t == 0;
+  if (prof) tc[nt++] = clock64();
   // G2 and its distance from the identity: the loss of orthogonality of the first pass
   double dev = 0.0;
   for (int idx = t; idx < SB * SB; idx += 256) {
@@ -280,9 +299,12 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
     for (int w = 0; w < 4; ++w) dmax = (s_red[w] > dmax || s_red[w] != s_red[w]) ? s_red[w] : dmax;
     if (!(dmax <= 0.25)) atomicExch(p.flag, 2);
   }
+  if (prof) tc[nt++] = clock64();
   if (t < 64) {
     if (!chol64_upper(sA, lane) && lane == 0) atomicExch(p.flag, 1);   // sA = R2
+    if (prof) tc[nt++] = clock64();
     triinv64_upper(sA, sB, lane);                                       // sB = R2^-1
+    if (prof) tc[nt++] = clock64();
   }
   for (int idx = t; idx < SB * SB; idx += 256) {                        // sC = top block of Qt
     const int i = idx & 63, j = idx >> 6;
@@ -291,27 +313,29 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   __syncthreads();
   mm64(sC, false, sB, false, sD);                                       // sD = Q top = Qt_top R2^-1
   __syncthreads();
+  if (prof) tc[nt++] = clock64();
   if (t < 64) {
     // LU of (Q_top - S) without pivoting, S(j,j) = -sign(pivot) so that |pivot| >= 1 (in place:
     // strictly lower = L1, upper = U)
     for (int j = 0; j < SB; ++j) {
-      double acc = sD[j * LD + lane];
-      for (int k = 0; k < j; ++k) acc -= sD[j * LD + k] * sD[k * LD + lane];
+      double acc = sD[j * LD + lane] -
+          dot8(0, j, [&](int k) { return sD[j * LD + k]; }, [&](int k) { return sD[k * LD + lane]; });
       double piv = __shfl(acc, j, 64);
       const double sj = (piv >= 0.0) ? -1.0 : 1.0;
       piv -= sj;
       if (lane == j) { acc = piv; s_sign[j] = sj; }
       if (lane >= j) sD[j * LD + lane] = acc;
       wave_sync();
-      double accl = sD[lane * LD + j];
-      for (int k = 0; k < j; ++k) accl -= sD[lane * LD + k] * sD[k * LD + j];
+      const double accl = sD[lane * LD + j] -
+          dot8(0, j, [&](int k) { return sD[lane * LD + k]; }, [&](int k) { return sD[k * LD + j]; });
       if (lane > j) sD[lane * LD + j] = accl / piv;
       wave_sync();
     }
+    if (prof) tc[nt++] = clock64();
     // T = -U S L1^-T, by rows: L1 t^T = c^T; kept transposed (sC(j, i) = T(i, j)), lane = i
     for (int j = 0; j < SB; ++j) {
-      double acc = (lane <= j) ? -sD[lane * LD + j] * s_sign[j] : 0.0;
-      for (int k = 0; k < j; ++k) acc -= sD[j * LD + k] * sC[k * LD + lane];
+      const double acc = ((lane <= j) ? -sD[lane * LD + j] * s_sign[j] : 0.0) -
+          dot8(0, j, [&](int k) { return sD[j * LD + k]; }, [&](int k) { return sC[k * LD + lane]; });
       sC[j * LD + lane] = acc;
       wave_sync();
     }
@@ -326,7 +350,9 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   __syncthreads();
   for (int idx = t; idx < IMG; idx += 256) sC[idx] = 0.0;
   __syncthreads();
+  if (prof) tc[nt++] = clock64();
   if (t < 64) triinv64_upper(sD, sC, lane);                             // sC = U^-1
+  if (prof) tc[nt++] = clock64();
   __syncthreads();
   mm64(sB, false, sC, false, nullptr, p.M2);                            // M2 = R2^-1 U^-1
   __syncthreads();
@@ -336,6 +362,7 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   }
   __syncthreads();
   mm64(sA, false, sC, false, nullptr, p.Rband, s_sign);                 // S R2 R1
+  if (prof) { tc[nt++] = clock64(); for (int q = 0; q + 1 < nt; ++q) p.prof[q] += tc[q + 1] - tc[q]; p.prof[9] += 1; }
 }
 
 // ---------------------------------------------------------------- panel with few rows: Householder
@@ -552,7 +579,11 @@ __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
       const int col = 16 * cg + c;
       double y = 0.0, v = 0.0;
       if (row < p.m) {
-        for (int s = 0; s < p.nsplit; ++s) y += p.Ypart[(size_t)s * p.sY + (size_t)row + (size_t)col * p.ldy];
+        const double *yp = p.Ypart + (size_t)row + (size_t)col * p.ldy;
+        double ys[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) ys[s] = (s < p.nsplit) ? yp[(size_t)s * p.sY] : 0.0;
+        y = ((ys[0] + ys[1]) + (ys[2] + ys[3])) + ((ys[4] + ys[5]) + (ys[6] + ys[7]));
         p.Y[(size_t)row + (size_t)col * p.ldy] = y;
         v = p.V[(size_t)row + (size_t)col * p.ldv];
       }
@@ -565,18 +596,13 @@ __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
 }
 
 // G = sum of the partials of V^T Y; Mw = [T ; -1/2 T^T G T] (128 x 64, column-major ld 128)
-__global__ __launch_bounds__(256) void wmat_kernel(int npart, const double *__restrict__ Gpart,
+__global__ __launch_bounds__(256) void wmat_kernel(const double *__restrict__ Gred,
                                                    const double *__restrict__ T, double *__restrict__ Mw) {
   __shared__ double sG[IMG], sT[IMG], sX[IMG];
   const int t = threadIdx.x;
   for (int idx = t; idx < SB * SB; idx += 256) {
-    // partials are stored (j + 64 i) = G(i, j)
-    double a0 = 0.0, a1 = 0.0;
-    int q = 0;
-    for (; q + 1 < npart; q += 2) { a0 += Gpart[(size_t)q * 4096 + idx]; a1 += Gpart[(size_t)(q + 1) * 4096 + idx]; }
-    if (q < npart) a0 += Gpart[(size_t)q * 4096 + idx];
-    const int j = idx & 63, i = idx >> 6;
-    sG[i * LD + j] = a0 + a1;
+    const int j = idx & 63, i = idx >> 6;       // stored (j + 64 i) = G(i, j)
+    sG[i * LD + j] = Gred[idx];
     const double tv = T[idx];                 // column-major: idx = i' + 64 j'
     sT[(idx & 63) * LD + (idx >> 6)] = tv;
     Mw[(idx & 63) + 128 * (idx >> 6)] = tv;
@@ -664,7 +690,7 @@ struct Layout {
     off_y = o; o += al256((size_t)mpad * SB * 8);
     off_ypart = o; o += al256((size_t)maxsplit * mpad * SB * 8);
     off_gpart = o; o += al256((size_t)nparts * SB * SB * 8);
-    off_small = o; o += al256((size_t)16 * SB * SB * 8);
+    off_small = o; o += al256((size_t)16 * SB * SB * 8);   // [10 * 4096 ..): profile counters
     total = o;
   }
 };
@@ -692,6 +718,7 @@ void sy2sb_lower(hipStream_t s, int n, double *A, int lda, double *Vall, int ldv
   double *Gred = sm, *R1 = sm + 4096, *R1inv = sm + 2 * 4096, *M2 = sm + 3 * 4096, *Tm = sm + 4 * 4096,
          *L1 = sm + 5 * 4096, *Rband = sm + 6 * 4096, *Mw = sm + 7 * 4096 /* 2 x 4096 */;
   const int ldi = L.mpad;
+  if (getenv("EK_SY2SB_PROF")) (void)hipMemsetAsync(sm + 10 * 4096, 0, 128, s);
   for (int c0 = 0; ; c0 += SB) {
     const int r0 = c0 + SB, m = n - r0;
     if (m < 2) break;
@@ -710,7 +737,8 @@ void sy2sb_lower(hipStream_t s, int n, double *A, int lda, double *Vall, int ldv
       pa.M = R1inv; pa.dst = Qt; pa.ldd = L.mpad;
       hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, s, pa);
       hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, s, nch, Gpart, Gred);
-      HrArgs ha{Gred, Qt, L.mpad, R1, M2, Tm, L1, Rband, tau1 + c0, d_flag};
+      HrArgs ha{Gred, Qt, L.mpad, R1, M2, Tm, L1, Rband, tau1 + c0, d_flag, nullptr};
+      if (getenv("EK_SY2SB_PROF")) ha.prof = (long long *)(sm + 10 * 4096);
       hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), s, ha);
       PanelArgs pf{};
       pf.m = m; pf.src = Qt; pf.lds_ = L.mpad; pf.M = M2; pf.L1 = L1; pf.Rband = Rband;
@@ -730,11 +758,21 @@ void sy2sb_lower(hipStream_t s, int n, double *A, int lda, double *Vall, int ldv
     hipLaunchKernelGGL(symm_lower_kernel, dim3(T, nsplit), dim3(256), 0, s, sy);
     YredArgs ya{m, nsplit, Ypart, L.mpad, (long long)L.mpad * SB, Y, V, ldi, Gpart};
     hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
-    hipLaunchKernelGGL(wmat_kernel, dim3(1), dim3(256), 0, s, nch, Gpart, Tm, Mw);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, s, nch, Gpart, Gred);
+    hipLaunchKernelGGL(wmat_kernel, dim3(1), dim3(256), 0, s, Gred, Tm, Mw);
     WArgs wa{m, Y, L.mpad, V, ldi, Mw, Vimg, ldi};
     hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
     // A22 -= W V^T + V W^T = [W | V] [V | W]^T, lower triangle
     gemm(s, false, true, m, m, 2 * SB, -1.0, Vimg, ldi, Vimg + (size_t)SB * ldi, ldi, 1.0, A22, lda, true);
+  }
+  if (getenv("EK_SY2SB_PROF")) {
+    long long h[10];
+    (void)hipMemcpyAsync(h, sm + 10 * 4096, sizeof(h), hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    if (h[9] > 0)
+      fprintf(stderr, "[hr_kernel prof] calls %lld; cycles: load %.0f chol %.0f inv %.0f qtop-mm %.0f lu %.0f tsolve+out %.0f "
+              "uinv %.0f mm2 %.0f\n", h[9], (double)h[0] / h[9], (double)h[1] / h[9], (double)h[2] / h[9], (double)h[3] / h[9],
+              (double)h[4] / h[9], (double)h[5] / h[9], (double)h[6] / h[9], (double)h[7] / h[9]);
   }
 }
 

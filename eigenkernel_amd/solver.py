@@ -113,6 +113,7 @@ def load_library(path=None):
         "ek_hip_debug_sy2sb": (c_int, [c_int, _dp, c_int, _dp, c_int, _dp, _ip]),
         "ek_hip_debug_sb2st": (c_int, [c_int, _dp, c_int, _dp, _dp, _dp, c_int, c_int, _ip]),
         "ek_hip_debug_two_stage_timing": (c_int, [c_int, c_int, c_int, _dp, _ip]),
+        "ek_hip_debug_set_two_stage": (c_int, [c_int]),
     }
     for name, (res, args) in sigs.items():
         try:
