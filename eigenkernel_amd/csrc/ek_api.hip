@@ -43,7 +43,13 @@ int ensure_init() {
   }
   EK_HIP_CHECK(hipSetDevice(g_ctx.device));
   EK_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-  EK_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream2, hipStreamNonBlocking));
+  {
+    // the look-ahead stream carries short latency-bound chains beside a chip-filling GEMM: its
+    // workgroups must be dispatched first
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    EK_HIP_CHECK(hipStreamCreateWithPriority(&g_ctx.stream2, hipStreamNonBlocking, hi));
+  }
   EK_HIP_CHECK(hipMalloc((void **)&g_ctx.d_info, 64 * sizeof(int)));
   g_ctx.ready = true;
   return 0;
@@ -1156,7 +1162,7 @@ int ek_hip_debug_sy2sb(int n, double *A, int lda, double *V, int ldv, double *ta
   EK_HIP_CHECK(hipMemsetAsync(dt, 0, (size_t)ld * 8, s));
   EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, 4 * sizeof(int), s));
   rc = h2d_matrix(n, n, A, lda, dA, ld, s); if (rc) return rc;
-  sy2sb_lower(s, n, dA, ld, dV, ld, dt, g_ctx.d_info + 2, work);
+  sy2sb_lower(s, g_ctx.stream2, n, dA, ld, dV, ld, dt, g_ctx.d_info + 2, work);
   EK_HIP_CHECK(hipGetLastError());
   rc = d2h_matrix(n, n, dA, ld, A, lda, s); if (rc) return rc;
   rc = d2h_matrix(n, n, dV, ld, V, ldv, s); if (rc) return rc;
@@ -1241,7 +1247,7 @@ int ek_hip_debug_two_stage_timing(int n, int ncols, int reps, double *seconds, i
     synth_matrix(s, n, 1, dA, ld);
     set_matrix(s, n, ncols, 0.0, 1.0, dZ, ld);
     EK_HIP_CHECK(hipEventRecord(ev[0], s));
-    sy2sb_lower(s, n, dA, ld, dV, ld, dt, g_ctx.d_info + 2, w1);
+    sy2sb_lower(s, g_ctx.stream2, n, dA, ld, dV, ld, dt, g_ctx.d_info + 2, w1);
     EK_HIP_CHECK(hipEventRecord(ev[1], s));
     sb2st_lower(s, n, dA, ld, dd, de, dV2, ld, g_ctx.d_info + 2, w2);
     EK_HIP_CHECK(hipEventRecord(ev[2], s));
@@ -1626,7 +1632,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     EK_HIP_CHECK(hipMemcpyAsync(wA0, wA, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
     EK_HIP_CHECK(hipMemsetAsync(wV2, 0, (size_t)ld * ld * 8, s));
     EK_HIP_CHECK(hipMemsetAsync(dt1, 0, (size_t)ld * 8, s));
-    sy2sb_lower(s, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
+    sy2sb_lower(s, g_ctx.stream2, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
     sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st);
     int flag = 0;
     EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));

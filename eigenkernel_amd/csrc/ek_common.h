@@ -205,7 +205,8 @@ size_t sy2sb_work_bytes(int n);
 // Vall (n x n, ldv; must be zero on entry): explicit reflectors, column j = v_j with its unit entry
 // at row j + 64; tau1[j] (must be zero on entry).  *d_flag (device int, 0 on entry) becomes non-zero if
 // a panel could not be factored by CholeskyQR2 (the caller then falls back to the one-stage path).
-void sy2sb_lower(hipStream_t s, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
+// s2: second stream, the panel factorisation of the next panel runs on it beside the trailing update.
+void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
                  int *d_flag, void *work);
 
 size_t sb2st_work_bytes(int n);

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
       if (prof) tc1 = clock64();
       // a first, non-blocking look at the gate of task k+1 (the value arrives while this task computes)
       unsigned gate_val = 0;
-      if (t == 0 && s > 0 && k + 1 < K)
+      if (!immediate && t == 0 && s > 0 && k + 1 < K)
         gate_val = __hip_atomic_load(&p.prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // ---- (a) the reflector: x = A(I_k, s) for k = 0, else the first column of B_{k-1}
       if (wave == 0) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
 constexpr int QG = 32;                 // sweeps per compact-WY block
 constexpr int QR = QG + SB;            // rows of a block's window (95 used, 96 with padding)
 constexpr int QVLD = QG + 1;           // LDS leading dimension of the V image (row-major)
-constexpr int QREC = 2 * QR * QG;      // doubles per group record: V (96 x 32, column-major), then V T
+constexpr int QREC = 2 * QR * QG;      // doubles per group record: V (96 x 32, column-major), then -(V T)
 
 struct Q2Geom {
   int n, nsweeps, nS, kmax;            // kmax: groups per block of sweeps (uniform index S * kmax + k)
@@ -374,19 +374,25 @@ __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *
       double a = 0.0;
 #pragma unroll
       for (int l = 0; l < QG; ++l) a += vrow[l] * sT[l * QVLD + j];     // T upper triangular: zeros below
-      rec[QR * QG + rr + QR * j] = a;
+      rec[QR * QG + rr + QR * j] = -a;
     }
   }
 }
 
 // ------------------------------------------------------------------------ Q2: application
-// Workgroup (512 threads) = QNC columns of Z.  For a block of sweeps S the windows of consecutive k
-// slide down the rows by 64: window k = chunk k (64 rows from S*32 + 1 + 64 k) + the first 32 rows
-// of chunk k+1.  Two chunks live in LDS; chunk k+2 and the record of group k+1 are in flight in
-// registers while group k is applied:  W1 = V^T Zw  (32 x 64),  Zw -= (V T) W1.
+// Workgroup (4 waves) = 64 columns of Z, every wave streams its own 16 columns down the rows and
+// keeps its window of Z in REGISTERS: the accumulator layout of v_mfma_f64_16x16x4 (D(i,j) in lane
+// (j = lane & 15, i = lane / 16 + 4 reg)) is also the layout of its second operand for the k-step
+// over rows 4 reg .. 4 reg + 3, so the same registers serve as the operand of W1 = V^T Zw and as the
+// accumulator of Zw += (-V T) W1, and W1 itself goes from the first product into the second without
+// leaving the registers.  Only the factors [V | -V T] of a group pass through LDS (double buffered,
+// one workgroup barrier per group); rows enter and leave through a small per-wave transposing buffer.
+// For a block of sweeps S the windows of consecutive k slide down by 64 rows: window k = chunk k
+// (64 rows from S*32 + 1 + 64 k) + the first 32 rows of chunk k+1; two chunks are in registers,
+// chunk k+2 and the record of group k+1 are in flight while group k is applied.
 constexpr int QNC = 64;
-constexpr int QZLD = QNC + 2;          // LDS chunk, row-major
-constexpr int QWLD = QNC + 2;
+constexpr int QSTLD = 17;
+constexpr int QOPSZ = 2 * QR * QVLD;   // doubles per operand buffer: V image, then -V T image (row-major, QVLD)
 
 struct Q2ApplyArgs {
   Q2Geom g;
@@ -394,88 +400,96 @@ struct Q2ApplyArgs {
   double *Z; int ldz; int ncols;
 };
 
-__global__ __launch_bounds__(512) void q2_apply_kernel(Q2ApplyArgs p) {
+__global__ __launch_bounds__(256) void q2_apply_kernel(Q2ApplyArgs p) {
   extern __shared__ double q2smem[];
-  double *sZ = q2smem;                                  // 2 chunks x 64 rows x QZLD
-  double *sV = sZ + 2 * SB * QZLD;                      // 96 x QVLD
-  double *sVT = sV + QR * QVLD;
-  double *sW1 = sVT + QR * QVLD;                        // 32 x QWLD
+  double *sOp = q2smem;                                 // 2 operand buffers
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int col0 = blockIdx.x * QNC;
+  double *st = q2smem + 2 * QOPSZ + wave * 64 * QSTLD;  // this wave's transposing buffer (64 x 16)
+  const int colw = blockIdx.x * QNC + 16 * wave;
   const int n = p.g.n;
-  double rreg[12], zreg[8];
-  auto fetch_rec = [&](int S, int k) {
+  double4_t za[4], zb[4];
+  double zreg[16], oreg[24];
+  auto fetch_ops = [&](int S, int k) {
     const double *rec = p.Rec + ((size_t)S * p.g.kmax + k) * QREC;
 #pragma unroll
-    for (int q = 0; q < 12; ++q) rreg[q] = rec[t + 512 * q];
+    for (int q = 0; q < 24; ++q) oreg[q] = rec[t + 256 * q];
   };
-  auto put_rec = [&]() {
+  auto put_ops = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 12; ++q) {
-      const int idx = t + 512 * q, half = idx / (QR * QG), e = idx % (QR * QG), rr = e % QR, i = e / QR;
-      (half ? sVT : sV)[rr * QVLD + i] = rreg[q];
+    for (int q = 0; q < 24; ++q) {
+      const int idx = t + 256 * q, half = idx / (QR * QG), e = idx % (QR * QG), rr = e % QR, i = e / QR;
+      sOp[buf * QOPSZ + half * QR * QVLD + rr * QVLD + i] = oreg[q];
     }
   };
-  // chunk j of the pass over block S: rows S*QG + 1 + 64 j ..; thread -> (row = t & 63, 8 columns t >> 6 + 8 q)
   auto fetch_chunk = [&](int S, int j) {
-    const int row = S * QG + 1 + SB * j + (t & 63);
+    const int row = S * QG + 1 + SB * j + lane;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int col = col0 + (t >> 6) + 8 * q;
-      zreg[q] = (row < n && col < p.ncols) ? p.Z[(size_t)row + (size_t)col * p.ldz] : 0.0;
-    }
+    for (int c = 0; c < 16; ++c)
+      zreg[c] = (row < n && colw + c < p.ncols) ? p.Z[(size_t)row + (size_t)(colw + c) * p.ldz] : 0.0;
   };
-  auto put_chunk = [&](int slot) {
+  auto chunk_to_tiles = [&](double4_t (&z)[4]) {       // zreg (row per lane) -> accumulator layout
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sZ[(slot * SB + (t & 63)) * QZLD + (t >> 6) + 8 * q] = zreg[q];
+    for (int c = 0; c < 16; ++c) st[lane * QSTLD + c] = zreg[c];
+    wave_sync();
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[tt][r] = st[(16 * tt + l4 + 4 * r) * QSTLD + l15];
+    wave_sync();
   };
-  auto store_chunk = [&](int S, int j, int slot) {
-    const int row = S * QG + 1 + SB * j + (t & 63);
+  auto tiles_to_global = [&](int S, int j, const double4_t (&z)[4]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int col = col0 + (t >> 6) + 8 * q;
-      if (row < n && col < p.ncols) p.Z[(size_t)row + (size_t)col * p.ldz] = sZ[(slot * SB + (t & 63)) * QZLD + (t >> 6) + 8 * q];
-    }
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[(16 * tt + l4 + 4 * r) * QSTLD + l15] = z[tt][r];
+    wave_sync();
+    const int row = S * QG + 1 + SB * j + lane;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (row < n && colw + c < p.ncols) p.Z[(size_t)row + (size_t)(colw + c) * p.ldz] = st[lane * QSTLD + c];
+    wave_sync();
   };
   for (int S = p.g.nS - 1; S >= 0; --S) {
     const int KS = q2_groups_of_block(n, S);
     if (KS <= 0) continue;
-    __syncthreads();
-    fetch_chunk(S, 0); put_chunk(0);
-    fetch_chunk(S, 1); put_chunk(1);
-    fetch_rec(S, 0);
+    fetch_chunk(S, 0); chunk_to_tiles(za);
+    fetch_chunk(S, 1); chunk_to_tiles(zb);
+    fetch_ops(S, 0);
+    __syncthreads();                                   // nobody still reads buffer 0 (previous block of sweeps)
+    put_ops(0);
     for (int k = 0; k < KS; ++k) {
-      const int s0 = k & 1, s1 = s0 ^ 1;              // slots of chunk k and chunk k+1
-      put_rec();
+      const int buf = k & 1;
       __syncthreads();
-      if (k + 1 < KS) { fetch_rec(S, k + 1); fetch_chunk(S, k + 2); }
-      // window row rr -> LDS row
-      auto zrow = [&](int rr) { return (rr < SB) ? (s0 * SB + rr) : (s1 * SB + rr - SB); };
-      {   // W1 (32 x 64) = V^T Zw: 2 x 4 tiles, one per wave
-        const int it = wave & 1, jt = wave >> 1;
-        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-        for (int kk = 0; kk < QR; kk += 4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(kk + l4) * QVLD + 16 * it + l15],
-                                                     sZ[zrow(kk + l4) * QZLD + 16 * jt + l15], acc, 0, 0, 0);
+      if (k + 1 < KS) { fetch_ops(S, k + 1); fetch_chunk(S, k + 2); }
+      const double *sV = sOp + buf * QOPSZ, *sVT = sV + QR * QVLD;
+      double4_t w1[2];
+      w1[0] = (double4_t){0.0, 0.0, 0.0, 0.0}; w1[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sW1[(16 * it + l4 + 4 * r) * QWLD + 16 * jt + l15] = acc[r];
+      for (int tile = 0; tile < 6; ++tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // the image is a parallelogram: reflector i lives in rows i .. i + 63, so rows 80.. hold
+          // nothing of reflectors 0..15 and rows 0..15 nothing of reflectors 16..31
+          const double y = (tile < 4) ? za[tile & 3][r] : zb[tile & 3][r];
+          const double *vrow = sV + (16 * tile + 4 * r + l4) * QVLD + l15;
+          if (tile < 5) w1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[0], y, w1[0], 0, 0, 0);
+          if (tile > 0) w1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[16], y, w1[1], 0, 0, 0);
+        }
+#pragma unroll
+      for (int tile = 0; tile < 6; ++tile) {
+        double4_t acc = (tile < 4) ? za[tile & 3] : zb[tile & 3];
+        const double *xrow = sVT + (16 * tile + l15) * QVLD + l4;
+#pragma unroll
+        for (int kk = (tile == 5 ? 16 : 0); kk < QG; kk += 4)      // rows 80.. of V T: columns 16.. only
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xrow[kk], w1[kk >> 4][(kk & 15) >> 2], acc, 0, 0, 0);
+        if (tile < 4) za[tile & 3] = acc; else zb[tile & 3] = acc;
       }
-      __syncthreads();
-      // Zw -= (V T) W1: 6 x 4 tiles, three per wave
+      if (k + 1 < KS) put_ops(buf ^ 1);
+      tiles_to_global(S, k, za);                       // chunk k is final for this block of sweeps
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int tile = wave * 3 + q, it = tile % 6, jt = tile / 6;
-        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-        for (int kk = 0; kk < QG; kk += 4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sVT[(16 * it + l15) * QVLD + kk + l4],
-                                                     sW1[(kk + l4) * QWLD + 16 * jt + l15], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sZ[zrow(16 * it + l4 + 4 * r) * QZLD + 16 * jt + l15] -= acc[r];
-      }
-      __syncthreads();
-      store_chunk(S, k, s0);                           // chunk k is final for this block of sweeps
-      if (k + 1 < KS) put_chunk(s0);                   // chunk k+2 takes its slot
-      else store_chunk(S, k + 1, s1);
+      for (int tt = 0; tt < 4; ++tt) za[tt] = zb[tt];
+      if (k + 1 < KS) chunk_to_tiles(zb);              // chunk k+2
+      else tiles_to_global(S, k + 1, za);
     }
   }
 }
@@ -552,11 +566,11 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   double *Rec = (double *)(w + L.off_T);
   Q2Geom g{n, L.nsweeps, L.nS, L.kmax};
   hipLaunchKernelGGL(q2_tfactor_kernel, dim3(L.kmax, L.nS), dim3(64), 0, s, g, V2, ldv2, tau2, L.ldt, Rec);
-  constexpr size_t lds = (size_t)(2 * SB * QZLD + 2 * QR * QVLD + QG * QWLD) * sizeof(double);
+  constexpr size_t lds = (size_t)(2 * QOPSZ + 4 * 64 * QSTLD) * sizeof(double);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)q2_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   Q2ApplyArgs a{g, Rec, Z, ldz, ncols};
-  hipLaunchKernelGGL(q2_apply_kernel, dim3(ceil_div(ncols, QNC)), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(q2_apply_kernel, dim3(ceil_div(ncols, QNC)), dim3(256), lds, s, a);
 }
 
 }  // namespace ek

@@ -331,37 +331,51 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
       if (lane > j) sD[lane * LD + j] = accl / piv;
       wave_sync();
     }
-    if (prof) tc[nt++] = clock64();
-    // T = -U S L1^-T, by rows: L1 t^T = c^T; kept transposed (sC(j, i) = T(i, j)), lane = i
+  }
+  if (prof) tc[nt++] = clock64();
+  __syncthreads();
+  // T = -U S L1^-T (wave 0, into sC transposed) and U^-1 (wave 1, into sA: R2 is no longer needed
+  // there -- it is kept in global memory for S R2 R1) side by side: both only read sD
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    p.L1[idx] = (i > j) ? sD[i * LD + j] : (i == j ? 1.0 : 0.0);
+    p.M2[idx] = sA[i * LD + j];                                          // R2, parked in M2 for a moment
+  }
+  __syncthreads();
+  for (int idx = t; idx < IMG; idx += 256) sA[idx] = 0.0;
+  __syncthreads();
+  if (wave == 0) {
+    // by rows: L1 t^T = c^T; kept transposed (sC(j, i) = T(i, j)), lane = i
     for (int j = 0; j < SB; ++j) {
       const double acc = ((lane <= j) ? -sD[lane * LD + j] * s_sign[j] : 0.0) -
           dot8(0, j, [&](int k) { return sD[j * LD + k]; }, [&](int k) { return sC[k * LD + lane]; });
       sC[j * LD + lane] = acc;
       wave_sync();
     }
+  } else if (wave == 1) {
+    triinv64_upper(sD, sA, lane);                                       // sA = U^-1
   }
+  if (prof) tc[nt++] = clock64();
   __syncthreads();
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     p.T[idx] = sC[j * LD + i];
-    p.L1[idx] = (i > j) ? sD[i * LD + j] : (i == j ? 1.0 : 0.0);
     if (i == j) p.tau[i] = sC[i * LD + i];
   }
   __syncthreads();
-  for (int idx = t; idx < IMG; idx += 256) sC[idx] = 0.0;
-  __syncthreads();
+  for (int idx = t; idx < SB * SB; idx += 256) {                        // sD = R2 back from its parking place
+    const int i = idx & 63, j = idx >> 6;
+    sD[i * LD + j] = p.M2[idx];
+  }
   if (prof) tc[nt++] = clock64();
-  if (t < 64) triinv64_upper(sD, sC, lane);                             // sC = U^-1
-  if (prof) tc[nt++] = clock64();
-  __syncthreads();
-  mm64(sB, false, sC, false, nullptr, p.M2);                            // M2 = R2^-1 U^-1
   __syncthreads();
   for (int idx = t; idx < SB * SB; idx += 256) {                        // sC = R1
     const int i = idx & 63, j = idx >> 6;
     sC[i * LD + j] = p.R1[idx];
   }
   __syncthreads();
-  mm64(sA, false, sC, false, nullptr, p.Rband, s_sign);                 // S R2 R1
+  mm64(sB, false, sA, false, nullptr, p.M2);                            // M2 = R2^-1 U^-1
+  mm64(sD, false, sC, false, nullptr, p.Rband, s_sign);                 // S R2 R1
   if (prof) { tc[nt++] = clock64(); for (int q = 0; q + 1 < nt; ++q) p.prof[q] += tc[q + 1] - tc[q]; p.prof[9] += 1; }
 }
 
@@ -679,17 +693,19 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Layout {
   int mpad, nparts, maxsplit;
-  size_t off_img, off_qt, off_y, off_ypart, off_gpart, off_small, total;
+  size_t off_img, off_img2, off_qt, off_y, off_ypart, off_gpart, off_gpart2, off_small, total;
   explicit Layout(int n) {
     mpad = round_up(n > 0 ? n : 1, 128);
     nparts = mpad / CH + 1;
     maxsplit = 8;
     size_t o = 0;
     off_img = o; o += al256((size_t)mpad * 3 * SB * 8);
+    off_img2 = o; o += al256((size_t)mpad * 3 * SB * 8);
     off_qt = o; o += al256((size_t)mpad * SB * 8);
     off_y = o; o += al256((size_t)mpad * SB * 8);
     off_ypart = o; o += al256((size_t)maxsplit * mpad * SB * 8);
     off_gpart = o; o += al256((size_t)nparts * SB * SB * 8);
+    off_gpart2 = o; o += al256((size_t)nparts * SB * SB * 8);
     off_small = o; o += al256((size_t)16 * SB * SB * 8);   // [10 * 4096 ..): profile counters
     total = o;
   }
@@ -699,52 +715,76 @@ struct Layout {
 
 size_t sy2sb_work_bytes(int n) { return Layout(n).total; }
 
-void sy2sb_lower(hipStream_t s, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
+void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
                  int *d_flag, void *work) {
   if (n <= 2) return;
   static bool attr = false;
+  static hipEvent_t evA[2], evB[2];
   if (!attr) {
     (void)hipFuncSetAttribute((const void *)hr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               4 * IMG * (int)sizeof(double));
     (void)hipFuncSetAttribute((const void *)house_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (SMALL_MAX * LD + IMG) * (int)sizeof(double));
+    for (int q = 0; q < 2; ++q) {
+      (void)hipEventCreateWithFlags(&evA[q], hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&evB[q], hipEventDisableTiming);
+    }
     attr = true;
   }
   const Layout L(n);
   char *w = (char *)work;
-  double *Vimg = (double *)(w + L.off_img), *Qt = (double *)(w + L.off_qt), *Y = (double *)(w + L.off_y);
+  double *img[2] = {(double *)(w + L.off_img), (double *)(w + L.off_img2)};
+  double *Qt = (double *)(w + L.off_qt), *Y = (double *)(w + L.off_y);
   double *Ypart = (double *)(w + L.off_ypart), *Gpart = (double *)(w + L.off_gpart);
   double *sm = (double *)(w + L.off_small);
-  double *Gred = sm, *R1 = sm + 4096, *R1inv = sm + 2 * 4096, *M2 = sm + 3 * 4096, *Tm = sm + 4 * 4096,
+  double *Gred = sm, *R1 = sm + 4096, *R1inv = sm + 2 * 4096, *M2 = sm + 3 * 4096, *Tm[2] = {sm + 4 * 4096, sm + 9 * 4096},
          *L1 = sm + 5 * 4096, *Rband = sm + 6 * 4096, *Mw = sm + 7 * 4096 /* 2 x 4096 */;
+  // panel-chain scratch of the look-ahead stream (its Gram partials must not meet those of yred)
+  double *Gpart2 = (double *)(w + L.off_gpart2), *Gred2 = sm + 11 * 4096;
   const int ldi = L.mpad;
-  if (getenv("EK_SY2SB_PROF")) (void)hipMemsetAsync(sm + 10 * 4096, 0, 128, s);
-  for (int c0 = 0; ; c0 += SB) {
+  const bool prof = getenv("EK_SY2SB_PROF") != nullptr;
+  if (prof) (void)hipMemsetAsync(sm + 10 * 4096, 0, 128, s);
+  static int la_min = -1;
+  if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 1024; }
+
+  // factorisation of the panel at column c0 into image `im`, T into `Tp`, issued on stream `st`
+  auto panel_chain = [&](hipStream_t st, int c0, double *Vimg, double *Tp) {
     const int r0 = c0 + SB, m = n - r0;
-    if (m < 2) break;
     double *Ap = A + (size_t)r0 + (size_t)c0 * lda;
     double *Vp = Vall + (size_t)r0 + (size_t)c0 * ldv;
     const int nch = ceil_div(m, CH);
     if (m <= SMALL_MAX) {
-      SmallArgs sa{m, Ap, lda, Vp, ldv, Vimg, ldi, Tm, tau1 + c0};
-      hipLaunchKernelGGL(house_small_kernel, dim3(1), dim3(256), (SMALL_MAX * LD + IMG) * sizeof(double), s, sa);
-    } else {
-      PanelArgs pa{};
-      pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = Gpart;
-      hipLaunchKernelGGL(panel_kernel<0>, dim3(nch), dim3(256), 0, s, pa);
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, s, nch, Gpart, Gred);
-      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, s, Gred, R1, R1inv, d_flag);
-      pa.M = R1inv; pa.dst = Qt; pa.ldd = L.mpad;
-      hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, s, pa);
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, s, nch, Gpart, Gred);
-      HrArgs ha{Gred, Qt, L.mpad, R1, M2, Tm, L1, Rband, tau1 + c0, d_flag, nullptr};
-      if (getenv("EK_SY2SB_PROF")) ha.prof = (long long *)(sm + 10 * 4096);
-      hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), s, ha);
-      PanelArgs pf{};
-      pf.m = m; pf.src = Qt; pf.lds_ = L.mpad; pf.M = M2; pf.L1 = L1; pf.Rband = Rband;
-      pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vimg = Vimg; pf.ldi = ldi;
-      hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, s, pf);
+      SmallArgs sa{m, Ap, lda, Vp, ldv, Vimg, ldi, Tp, tau1 + c0};
+      hipLaunchKernelGGL(house_small_kernel, dim3(1), dim3(256), (SMALL_MAX * LD + IMG) * sizeof(double), st, sa);
+      return;
     }
+    PanelArgs pa{};
+    pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = Gpart2;
+    hipLaunchKernelGGL(panel_kernel<0>, dim3(nch), dim3(256), 0, st, pa);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, st, nch, Gpart2, Gred2);
+    hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, Gred2, R1, R1inv, d_flag);
+    pa.M = R1inv; pa.dst = Qt; pa.ldd = L.mpad;
+    hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, st, pa);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, st, nch, Gpart2, Gred2);
+    HrArgs ha{Gred2, Qt, L.mpad, R1, M2, Tp, L1, Rband, tau1 + c0, d_flag, nullptr};
+    if (prof) ha.prof = (long long *)(sm + 10 * 4096);
+    hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), st, ha);
+    PanelArgs pf{};
+    pf.m = m; pf.src = Qt; pf.lds_ = L.mpad; pf.M = M2; pf.L1 = L1; pf.Rband = Rband;
+    pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vimg = Vimg; pf.ldi = ldi;
+    hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, st, pf);
+  };
+
+  panel_chain(s, 0, img[0], Tm[0]);
+  bool waited = true;        // whether stream s already follows the chain of the current panel
+  int p = 0;
+  for (int c0 = 0; ; c0 += SB, ++p) {
+    const int r0 = c0 + SB, m = n - r0;
+    if (m < 2) break;
+    const int cur = p & 1;
+    double *Vimg = img[cur];
+    if (!waited) (void)hipStreamWaitEvent(s, evB[cur], 0);
+    const int nch = ceil_div(m, CH);
     // Y = A22 V, split over K so that the launch fills the chip
     double *A22 = A + (size_t)r0 + (size_t)r0 * lda;
     const double *V = Vimg + (size_t)SB * ldi;
@@ -759,11 +799,27 @@ void sy2sb_lower(hipStream_t s, int n, double *A, int lda, double *Vall, int ldv
     YredArgs ya{m, nsplit, Ypart, L.mpad, (long long)L.mpad * SB, Y, V, ldi, Gpart};
     hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, s, nch, Gpart, Gred);
-    hipLaunchKernelGGL(wmat_kernel, dim3(1), dim3(256), 0, s, Gred, Tm, Mw);
+    hipLaunchKernelGGL(wmat_kernel, dim3(1), dim3(256), 0, s, Gred, Tm[cur], Mw);
     WArgs wa{m, Y, L.mpad, V, ldi, Mw, Vimg, ldi};
     hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
-    // A22 -= W V^T + V W^T = [W | V] [V | W]^T, lower triangle
-    gemm(s, false, true, m, m, 2 * SB, -1.0, Vimg, ldi, Vimg + (size_t)SB * ldi, ldi, 1.0, A22, lda, true);
+    // A22 -= W V^T + V W^T = [W | V] [V | W]^T, lower triangle.  With look-ahead the first block column is
+    // updated first and the NEXT panel is factored on the second stream while the rest is updated.
+    const bool has_next = m - SB >= 2;
+    const double *P1 = Vimg, *P2 = Vimg + (size_t)SB * ldi;
+    if (has_next && m >= la_min) {
+      gemm(s, false, true, m, SB, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true);
+      (void)hipEventRecord(evA[cur], s);
+      (void)hipStreamWaitEvent(s2, evA[cur], 0);
+      panel_chain(s2, r0, img[cur ^ 1], Tm[cur ^ 1]);
+      (void)hipEventRecord(evB[cur ^ 1], s2);
+      gemm(s, false, true, m - SB, m - SB, 2 * SB, -1.0, P1 + SB, ldi, P2 + SB, ldi, 1.0,
+           A22 + (size_t)SB + (size_t)SB * lda, lda, true);
+      waited = false;
+    } else {
+      gemm(s, false, true, m, m, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true);
+      if (has_next) panel_chain(s, r0, img[cur ^ 1], Tm[cur ^ 1]);
+      waited = true;
+    }
   }
   if (getenv("EK_SY2SB_PROF")) {
     long long h[10];
