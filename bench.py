@@ -22,11 +22,22 @@ checked on every rank).  The faster distributed mode that passed becomes the hea
 on); if neither passes (or an exchange hangs: a watchdog abandons it) the replicas line is the
 headline ("scaling": "weak").  `--distribution replicas | columns | grid` force one mode.
 
+`--config c2|c3|c4|c5` selects a BASELINE.json configuration by name (c3, the default, is the one
+the metric is quoted on; c4 and c5 name 8-GPU layouts: with fewer ranks the same problem is run on
+the ranks there are).
+
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline"     : the dominant kernel (symv of the tridiagonalisation, HBM-bound), timed
-                   live with HIP events on its launch stream in the timed region;
-  "cpu_baseline" : the CPU oracle (a port, 1 core) on a bounded sample (smaller N) of the
-                   same generator, rank 0 at N=1 only.
+  "roofline"        : the dominant kernel, timed live with HIP events on its launch stream in the
+                      timed region: with the two-stage tridiagonalisation (orders >= 12288) the
+                      MFMA-bound application of the bulge-chasing reflectors (q2_apply_kernel),
+                      else the HBM-bound symv of the one-stage reduction;
+  "roofline_stages" : per stage of the path, algorithmic flops / device seconds
+                      against the fp64 matrix peak;
+  "value_incl_copies": the same solve through ek_hip_solve on HOST arrays (PCIe staging of A, B in
+                      and Z, A, B, w out included; SURVEY.md 8(d)), one step, outside the timed region;
+  "cpu_baseline"    : the reference's ScaLAPACK call sequence on the host cores on a bounded sample
+                      (smaller N) of the same generator, rank 0 at N=1 only, with the GPU path timed
+                      at that SAME order beside it ("gpu_same_order").
 """
 import argparse
 import numpy as np
@@ -89,7 +100,13 @@ def cpu_baseline_scalapack(problem, sample_n):
     except Exception:
         cores = os.cpu_count() or 1
     np_ = max(1, min(cores, 64))
-    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    # the ranks are CPU-only children: nothing of a profiler wrapped around bench.py (its preloaded
+    # tool library would initialise the GPU in every rank and across every exec hop of mpiexec) and
+    # no GPU may reach them
+    env = {k: v for k, v in os.environ.items()
+           if not (k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE", "ROCP_TOOL_LIBRARIES")
+                   or k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX", "HSA_TOOLS")))}
+    env.update(MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     try:
         out = subprocess.run([mpiexec, "-np", str(np_), exe, str(sample_n), str(problem)], env=env,
                              capture_output=True, text=True, timeout=600)
@@ -106,6 +123,61 @@ def cpu_baseline_scalapack(problem, sample_n):
                       "np=%d (grid %dx%d), NB=64, 1 BLAS thread/rank" % (
                           "GEP" if problem == 1 else "SEP", sample_n, np_, j["grid"][0], j["grid"][1]),
             "gflops_equiv": flops(problem, sample_n, sample_n) / solve / 1e9}
+
+
+def gpu_step_at(lib, torch, dev, problem, n, steps=3):
+    """The GPU path at the order the CPU baseline was run on (device-resident inputs, like the headline)."""
+    dA = torch.empty((n, n), dtype=torch.float64, device=dev)
+    dB = torch.empty((n, n), dtype=torch.float64, device=dev) if problem == 1 else None
+    dZ = torch.empty((n, n), dtype=torch.float64, device=dev)
+    dw = torch.empty((n,), dtype=torch.float64, device=dev)
+    tot = 0.0
+    for it in range(steps + 1):
+        assert lib.ek_hip_synth_matrix_device(n, 1, dA.data_ptr(), n) == 0
+        if problem == 1:
+            assert lib.ek_hip_synth_matrix_device(n, 2, dB.data_ptr(), n) == 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = lib.ek_hip_solve_device(problem, n, n, dA.data_ptr(), n, dB.data_ptr() if problem == 1 else None, n,
+                                       dw.data_ptr(), dZ.data_ptr(), n, None, 0)
+        torch.cuda.synchronize()
+        assert info == 0, info
+        if it > 0:
+            tot += time.perf_counter() - t0
+    sec = tot / steps
+    return {"n": n, "seconds": sec, "value": n / sec, "unit": "eigenpairs/s",
+            "gflops_equiv": flops(problem, n, n) / sec / 1e9}
+
+
+def host_path_step(lib, solver, problem, n, n_vec):
+    """One solve through ek_hip_solve on host arrays: what a host of the reference's shape sees, PCIe
+    staging included.  Inputs are generated on the device and copied out first."""
+    import numpy as np
+    from eigenkernel_amd import descriptor as dsc
+    try:
+        A = np.zeros((n, n), order="F"); B = np.zeros((n, n), order="F") if problem == 1 else None
+        Z = np.zeros((n, n), order="F"); w = np.zeros(n)
+        tmp = ctypes.c_void_p()
+        assert lib.ek_hip_malloc(ctypes.byref(tmp), n * n * 8) == 0
+        for seed, M in ((1, A), (2, B)):
+            if M is not None:
+                assert lib.ek_hip_synth_matrix_device(n, seed, tmp, n) == 0
+                assert lib.ek_hip_memcpy_d2h(M.ctypes.data, tmp, n * n * 8) == 0
+        lib.ek_hip_free(tmp)
+        desc = dsc.descinit(n, n, 64, 64, 0, 0, 0, n)
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        st = (ctypes.c_double * 8)()
+        t0 = time.perf_counter()
+        info = lib.ek_hip_solve(problem, n, n_vec, A.ctypes.data_as(dp), desc.ctypes.data_as(ip),
+                                B.ctypes.data_as(dp) if problem == 1 else None, desc.ctypes.data_as(ip) if problem == 1 else None,
+                                w.ctypes.data_as(dp), Z.ctypes.data_as(dp), desc.ctypes.data_as(ip), 1, 1, 0, 0, st, 8)
+        sec = time.perf_counter() - t0
+        if info != 0:
+            return {"error": "ek_hip_solve info=%d" % info}
+        return {"value": n_vec / sec, "unit": "eigenpairs/s", "seconds": sec, "host_device_copies_seconds": st[7],
+                "note": "one ek_hip_solve call on pageable host arrays (A, B in; Z, A, B, w out)"}
+    except MemoryError as exc:
+        return {"error": repr(exc)}
 
 
 _emitted = False
@@ -166,7 +238,7 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
                         pass
                 emit(_pending)
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)          # an abandoned exchange is a failure of the run, whatever line could be saved
 
     def sync():
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
@@ -305,6 +377,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default=None,
+                    help="a BASELINE.json configuration by name: c2 N=4096 standard, c3 N=16384 generalized "
+                         "(default), c4 N=32768 generalized, c5 N=16384 generalized lowest 1024 pairs")
     ap.add_argument("--order", dest="n", type=int, default=16384, help="matrix order N")
     ap.add_argument("--problem", choices=["gep", "sep"], default="gep")
     ap.add_argument("--n-vec", type=int, default=0,
@@ -328,7 +403,9 @@ def main():
                     help="with --distribution columns on ONE GPU: play rank --virtual-rank of a 1 x P grid "
                          "(the mode has no collective, so a rank's time does not depend on the others)")
     ap.add_argument("--virtual-rank", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the ScaLAPACK baseline (mandatory under a profiler: 64 MPI ranks are not to be profiled)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive step (value_incl_copies)")
     ap.add_argument("--no-symv-events", action="store_true")
     ap.add_argument("--symv-events-stride", type=int, default=8,
                     help="time the symv launch of every k-th column with HIP events (1 = all launches; "
@@ -347,6 +424,9 @@ def main():
     ap.add_argument("--grid-probe-timeout", type=float, default=240.0,
                     help="seconds after which a stuck grid probe is abandoned (the main line is still printed)")
     args = ap.parse_args()
+    if args.config:
+        args.n, args.problem, args.n_vec = {"c2": (4096, "sep", 0), "c3": (16384, "gep", 0),
+                                            "c4": (32768, "gep", 0), "c5": (16384, "gep", 1024)}[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -435,6 +515,7 @@ def main():
     events = not args.no_symv_events
     if events:
         lib.ek_hip_profile_symv(max(1, args.symv_events_stride))
+        lib.ek_hip_profile_kernels(1)
     barrier()
     t0 = time.perf_counter()
     for i in range(K):
@@ -447,9 +528,12 @@ def main():
         total = float(tt.item())
 
     symv_s, symv_l, symv_b = ctypes.c_double(0), ctypes.c_longlong(0), ctypes.c_double(0)
+    kp_s, kp_l = (ctypes.c_double * 4)(), (ctypes.c_longlong * 4)()
     if events:
         lib.ek_hip_profile_symv_get(ctypes.byref(symv_s), ctypes.byref(symv_l), ctypes.byref(symv_b))
         lib.ek_hip_profile_symv(0)
+        lib.ek_hip_profile_kernels_get(kp_s, kp_l)
+        lib.ek_hip_profile_kernels(0)
 
     # Parity guard on the output of the LAST timed step, at the full benchmark size, through the
     # reference's own acceptance quantities (verifier.f90:75-204, 233-330) evaluated on the GPU
@@ -503,30 +587,80 @@ def main():
             "stage_seconds_per_step": {lib.ek_hip_stage_name(i).decode(): stage_sum[i] / K for i in range(8)},
             "parity": parity,
         }
-        if events and symv_l.value > 0 and symv_s.value > 0:
+        n3 = float(n) ** 3
+        k = float(nc_loc if columns else n_vec)
+        if events and kp_l[0] > 0 and kp_s[0] > 0:
+            # two-stage path: the application of the bulge-chasing reflectors Q2 to the eigenvectors is
+            # the largest kernel.  Algorithmic flops: n^2 / (2*64) reflectors of length 64 applied to k
+            # columns at 4 flops per entry = 2 n^2 k per launch (the compact-WY form the kernel executes
+            # issues ~1.3x that on the matrix cores; that surplus is not counted).
+            fl = 2.0 * n * n * k
+            dur = kp_s[0] / kp_l[0]
+            ach = fl / dur / 1e12
+            traffic, tsrc = None, None
+            tpath = os.path.join(ROOT, "profiles", "r02_q2_apply_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("n") == n and tj.get("ncols") == int(k):
+                        traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/r02_q2_apply_traffic.json (rocprofv3 --pmc, not live)"
+                except Exception:
+                    pass
+            out["roofline"] = {
+                "kernel": "q2_apply_kernel (Z <- Q2 Z: reflectors of the band->tridiagonal stage, compact-WY blocks of 32 "
+                          "sweeps, window of Z resident in MFMA accumulator registers)",
+                "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                "launches": int(kp_l[0]), "avg_launch_us": 1e6 * dur, "algorithmic_flops_per_launch": fl,
+                "measured_mfma_ceiling_tflops": 49.5,
+                "other_kernels": {
+                    "chase_kernel (band -> tridiagonal, latency-bound pipeline of sweeps)":
+                        {"launches": int(kp_l[1]), "avg_launch_us": 1e6 * kp_s[1] / max(kp_l[1], 1)},
+                    "symm_lower_kernel (Y = A22 V of every 8th panel)":
+                        {"launches": int(kp_l[2]), "avg_launch_us": 1e6 * kp_s[2] / max(kp_l[2], 1)}},
+            }
+        elif events and symv_l.value > 0 and symv_s.value > 0:
             ach = symv_b.value / symv_s.value / 1e9
-            traffic = None
+            traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "symv_traffic.json")
             if os.path.exists(tpath):   # PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected) if committed
                 try:
                     tj = json.load(open(tpath))
                     if tj.get("n") == n:
-                        traffic = tj.get("hbm_bytes_per_launch")
+                        traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/symv_traffic.json (rocprofv3 --pmc, round 1, not live)"
                 except Exception:
                     traffic = None
             out["roofline"] = {
                 "kernel": "symv_kernel (tridiagonalisation panel: y = A22 v, lower triangle read once)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                 "launches": symv_l.value, "timed_every_kth_column": max(1, args.symv_events_stride),
                 "avg_launch_us": 1e6 * symv_s.value / symv_l.value,
                 "algorithmic_bytes_per_launch": symv_b.value / symv_l.value,
             }
         else:
             out["roofline"] = None
+        # per stage: algorithmic flops of SURVEY.md 8(d) (K1 n^3/3, K2 n^3, K3 4n^3/3, K5 ~4n^3/3, K6 2 n^2 k,
+        # K7 n^2 k) over the stage's device seconds, against the fp64 matrix peak
+        st_fl = {"reduce_generalized:pdpotrf": n3 / 3 if problem == 1 else 0.0,
+                 "reduce_generalized:pdsygst": n3 if problem == 1 else 0.0,
+                 "eigen_solver_scalapack_all:pdsytrd": 4 * n3 / 3,
+                 "eigen_solver_scalapack_all:pdstedc": 4 * n3 / 3 if k == n else 2 * n3 / 3 + 2 * n * n * k / 3,
+                 "eigen_solver_scalapack_all:pdormtr": 2.0 * n * n * k,
+                 "recovery_generalized": n * n * k if problem == 1 else 0.0}
+        out["roofline_stages"] = {}
+        for name, fl in st_fl.items():
+            sec = out["stage_seconds_per_step"].get(name, 0.0)
+            if fl > 0 and sec > 0:
+                out["roofline_stages"][name] = {"algorithmic_flops": fl, "seconds": sec, "tflops": fl / sec / 1e12,
+                                                "frac_of_fp64_mfma_peak": fl / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+        if world == 1 and not columns and not args.no_host_path:
+            out["value_incl_copies"] = host_path_step(lib, solver, problem, n, n_vec)
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline_scalapack(problem, args.scalapack_sample_n)
             out["cpu_baseline"] = base if base is not None else cpu_baseline(problem, args.cpu_sample_n)
+            sn = args.scalapack_sample_n if base is not None else args.cpu_sample_n
+            out["cpu_baseline"]["gpu_same_order"] = gpu_step_at(lib, torch, dev, problem, sn)
         _pending = out
     if ((world > 1 or args.force_grid_probe) and dist is not None and args.distribution in ("auto", "replicas")
             and not args.no_grid_probe):

@@ -4,6 +4,7 @@
 // does (info = -k), stages host arrays into padded device work arrays, runs the stage
 // kernels on one HIP stream and hands results back.  No numerical work happens on the CPU.
 #include "../../include/ek_hip.h"
+#include "../../include/ek_hip_debug.h"
 #include "ek_common.h"
 
 #include <rccl/rccl.h>   // types only: the library is bound at run time (dlopen), see Rccl below
@@ -278,7 +279,7 @@ int two_stage_min() {
   if (g_two_stage_min >= 0) return g_two_stage_min;
   static int env = -2;
   if (env == -2) { const char *e = getenv("EK_HIP_TWO_STAGE_MIN"); env = e ? atoi(e) : -1; }
-  return env >= 0 ? env : 3072;
+  return env >= 0 ? env : 12288;
 }
 
 // From how many ranks on the Cholesky factor and the reduction to standard form are distributed
@@ -1217,6 +1218,23 @@ int ek_hip_debug_sb2st(int n, const double *A, int lda, double *d, double *e, do
 }
 
 int ek_hip_debug_set_two_stage(int min_order) { g_two_stage_min = min_order; return 0; }   // -1: default
+
+// HIP-event brackets around the kernels of the two-stage path bench.py reports a roofline for
+// (0 q2_apply_kernel, 1 chase_kernel, 2 symm_lower_kernel of every 8th panel); _get after the solves.
+int ek_hip_profile_kernels(int enable) {
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  EK_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  kprof_enable(enable != 0);
+  return 0;
+}
+int ek_hip_profile_kernels_get(double *seconds, long long *launches) {
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  EK_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  kprof_collect(seconds, launches);
+  return 0;
+}
 
 // Timing of the two-stage pieces on a device-generated synthetic matrix of order n:
 // seconds[0] dense -> band, [1] band -> tridiagonal, [2] Q2 applied to ncols columns, [3] Q1 applied.

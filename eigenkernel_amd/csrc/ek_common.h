@@ -50,6 +50,16 @@ inline void gemm(hipStream_t s, bool ta, bool tb, int M, int N, int K, double al
   gemm(s, g);
 }
 
+// ---------------------------------------------------------------- kernel timing (ek_util.hip)
+// Optional HIP-event brackets around the launches of the kernels bench.py reports a roofline for, on
+// the stream they are launched on.  Off by default (an event pair costs a few microseconds of host time).
+enum { kProfQ2Apply = 0, kProfChase = 1, kProfSymm = 2, kProfSyr2k = 3, kProfCount = 4 };
+void kprof_enable(bool on);
+bool kprof_enabled();
+void kprof_begin(hipStream_t s, int id);
+void kprof_end(hipStream_t s, int id);
+void kprof_collect(double *seconds /* kProfCount */, long long *launches /* kProfCount */);   // after a stream sync; resets
+
 // ---------------------------------------------------------------- small utilities (ek_util.hip)
 void copy_matrix(hipStream_t s, int m, int n, const double *src, int lds, double *dst, int ldd);
 void set_matrix(hipStream_t s, int m, int n, double offdiag, double diag, double *A, int lda);

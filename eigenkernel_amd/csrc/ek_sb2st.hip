@@ -543,7 +543,9 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
     if (nwg > 256) nwg = 256;
     if (nwg > L.nsweeps) nwg = L.nsweeps;
     if (const char *ev = getenv("EK_SB2ST_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
+    kprof_begin(s, kProfChase);
     hipLaunchKernelGGL(chase_kernel, dim3(nwg), dim3(256), 0, s, c);
+    kprof_end(s, kProfChase);
   }
   hipLaunchKernelGGL(unpack_de_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, AB, d, e);
   if (getenv("EK_SB2ST_PROF")) {
@@ -570,7 +572,9 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)q2_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   Q2ApplyArgs a{g, Rec, Z, ldz, ncols};
+  kprof_begin(s, kProfQ2Apply);
   hipLaunchKernelGGL(q2_apply_kernel, dim3(ceil_div(ncols, QNC)), dim3(256), lds, s, a);
+  kprof_end(s, kProfQ2Apply);
 }
 
 }  // namespace ek

@@ -795,7 +795,10 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     const int tps = ceil_div(T, nsplit);
     nsplit = ceil_div(T, tps);
     SymmArgs sy{m, A22, lda, V, ldi, Ypart, L.mpad, (long long)L.mpad * SB, T, tps};
+    const bool timed = kprof_enabled() && (p % 8 == 0);          // a uniform sample of the panels
+    if (timed) kprof_begin(s, kProfSymm);
     hipLaunchKernelGGL(symm_lower_kernel, dim3(T, nsplit), dim3(256), 0, s, sy);
+    if (timed) kprof_end(s, kProfSymm);
     YredArgs ya{m, nsplit, Ypart, L.mpad, (long long)L.mpad * SB, Y, V, ldi, Gpart};
     hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, s, nch, Gpart, Gred);

@@ -3,6 +3,8 @@
 // consecutive rows of the column-major arrays so every wave access is a 512-byte run.
 #include "ek_common.h"
 
+#include <vector>
+
 namespace ek {
 namespace {
 
@@ -203,6 +205,52 @@ void scale_lower(hipStream_t s, int n, double alpha, double *A, int lda) {
 void scale_vector(hipStream_t s, int n, double alpha, double *x) {
   if (n <= 0) return;
   hipLaunchKernelGGL(scale_vector_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, alpha, x);
+}
+
+// ------------------------------------------------------------------------------ kernel timing
+namespace {
+struct KProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ids;          // id of every recorded (begin, end) pair
+  size_t used = 0;
+  double sec[kProfCount] = {0, 0, 0, 0};
+  long long cnt[kProfCount] = {0, 0, 0, 0};
+} g_kprof;
+}  // namespace
+
+void kprof_enable(bool on) {
+  g_kprof.on = on; g_kprof.used = 0; g_kprof.ids.clear();
+  for (int i = 0; i < kProfCount; ++i) { g_kprof.sec[i] = 0.0; g_kprof.cnt[i] = 0; }
+}
+bool kprof_enabled() { return g_kprof.on; }
+void kprof_begin(hipStream_t s, int id) {
+  if (!g_kprof.on) return;
+  if (g_kprof.used + 2 > g_kprof.ev.size()) {
+    const size_t old = g_kprof.ev.size();
+    g_kprof.ev.resize(old + 1024);
+    for (size_t q = old; q < g_kprof.ev.size(); ++q) (void)hipEventCreate(&g_kprof.ev[q]);
+  }
+  g_kprof.ids.push_back(id);
+  (void)hipEventRecord(g_kprof.ev[g_kprof.used], s);
+}
+void kprof_end(hipStream_t s, int id) {
+  (void)id;
+  if (!g_kprof.on) return;
+  (void)hipEventRecord(g_kprof.ev[g_kprof.used + 1], s);
+  g_kprof.used += 2;
+}
+void kprof_collect(double *seconds, long long *launches) {
+  for (size_t q = 0; q + 1 < g_kprof.used; q += 2) {
+    float ms = 0.f;
+    const int id = g_kprof.ids[q / 2];
+    if (hipEventElapsedTime(&ms, g_kprof.ev[q], g_kprof.ev[q + 1]) == hipSuccess) { g_kprof.sec[id] += ms * 1e-3; g_kprof.cnt[id] += 1; }
+  }
+  g_kprof.used = 0; g_kprof.ids.clear();
+  for (int i = 0; i < kProfCount; ++i) {
+    if (seconds) seconds[i] = g_kprof.sec[i];
+    if (launches) launches[i] = g_kprof.cnt[i];
+  }
 }
 
 }  // namespace ek

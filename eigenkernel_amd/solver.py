@@ -114,6 +114,8 @@ def load_library(path=None):
         "ek_hip_debug_sb2st": (c_int, [c_int, _dp, c_int, _dp, _dp, _dp, c_int, c_int, _ip]),
         "ek_hip_debug_two_stage_timing": (c_int, [c_int, c_int, c_int, _dp, _ip]),
         "ek_hip_debug_set_two_stage": (c_int, [c_int]),
+        "ek_hip_profile_kernels": (c_int, [c_int]),
+        "ek_hip_profile_kernels_get": (c_int, [_dp, _llp]),
     }
     for name, (res, args) in sigs.items():
         try:
@@ -141,6 +143,8 @@ EXPORTED_SYMBOLS = (
     "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device", "ek_hip_debug_sytrd_team", "ek_hip_sygst_team",
     "ek_hip_potrf_team", "ek_hip_debug_reduce_team", "ek_hip_comm_attach_host",
     "ek_hip_comm_peer_enable", "ek_hip_comm_peer_disable", "ek_hip_debug_set_sytrd_maxcols", "ek_hip_debug_sytrd_work_bytes", "ek_hip_debug_sytrd_at", "ek_hip_debug_sytrd_split", "ek_hip_debug_gemm_at",
+    "ek_hip_debug_sy2sb", "ek_hip_debug_sb2st", "ek_hip_debug_two_stage_timing", "ek_hip_debug_set_two_stage",
+    "ek_hip_profile_kernels", "ek_hip_profile_kernels_get",
 )
 
 
@@ -431,6 +435,43 @@ def trtrs(L, Z):
     Z = np.array(_farr(Z), order="F", copy=True)
     info = lib.ek_hip_trtrs(L.shape[0], Z.shape[1], _P(L), _I(_desc_for(L)), _P(Z), _I(_desc_for(Z)))
     return Z, info
+
+
+BAND_W = 64   # half bandwidth of the two-stage tridiagonalisation (kBandW in csrc/ek_common.h)
+
+
+def set_two_stage(min_order=-1):
+    """Order from which the whole-path calls tridiagonalise in two stages (-1: default, 0: never)."""
+    load_library().ek_hip_debug_set_two_stage(int(min_order))
+
+
+def sy2sb(A):
+    """Stage 1 of the two-stage tridiagonalisation on its own (include/ek_hip_debug.h):
+    returns (A_out with the band in its lower band, V explicit reflectors, tau, flag)."""
+    lib = load_library()
+    A = np.array(_farr(A), order="F", copy=True)
+    n = A.shape[0]
+    V = np.zeros((n, n), order="F"); tau = np.zeros(max(n, 1)); flag = ctypes.c_int(-1)
+    rc = lib.ek_hip_debug_sy2sb(n, _P(A), max(1, n), _P(V), max(1, n), _P(tau), ctypes.byref(flag))
+    if rc:
+        raise RuntimeError("ek_hip_debug_sy2sb info=%d" % rc)
+    return A, V, tau[:n], flag.value
+
+
+def sb2st(Bd, Z=None):
+    """Stage 2 on its own: the lower band (half bandwidth 64) of Bd -> (d, e, Q2 Z or None, flag)."""
+    lib = load_library()
+    Bd = np.array(_farr(Bd), order="F", copy=True)
+    n = Bd.shape[0]
+    d = np.zeros(max(n, 1)); e = np.zeros(max(n, 1)); flag = ctypes.c_int(-1)
+    if Z is None:
+        rc = lib.ek_hip_debug_sb2st(n, _P(Bd), max(1, n), _P(d), _P(e), None, max(1, n), 0, ctypes.byref(flag))
+    else:
+        Z = np.array(_farr(Z), order="F", copy=True)
+        rc = lib.ek_hip_debug_sb2st(n, _P(Bd), max(1, n), _P(d), _P(e), _P(Z), max(1, n), Z.shape[1], ctypes.byref(flag))
+    if rc:
+        raise RuntimeError("ek_hip_debug_sb2st info=%d" % rc)
+    return d[:n], e[:max(n - 1, 0)], Z, flag.value
 
 
 def dgemm(transa, transb, alpha, A, B, beta, C, lower_only=False):

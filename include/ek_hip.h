@@ -253,24 +253,15 @@ int ek_hip_check(int what, int problem, int n, int n_cols, int index1, int index
                  const double *A_loc, const int desc_A[9], const double *B_loc, const int desc_B[9],
                  const double *w, const double *Z_loc, const int desc_Z[9], double *out);
 
-/* Instrumentation for the roofline line of bench.py: enable = k > 0 brackets the launch of the
- * HBM-bound symv kernel of every k-th Householder column (k = 1: every launch; a uniform sample
- * over the trailing orders otherwise) by HIP events on its own stream; 0 switches it off.
- * _get returns the accumulated device seconds, the number of timed launches and their
- * algorithmic bytes (8 B x lower triangle of the active matrix per launch). */
-int ek_hip_profile_symv(int enable);
-/* Tuning hook: tridiagonalise a device-generated synthetic matrix (order n, leading dimension
- * ld >= n rounded up to 128) `reps` times; *seconds = stage time per repetition. */
-int ek_hip_debug_sytrd(int n, int ld, int reps, double *seconds);
-unsigned long long ek_hip_debug_sytrd_work_bytes(int n);
-int ek_hip_debug_sytrd_at(int n, int max_cols, int reps, double *dA, void *work, double *vecs, double *seconds);
-int ek_hip_debug_gemm_at(int transa, int transb, int m, int n, int k, const double *dA, int lda, const double *dB,
-                         int ldb, double beta, double *dC, int ldc, int lower_only, int reps, double *seconds);
-int ek_hip_debug_sytrd_split(void *alt, int mask);  /* placement experiments: sub-buffers of the scratch from alt */
-int ek_hip_debug_set_sytrd_maxcols(int max_cols);   /* the hooks stop after max_cols columns (-1: all) */
-int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds);
-int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds /* [2]: potrf, sygst */);   /* distributed form, see ek_hip_sytrd_team */
-int ek_hip_profile_symv_get(double *seconds, long long *launches, double *algorithmic_bytes);
+/* Which tridiagonalisation the whole-path calls use is an implementation detail behind the results
+ * contract: orders >= 12288 (EK_HIP_TWO_STAGE_MIN overrides, 0 = never) go dense -> band -> tridiagonal
+ * (two stages, all O(n^3) work on the matrix cores), smaller ones take the one-stage Householder
+ * reduction that ek_hip_sytrd exposes with PDSYTRD's own output convention.  With two stages A_loc
+ * returns the band and the first stage's R factors instead of PDSYTRD's reflectors (the reference
+ * deallocates A without reading it, solver_scalapack_all.f90:19-124).  The library times a one-off
+ * placement probe inside the first large one-stage solve (EK_HIP_PLACEMENT=0 turns it off; it prints
+ * nothing unless EK_HIP_PLACEMENT_VERBOSE is set).
+ * Tuning, profiling and test hooks are declared in ek_hip_debug.h, not here. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,58 @@
+/*
+ * ek_hip_debug.h -- tuning, profiling and test hooks of libek_hip.so.  NOT part of the drop-in
+ * boundary (include/ek_hip.h): nothing a host of the reference's shape needs is declared here, and
+ * these entries may change between rounds.  Used by bench.py (roofline instrumentation), tools/ and
+ * the GPU test-suite (stage-level checks of the two-stage tridiagonalisation).
+ */
+#ifndef EK_HIP_DEBUG_H
+#define EK_HIP_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Instrumentation for the roofline line of bench.py: enable = k > 0 brackets the launch of the
+ * HBM-bound symv kernel of every k-th Householder column (one-stage path; k = 1: every launch; a
+ * uniform sample over the trailing orders otherwise) by HIP events on its own stream; 0 switches it
+ * off.  _get returns the accumulated device seconds, the number of timed launches and their
+ * algorithmic bytes (8 B x lower triangle of the active matrix per launch). */
+int ek_hip_profile_symv(int enable);
+int ek_hip_profile_symv_get(double *seconds, long long *launches, double *algorithmic_bytes);
+
+/* The same for the kernels of the two-stage path: seconds[i], launches[i] with i = 0 q2_apply_kernel
+ * (application of the bulge-chasing reflectors, the largest kernel of a full-spectrum solve),
+ * 1 chase_kernel, 2 symm_lower_kernel (every 8th panel), 3 unused. */
+int ek_hip_profile_kernels(int enable);
+int ek_hip_profile_kernels_get(double *seconds /* 4 */, long long *launches /* 4 */);
+
+/* One-stage tridiagonalisation: tridiagonalise a device-generated synthetic matrix (order n, leading
+ * dimension ld >= n rounded up to 128) `reps` times; *seconds = stage time per repetition. */
+int ek_hip_debug_sytrd(int n, int ld, int reps, double *seconds);
+unsigned long long ek_hip_debug_sytrd_work_bytes(int n);
+int ek_hip_debug_sytrd_at(int n, int max_cols, int reps, double *dA, void *work, double *vecs, double *seconds);
+int ek_hip_debug_gemm_at(int transa, int transb, int m, int n, int k, const double *dA, int lda, const double *dB,
+                         int ldb, double beta, double *dC, int ldc, int lower_only, int reps, double *seconds);
+int ek_hip_debug_sytrd_split(void *alt, int mask);  /* placement experiments: sub-buffers of the scratch from alt */
+int ek_hip_debug_set_sytrd_maxcols(int max_cols);   /* the hooks stop after max_cols columns (-1: all) */
+int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds);
+int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds /* [2]: potrf, sygst */);
+
+/* Two-stage tridiagonalisation, piece by piece on host arrays.
+ *   _sy2sb : A (n x n, lda, symmetric, lower referenced) -> band (half bandwidth 64) left in the lower
+ *            band of A, explicit reflectors V (n x n, ldv: column j = v_j, unit entry at row j + 64),
+ *            tau (n); *flag = 0 or why the CholeskyQR2 panel factorisation gave up (1 Cholesky pivot,
+ *            2 loss of orthogonality): the whole-path call then takes the one-stage path.
+ *   _sb2st : the lower band of A -> d (n), e (n-1) by bulge chasing; Z (n x ncols, ldz; may be NULL
+ *            with ncols = 0) <- Q2 Z; *flag bit 2 = the persistent kernel was abandoned.
+ *   _two_stage_timing : seconds[0..3] = dense->band, band->tridiagonal, Q2 applied to ncols columns,
+ *            Q1 applied, on a device-generated synthetic matrix.
+ *   _set_two_stage : order from which the whole-path calls use two stages (-1 default, 0 never). */
+int ek_hip_debug_sy2sb(int n, double *A, int lda, double *V, int ldv, double *tau, int *flag);
+int ek_hip_debug_sb2st(int n, const double *A, int lda, double *d, double *e, double *Z, int ldz, int ncols, int *flag);
+int ek_hip_debug_two_stage_timing(int n, int ncols, int reps, double *seconds, int *flag);
+int ek_hip_debug_set_two_stage(int min_order);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EK_HIP_DEBUG_H */

@@ -1,0 +1,191 @@
+"""GPU parity of the two-stage tridiagonalisation (dense -> band -> tridiagonal) that the whole-path
+calls use for large orders in place of the one-stage PDSYTRD of solver_scalapack_all.f90:59 and the
+PDORMTR of :115.  Stage level: oracle-independent identities at rounding level (orthogonal similarity,
+band structure, spectrum); path level: the same oracle / ScaLAPACK-fixture / verifier bounds as the
+one-stage path, with the two-stage form forced on at small orders so that the CPU
+oracle can follow.  The full-size configurations run through it in tests/test_gpu_configs.py."""
+import os
+
+import numpy as np
+import pytest
+
+from eigenkernel_amd.verifier import eval_orthogonality, eval_residual_norm
+
+pytestmark = pytest.mark.gpu
+EPS = 2.220446049250313e-16
+B = 64
+
+
+def _band_of(Ab):
+    L = np.tril(Ab) - np.tril(Ab, -(B + 1))
+    return L + np.tril(L, -1).T
+
+
+def _q_from_reflectors(V, tau):
+    n = V.shape[0]
+    Q = np.eye(n)
+    for j in range(n - 1, -1, -1):
+        if tau[j] != 0.0:
+            v = V[:, j]
+            Q -= tau[j] * np.outer(v, v @ Q)
+    return Q
+
+
+def _random_band(n, seed):
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((n, n))
+    M = np.tril(M) - np.tril(M, -(B + 1))
+    return M + np.tril(M, -1).T
+
+
+@pytest.mark.parametrize("n", [3, 64, 65, 66, 130, 200, 257, 258, 321, 449, 700, 1000])
+def test_dense_to_band_is_an_orthogonal_similarity(hip, oracle, n):
+    """Panels with > 192 rows go through CholeskyQR2 + Householder reconstruction, the last ones through
+    the in-LDS Householder QR: both must give A = Q1 Bd Q1^T with Q1 orthogonal to rounding."""
+    A = oracle.synth_matrix(n, 1)
+    Ab, V, tau, flag = hip.sy2sb(A)
+    assert flag == 0
+    if n > B + 1:
+        assert np.abs(np.tril(Ab, -(B + 1))).max() == 0.0          # nothing is left below the band
+    Bd = _band_of(Ab)
+    Q = _q_from_reflectors(V, tau)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 64 * n * EPS
+    assert np.linalg.norm(Q.T @ A @ Q - Bd) <= 32 * n * EPS * np.linalg.norm(A)
+    w0, w1 = np.linalg.eigvalsh(A), np.linalg.eigvalsh(Bd)
+    assert np.abs(w0 - w1).max() <= 4 * n * EPS * np.abs(w0).max()
+    # reflector j starts at row j + 64: zeros above, unit entry on it
+    for j in range(0, max(n - B - 1, 0), 37):
+        assert np.all(V[:j + B, j] == 0.0) and (tau[j] == 0.0 or V[j + B, j] == 1.0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 65, 66, 100, 129, 200, 321, 640, 1000])
+def test_band_to_tridiagonal_by_bulge_chasing(hip, n):
+    Bd = _random_band(n, n)
+    d, e, Q2, flag = hip.sb2st(Bd, np.eye(n))
+    assert flag == 0
+    T = np.diag(d) + (np.diag(e, 1) + np.diag(e, -1) if n > 1 else 0.0)
+    nrm = max(np.linalg.norm(Bd), 1e-300)
+    assert np.linalg.norm(Q2.T @ Q2 - np.eye(n)) <= 64 * n * EPS
+    assert np.linalg.norm(Q2.T @ Bd @ Q2 - T) <= 32 * n * EPS * nrm
+    w0, w1 = np.linalg.eigvalsh(Bd), np.linalg.eigvalsh(T)
+    assert np.abs(w0 - w1).max() <= 4 * n * EPS * max(np.abs(w0).max(), 1e-300)
+
+
+@pytest.mark.parametrize("kind", ["tridiagonal", "diagonal", "zero", "narrow_band", "block_diagonal"])
+def test_band_to_tridiagonal_degenerate_bands(hip, kind):
+    """tau = 0 reflectors, empty bulges, already tridiagonal input."""
+    n = 300
+    rng = np.random.default_rng(7)
+    if kind == "tridiagonal":
+        Bd = np.diag(rng.uniform(-1, 1, n)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    elif kind == "diagonal":
+        Bd = np.diag(rng.uniform(-1, 1, n))
+    elif kind == "zero":
+        Bd = np.zeros((n, n))
+    elif kind == "narrow_band":
+        M = np.tril(rng.standard_normal((n, n))); M = M - np.tril(M, -8); Bd = M + np.tril(M, -1).T
+    else:
+        Bd = np.zeros((n, n))
+        for i in range(0, n, 50):
+            blk = rng.standard_normal((50, 50)); Bd[i:i + 50, i:i + 50] = blk + blk.T
+    d, e, Q2, flag = hip.sb2st(Bd, np.eye(n))
+    assert flag == 0
+    T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    scale = max(np.linalg.norm(Bd), 1.0)
+    assert np.linalg.norm(Q2.T @ Q2 - np.eye(n)) <= 64 * n * EPS
+    assert np.linalg.norm(Q2.T @ Bd @ Q2 - T) <= 32 * n * EPS * scale
+
+
+def test_bulge_chasing_is_bitwise_reproducible(hip):
+    """The sweeps hand blocks to each other through agent-scope loads and stores guarded by progress
+    words; a stale read would show up as run-to-run differences."""
+    Bd = _random_band(777, 1)
+    d0, e0, _, _ = hip.sb2st(Bd)
+    for _ in range(4):
+        d1, e1, _, f = hip.sb2st(Bd)
+        assert f == 0 and np.array_equal(d0, d1) and np.array_equal(e0, e1)
+
+
+@pytest.fixture()
+def forced_two_stage(hip):
+    hip.set_two_stage(100)
+    yield
+    hip.set_two_stage(-1)
+
+
+def _check_pairs(A, Bm, w, Z, n_vec=None):
+    n = A.shape[0]
+    n_vec = n if n_vec is None else n_vec
+    _, _, mx = eval_residual_norm(A, w[:n_vec], Z[:, :n_vec], Bm)
+    assert mx <= 1e-14 * max(1.0, np.sqrt(n / 1024.0)), mx
+    assert eval_orthogonality(Z[:, :n_vec], Bm) <= 1e-11
+
+
+@pytest.mark.parametrize("n", [100, 129, 257, 640, 1000])
+def test_whole_path_through_two_stages_matches_oracle(hip, oracle, forced_two_stage, n):
+    A = oracle.synth_matrix(n, 1)
+    Bm = oracle.synth_matrix(n, 2)
+    w_or = oracle.solve(A, Bm)[0]
+    ep, _ = hip.eigen_solver("general_hip", A, Bm)
+    assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * np.abs(w_or).max()
+    _check_pairs(A, Bm, ep.values, ep.Vectors)
+    w_or = oracle.solve(A)[0]
+    ep, _ = hip.eigen_solver("hip", A)
+    assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * np.abs(w_or).max()
+    _check_pairs(A, None, ep.values, ep.Vectors)
+    ep, _ = hip.eigen_solver("general_hip_select", A, Bm, n_vec=37)
+    _check_pairs(A, Bm, ep.values, ep.Vectors, 37)
+
+
+def test_two_stage_and_one_stage_agree(hip, oracle):
+    n = 700
+    A = oracle.synth_matrix(n, 1); Bm = oracle.synth_matrix(n, 2)
+    hip.set_two_stage(0)
+    try:
+        ep1, _ = hip.eigen_solver("general_hip", A, Bm)
+        hip.set_two_stage(100)
+        ep2, _ = hip.eigen_solver("general_hip", A, Bm)
+    finally:
+        hip.set_two_stage(-1)
+    assert np.abs(ep1.values - ep2.values).max() <= 4 * n * EPS * np.abs(ep1.values).max()
+    # eigenvectors agree up to sign (the spectrum of the generator is simple)
+    Bz = Bm @ ep2.Vectors
+    dots = np.abs(np.einsum("ij,ij->j", ep1.Vectors, Bz))
+    assert np.abs(dots - 1.0).max() <= 1e-9
+
+
+@pytest.mark.parametrize("kind", ["banded", "diagonal", "rank_deficient_panel", "low_rank_plus_identity"])
+def test_inputs_cholesky_qr_cannot_factor_fall_back_to_one_stage(hip, oracle, forced_two_stage, kind):
+    """A panel without full column rank makes CholeskyQR2 raise its flag on the device (stage level:
+    flag != 0); the whole-path call then repeats the reduction with the one-stage algorithm and still
+    returns correct pairs."""
+    n = 500
+    rng = np.random.default_rng(3)
+    if kind == "banded":
+        M = np.tril(rng.standard_normal((n, n))); M = M - np.tril(M, -5); A = M + np.tril(M, -1).T
+    elif kind == "diagonal":
+        A = np.diag(rng.uniform(1, 2, n))
+    elif kind == "rank_deficient_panel":
+        A = oracle.synth_matrix(n, 1); A[64:, 3] = 0.0; A[3, 64:] = 0.0          # a zero column in the first panel
+    else:
+        u = rng.standard_normal((n, 3)); A = u @ u.T + np.eye(n)
+    _, _, _, flag = hip.sy2sb(A)
+    assert flag != 0
+    w_or = np.linalg.eigvalsh(A)
+    ep, _ = hip.eigen_solver("hip", A)
+    assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * max(np.abs(w_or).max(), 1.0)
+    _check_pairs(A, None, ep.values, ep.Vectors)
+
+
+def test_grid_cell_piece_through_two_stages_is_bit_identical(hip, oracle, forced_two_stage):
+    """Replicated-input mode on a 2 x 2 grid: the cell's block-cyclic piece equals the 1 x 1 result."""
+    from eigenkernel_amd import descriptor as dsc
+    n = 400
+    A = oracle.synth_matrix(n, 1); Bm = oracle.synth_matrix(n, 2)
+    ep, _ = hip.eigen_solver("general_hip", A, Bm)
+    proc = hip.Process(my_rank=3, n_procs=4, n_procs_row=2, n_procs_col=2, my_proc_row=1, my_proc_col=1)
+    epg, _ = hip.eigen_solver("general_hip", A, Bm, proc=proc)
+    nb = int(epg.desc[dsc.BLOCK_ROW_])
+    ri = dsc.local_indices(n, nb, 1, 2); ci = dsc.local_indices(n, nb, 1, 2)
+    assert np.array_equal(epg.values, ep.values)
+    assert np.array_equal(epg.Vectors[:len(ri), :len(ci)], ep.Vectors[np.ix_(ri, ci)])

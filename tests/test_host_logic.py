@@ -90,10 +90,16 @@ def test_verifier_normalisations():
 
 
 def test_header_and_library_export_the_same_symbols():
-    """Every function include/ek_hip.h declares is exported by libek_hip.so and bound by the
-    host mirror (no compute call: works without a GPU)."""
+    """Every function include/ek_hip.h (the drop-in boundary) and include/ek_hip_debug.h (tuning / test
+    hooks) declare is exported by libek_hip.so and bound by the host mirror (no compute call: works
+    without a GPU); the boundary header carries no debug or profile hook."""
     hdr = open(os.path.join(ROOT, "include", "ek_hip.h")).read()
-    declared = set(re.findall(r"\b(ek_hip_\w+)\s*\(", hdr))
+    dbg = open(os.path.join(ROOT, "include", "ek_hip_debug.h")).read()
+    boundary = set(re.findall(r"\b(ek_hip_\w+)\s*\(", hdr))
+    hooks = set(re.findall(r"\b(ek_hip_\w+)\s*\(", dbg))
+    assert not any("debug" in f or "profile" in f for f in boundary)
+    assert not (boundary & hooks)
+    declared = boundary | hooks
     assert declared == set(solver.EXPORTED_SYMBOLS)
     assert os.path.exists(solver.LIB_PATH), "build with __graft_entry__.build()"
     lib = ctypes.CDLL(solver.LIB_PATH)
