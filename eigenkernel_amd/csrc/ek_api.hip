@@ -1204,7 +1204,7 @@ int ek_hip_debug_sb2st(int n, const double *A, int lda, double *d, double *e, do
   sb2st_lower(s, n, dA, ld, dd, de, dV2, ld, g_ctx.d_info + 2, work);
   if (ncols > 0) {
     rc = h2d_matrix(n, ncols, Z, ldz, dZ, ld, s); if (rc) return rc;
-    sb2st_apply_q2(s, n, ncols, dV2, ld, dZ, ld, work);
+    sb2st_apply_q2(s, n, ncols, dV2, ld, dZ, ld, g_ctx.d_info + 2, work);
     rc = d2h_matrix(n, ncols, dZ, ld, Z, ldz, s); if (rc) return rc;
   }
   EK_HIP_CHECK(hipGetLastError());
@@ -1269,7 +1269,7 @@ int ek_hip_debug_two_stage_timing(int n, int ncols, int reps, double *seconds, i
     EK_HIP_CHECK(hipEventRecord(ev[1], s));
     sb2st_lower(s, n, dA, ld, dd, de, dV2, ld, g_ctx.d_info + 2, w2);
     EK_HIP_CHECK(hipEventRecord(ev[2], s));
-    sb2st_apply_q2(s, n, ncols, dV2, ld, dZ, ld, w2);
+    sb2st_apply_q2(s, n, ncols, dV2, ld, dZ, ld, g_ctx.d_info + 2, w2);
     EK_HIP_CHECK(hipEventRecord(ev[3], s));
     ormtr_lower(s, n, ncols, dV, ld, dt, dZ, ld, w3);
     EK_HIP_CHECK(hipEventRecord(ev[4], s));
@@ -1674,7 +1674,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   mark();                                                              // 5
   double *zc = wZ;
   if (two_stage_done) {
-    sb2st_apply_q2(s, n, nc_loc, wV2, ld, zc, ld, work_sb2st);
+    sb2st_apply_q2(s, n, nc_loc, wV2, ld, zc, ld, g_ctx.d_info + 2, work_sb2st);
     ormtr_lower(s, n, nc_loc, wV, ld, dt1, zc, ld, work);
   } else {
     ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work);
@@ -1711,6 +1711,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", comm_error_string());
     return -996;
   }
+  if (two_stage_done && info[2] != 0) return -992;   // the pipelined back-transformation was abandoned (a bounded wait ran out)
   if (info[0] != 0) return info[0];          // Cholesky: leading minor not positive definite
   if (info[1] != 0) return 100000 + info[1];  // tridiagonal eigensolver did not converge
   return 0;

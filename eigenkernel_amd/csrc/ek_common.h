@@ -225,8 +225,9 @@ size_t sb2st_work_bytes(int n);
 // persistent kernel had to be abandoned.  work: >= sb2st_work_bytes(n), shared with sb2st_apply_q2.
 void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, double *e, double *V2, int ldv2,
                  int *d_flag, void *work);
-// Z(:, 0:ncols) <- Q2 Z
-void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2, double *Z, int ldz, void *work);
+// Z(:, 0:ncols) <- Q2 Z (Z 16-byte aligned, ldz even); *d_flag |= 4 if the pipeline had to be abandoned
+void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2, double *Z, int ldz, int *d_flag,
+                    void *work);
 
 // ---------------------------------------------------------------- tridiagonal D&C (ek_stedc.hip)
 size_t stedc_work_bytes(int n);

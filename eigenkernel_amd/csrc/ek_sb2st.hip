@@ -299,6 +299,8 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
 }
 
 // ------------------------------------------------------------------------ Q2: compact-WY factors
+// Block S of sweeps = sweeps 32 S - 1 .. 32 S + 30 (block 0 has 31): with that offset every window of
+// rows starts on an EVEN row (o = 32 S + 64 k), so rows travel as aligned 16-byte pairs.
 constexpr int QG = 32;                 // sweeps per compact-WY block
 constexpr int QR = QG + SB;            // rows of a block's window (95 used, 96 with padding)
 constexpr int QVLD = QG + 1;           // LDS leading dimension of the V image (row-major)
@@ -307,23 +309,24 @@ constexpr int QREC = 2 * QR * QG;      // doubles per group record: V (96 x 32, 
 struct Q2Geom {
   int n, nsweeps, nS, kmax;            // kmax: groups per block of sweeps (uniform index S * kmax + k)
 };
+__host__ __device__ inline int q2_first_sweep(int S) { return S * QG - 1; }
 __host__ __device__ inline int q2_groups_of_block(int n, int S) {   // number of k for which any reflector exists
-  const int s0 = S * QG;
+  int s0 = q2_first_sweep(S); if (s0 < 0) s0 = 0;
   return (s0 <= n - 3) ? (n - 3 - s0) / SB + 1 : 0;
 }
 
-// V image of group (S, k): rows o .. o + QR - 1 (o = S*QG + 1 + k*SB), column i = sweep S*QG + i,
+// V image of group (S, k): rows o .. o + QR - 1 (o = 32 S + 64 k), column i = sweep 32 S - 1 + i,
 // non-zero for i <= row - o < i + SB where the reflector (s, k) exists.
 __device__ __forceinline__ double q2_v_entry(const Q2Geom &g, const double *__restrict__ V2, int ldv2, int S, int k,
                                              int rr, int i) {
-  const int s = S * QG + i, o = S * QG + 1 + k * SB, row = o + rr;
-  if (s >= g.nsweeps || rr < i || rr >= i + SB || row >= g.n) return 0.0;
+  const int s = q2_first_sweep(S) + i, o = S * QG + k * SB, row = o + rr;
+  if (s < 0 || s >= g.nsweeps || rr < i || rr >= i + SB || row >= g.n) return 0.0;
   if (s + 1 + k * SB > g.n - 2) return 0.0;                 // task (s, k) does not exist
   return V2[(size_t)row + (size_t)s * ldv2];
 }
 
 // One wave per group: T (DLARFT, forward columnwise) from the reflectors and their tau, then the
-// record [V | V T] the application streams.
+// record [V | -V T] the application streams.
 __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *__restrict__ V2, int ldv2,
                                                         const double *__restrict__ tau2, int ldt,
                                                         double *__restrict__ Rec) {
@@ -342,8 +345,8 @@ __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *
   for (int idx = lane; idx < QG * QVLD; idx += 64) sT[idx] = 0.0;
   wave_sync();
   for (int i = 0; i < QG; ++i) {
-    const int s = S * QG + i;
-    const bool exists = s < g.nsweeps && s + 1 + k * SB <= g.n - 2;
+    const int s = q2_first_sweep(S) + i;
+    const bool exists = s >= 0 && s < g.nsweeps && s + 1 + k * SB <= g.n - 2;
     const double ti = exists ? tau2[(size_t)k + (size_t)s * ldt] : 0.0;
     if (lane < i) {                              // g_a = v_a^T v_i over the common rows [i, a + SB)
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -380,88 +383,158 @@ __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *
 }
 
 // ------------------------------------------------------------------------ Q2: application
-// Workgroup (4 waves) = 64 columns of Z, every wave streams its own 16 columns down the rows and
-// keeps its window of Z in REGISTERS: the accumulator layout of v_mfma_f64_16x16x4 (D(i,j) in lane
-// (j = lane & 15, i = lane / 16 + 4 reg)) is also the layout of its second operand for the k-step
-// over rows 4 reg .. 4 reg + 3, so the same registers serve as the operand of W1 = V^T Zw and as the
-// accumulator of Zw += (-V T) W1, and W1 itself goes from the first product into the second without
-// leaving the registers.  Only the factors [V | -V T] of a group pass through LDS (double buffered,
-// one workgroup barrier per group); rows enter and leave through a small per-wave transposing buffer.
-// For a block of sweeps S the windows of consecutive k slide down by 64 rows: window k = chunk k
-// (64 rows from S*32 + 1 + 64 k) + the first 32 rows of chunk k+1; two chunks are in registers,
-// chunk k+2 and the record of group k+1 are in flight while group k is applied.
+// Z <- Q2 Z as a two-dimensional pipeline of PASSES (S, slab): pass = one block of sweeps S applied to
+// one slab of 64 columns, walking down the rows in chunks of 64 (window k = chunk k + half of chunk
+// k+1, sliding by one chunk per group).  Pass (S, slab) may touch chunk j once pass (S+1, slab) has
+// finished it, so passes of one slab follow each other a few chunks apart: few columns (the *_select
+// arms) still fill the chip, and many columns run two passes per CU (two waves per SIMD is what
+// the fp64 matrix pipe needs, profiles/r02_mfma_peak.txt).  Persistent workgroups take passes from
+// a ticket counter in dependency order (S descending), so a workgroup only waits for passes whose
+// owners are running; a finished chunk is handed over through memory with agent-scope (sc1) stores,
+// a drain, a barrier and one progress word per pass, like the sweeps of chase_kernel.
+//
+// Inside a pass every wave streams its own 16 columns and keeps its window of Z in REGISTERS: the
+// accumulator layout of v_mfma_f64_16x16x4 (D(i,j) in lane (j = lane & 15, i = lane / 16 + 4 reg)) is
+// also the layout of its second operand for the k-step over rows 4 reg .. 4 reg + 3, so the same
+// registers serve as the operand of W1 = V^T Zw and as the accumulator of Zw += (-V T) W1, and W1
+// goes from the first product into the second without leaving the registers.  Only the factors
+// [V | -V T] of a group pass through LDS.
 constexpr int QNC = 64;
-constexpr int QSTLD = 17;
-constexpr int QOPSZ = 2 * QR * QVLD;   // doubles per operand buffer: V image, then -V T image (row-major, QVLD)
+constexpr int QSTLD = 34;              // per-wave transposing buffer: 16 columns x 32 rows (+2), column-major
+constexpr int QOPSZ = 2 * QR * QVLD;   // doubles of the operand buffer: V image, then -V T image (row-major, QVLD)
+constexpr unsigned kQ2Done = 0x7fffffffu;
 
 struct Q2ApplyArgs {
   Q2Geom g;
   const double *Rec;
   double *Z; int ldz; int ncols;
+  int nslab, npass;
+  unsigned *prog;        // [npass] chunks stored by pass (S, slab) at index (nS-1-S) * nslab + slab
+  unsigned *ctl;         // [2] ticket, [1] abort (shared with the chase)
+  int extra;             // chunks a pass keeps behind its predecessor beyond the two it must
 };
 
-__global__ __launch_bounds__(256) void q2_apply_kernel(Q2ApplyArgs p) {
+typedef double d2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_sc1_x2(double *p, double a, double b) {
+  d2_t v = {a, b};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
   extern __shared__ double q2smem[];
-  double *sOp = q2smem;                                 // 2 operand buffers
+  double *sOp = q2smem;
+  __shared__ int s_pass, s_ok;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
-  double *st = q2smem + 2 * QOPSZ + wave * 64 * QSTLD;  // this wave's transposing buffer (64 x 16)
-  const int colw = blockIdx.x * QNC + 16 * wave;
+  double *st = q2smem + QOPSZ + wave * 16 * QSTLD;      // this wave's transposing buffer
   const int n = p.g.n;
-  double4_t za[4], zb[4];
-  double zreg[16], oreg[24];
-  auto fetch_ops = [&](int S, int k) {
-    const double *rec = p.Rec + ((size_t)S * p.g.kmax + k) * QREC;
-#pragma unroll
-    for (int q = 0; q < 24; ++q) oreg[q] = rec[t + 256 * q];
-  };
-  auto put_ops = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < 24; ++q) {
-      const int idx = t + 256 * q, half = idx / (QR * QG), e = idx % (QR * QG), rr = e % QR, i = e / QR;
-      sOp[buf * QOPSZ + half * QR * QVLD + rr * QVLD + i] = oreg[q];
-    }
-  };
-  auto fetch_chunk = [&](int S, int j) {
-    const int row = S * QG + 1 + SB * j + lane;
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-      zreg[c] = (row < n && colw + c < p.ncols) ? p.Z[(size_t)row + (size_t)(colw + c) * p.ldz] : 0.0;
-  };
-  auto chunk_to_tiles = [&](double4_t (&z)[4]) {       // zreg (row per lane) -> accumulator layout
-#pragma unroll
-    for (int c = 0; c < 16; ++c) st[lane * QSTLD + c] = zreg[c];
-    wave_sync();
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) z[tt][r] = st[(16 * tt + l4 + 4 * r) * QSTLD + l15];
-    wave_sync();
-  };
-  auto tiles_to_global = [&](int S, int j, const double4_t (&z)[4]) {
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) st[(16 * tt + l4 + 4 * r) * QSTLD + l15] = z[tt][r];
-    wave_sync();
-    const int row = S * QG + 1 + SB * j + lane;
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-      if (row < n && colw + c < p.ncols) p.Z[(size_t)row + (size_t)(colw + c) * p.ldz] = st[lane * QSTLD + c];
-    wave_sync();
-  };
-  for (int S = p.g.nS - 1; S >= 0; --S) {
+  const double *sV = sOp, *sVT = sOp + QR * QVLD;
+  while (true) {
+    __syncthreads();
+    if (t == 0) s_pass = (int)atomicAdd(&p.ctl[2], 1u);
+    __syncthreads();
+    const int pass = s_pass;
+    if (pass >= p.npass) break;
+    const int S = p.g.nS - 1 - pass / p.nslab, slab = pass % p.nslab;
     const int KS = q2_groups_of_block(n, S);
-    if (KS <= 0) continue;
-    fetch_chunk(S, 0); chunk_to_tiles(za);
-    fetch_chunk(S, 1); chunk_to_tiles(zb);
-    fetch_ops(S, 0);
-    __syncthreads();                                   // nobody still reads buffer 0 (previous block of sweeps)
-    put_ops(0);
+    const int colw = slab * QNC + 16 * wave;
+    const unsigned *pprog = (S + 1 < p.g.nS) ? p.prog + (size_t)(pass - p.nslab) : nullptr;   // predecessor (S+1, slab)
+    unsigned *myprog = p.prog + pass;
+    if (KS <= 0) { if (t == 0) __hip_atomic_store(myprog, kQ2Done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
+    const int o0 = S * QG;                               // first row of chunk 0 (even)
+    // chunks of the predecessor are offset by +32 rows: chunk j of this pass is final once the predecessor
+    // has stored its chunks <= j; waiting for `need` stored chunks, bounded
+    auto wait_for = [&](unsigned need) -> bool {         // thread 0 only
+      if (!pprog) return true;
+      unsigned spins = 0;
+      while (__hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 63u) == 0u &&
+            (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+          return false;
+      }
+      return true;
+    };
+    double4_t za[4], zb[4];
+    double zreg[16], oreg[24];
+    auto fetch_ops = [&](int k) {
+      const double *rec = p.Rec + ((size_t)S * p.g.kmax + k) * QREC;
+#pragma unroll
+      for (int q = 0; q < 24; ++q) oreg[q] = rec[t + 256 * q];
+    };
+    auto put_ops = [&]() {
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        const int idx = t + 256 * q, half = idx / (QR * QG), e = idx % (QR * QG), rr = e % QR, i = e / QR;
+        sOp[half * QR * QVLD + rr * QVLD + i] = oreg[q];
+      }
+    };
+    // chunk j -> zreg: lane = row of the chunk, 16 columns (sc1: another pass may have written them)
+    auto fetch_chunk = [&](int j) {
+      const int row = o0 + SB * j + lane;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        zreg[c] = (row < n && colw + c < p.ncols) ? ld_sc1(p.Z + (size_t)row + (size_t)(colw + c) * p.ldz) : 0.0;
+    };
+    // zreg (row per lane) -> accumulator layout, through the per-wave buffer in two halves of 32 rows
+    auto chunk_to_tiles = [&](double4_t (&z)[4]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) st[c * QSTLD + (lane & 31)] = zreg[c];
+        }
+        wave_sync();
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[2 * h + tt][r] = st[l15 * QSTLD + 16 * tt + l4 + 4 * r];
+        wave_sync();
+      }
+    };
+    // accumulator layout -> memory as aligned row pairs (16-byte write-through stores)
+    auto tiles_to_global = [&](int j, const double4_t (&z)[4]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[l15 * QSTLD + 16 * tt + l4 + 4 * r] = z[2 * h + tt][r];
+        wave_sync();
+        {
+          const int pr = lane & 15, cg = lane >> 4;      // row pair of this half, 4 columns per lane
+          const int row = o0 + SB * j + 32 * h + 2 * pr;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = 4 * cg + q;
+            if (colw + c < p.ncols) {
+              const double a = st[c * QSTLD + 2 * pr], b = st[c * QSTLD + 2 * pr + 1];
+              double *dst = p.Z + (size_t)row + (size_t)(colw + c) * p.ldz;
+              if (row + 1 < n) st_sc1_x2(dst, a, b);
+              else if (row < n) st_sc1(dst, a);
+            }
+          }
+        }
+        wave_sync();
+      }
+    };
+    // ---- prologue: chunks 0 and 1 need the predecessor's chunks <= 1 (+ slack)
+    if (t == 0) s_ok = wait_for((unsigned)(2 + p.extra)) ? 1 : 0;
+    __syncthreads();
+    if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    fetch_chunk(0); chunk_to_tiles(za);
+    fetch_chunk(1); chunk_to_tiles(zb);
+    fetch_ops(0);
     for (int k = 0; k < KS; ++k) {
-      const int buf = k & 1;
+      // gate of this group: chunk k+2 is fetched below, it needs the predecessor's chunks <= k+2
+      if (t == 0) s_ok = wait_for((unsigned)(k + 3 + p.extra)) ? 1 : 0;
+      // the stores of chunk k-1 have completed: tell the follower (after the barrier)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (k + 1 < KS) { fetch_ops(S, k + 1); fetch_chunk(S, k + 2); }
-      const double *sV = sOp + buf * QOPSZ, *sVT = sV + QR * QVLD;
+      if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+      if (t == 0 && k > 0) __hip_atomic_store(myprog, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      put_ops();
+      __syncthreads();
+      if (k + 1 < KS) { fetch_ops(k + 1); fetch_chunk(k + 2); }
       double4_t w1[2];
       w1[0] = (double4_t){0.0, 0.0, 0.0, 0.0}; w1[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -484,13 +557,15 @@ __global__ __launch_bounds__(256) void q2_apply_kernel(Q2ApplyArgs p) {
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xrow[kk], w1[kk >> 4][(kk & 15) >> 2], acc, 0, 0, 0);
         if (tile < 4) za[tile & 3] = acc; else zb[tile & 3] = acc;
       }
-      if (k + 1 < KS) put_ops(buf ^ 1);
-      tiles_to_global(S, k, za);                       // chunk k is final for this block of sweeps
+      tiles_to_global(k, za);                            // chunk k is final for this block of sweeps
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) za[tt] = zb[tt];
-      if (k + 1 < KS) chunk_to_tiles(zb);              // chunk k+2
-      else tiles_to_global(S, k + 1, za);
+      if (k + 1 < KS) chunk_to_tiles(zb);                // chunk k+2
+      else tiles_to_global(k + 1, za);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(myprog, kQ2Done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -500,10 +575,10 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Layout {
   int nsweeps, nS, kmax, ldt;
-  size_t off_ab, off_tau, off_prog, off_ctl, off_T, total;
+  size_t off_ab, off_tau, off_prog, off_ctl, off_T, off_qprog, total;
   explicit Layout(int n) {
     nsweeps = n > 2 ? n - 2 : 0;
-    nS = ceil_div(nsweeps > 0 ? nsweeps : 1, QG);
+    nS = ceil_div((nsweeps > 0 ? nsweeps : 1) + 1, QG);   // block S = sweeps 32 S - 1 .. 32 S + 30
     kmax = q2_groups_of_block(n, 0); if (kmax < 1) kmax = 1;
     ldt = kmax + 1;
     size_t o = 0;
@@ -512,6 +587,7 @@ struct Layout {
     off_prog = o; o += al256((size_t)(nsweeps + 1) * 4);
     off_ctl = o; o += 256;
     off_T = o; o += al256((size_t)nS * kmax * QREC * 8);
+    off_qprog = o; o += al256((size_t)nS * ceil_div(n, QNC) * 4);
     total = o;
   }
 };
@@ -560,21 +636,31 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
 }
 
 // Z(:, 0:ncols) <- Q2 Z with the reflectors left by sb2st_lower (same V2, same workspace)
-void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2, double *Z, int ldz, void *work) {
+void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2, double *Z, int ldz, int *d_flag,
+                    void *work) {
   if (n <= 2 || ncols <= 0) return;
   const Layout L(n);
   char *w = (char *)work;
   const double *tau2 = (const double *)(w + L.off_tau);
   double *Rec = (double *)(w + L.off_T);
+  unsigned *ctl = (unsigned *)(w + L.off_ctl), *qprog = (unsigned *)(w + L.off_qprog);
   Q2Geom g{n, L.nsweeps, L.nS, L.kmax};
   hipLaunchKernelGGL(q2_tfactor_kernel, dim3(L.kmax, L.nS), dim3(64), 0, s, g, V2, ldv2, tau2, L.ldt, Rec);
-  constexpr size_t lds = (size_t)(2 * QOPSZ + 4 * 64 * QSTLD) * sizeof(double);
+  constexpr size_t lds = (size_t)(QOPSZ + 4 * 16 * QSTLD) * sizeof(double);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)q2_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  Q2ApplyArgs a{g, Rec, Z, ldz, ncols};
+  const int nslab = ceil_div(ncols, QNC), npass = L.nS * nslab;
+  (void)hipMemsetAsync(qprog, 0, (size_t)npass * 4, s);
+  (void)hipMemsetAsync(ctl + 2, 0, 4, s);
+  Q2ApplyArgs a{g, Rec, Z, ldz, ncols, nslab, npass, qprog, ctl, 2};
+  if (const char *ev = getenv("EK_Q2_EXTRA")) a.extra = atoi(ev);
+  int nwg = 512;
+  if (const char *ev = getenv("EK_Q2_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
+  if (nwg > npass) nwg = npass;
   kprof_begin(s, kProfQ2Apply);
-  hipLaunchKernelGGL(q2_apply_kernel, dim3(ceil_div(ncols, QNC)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(q2_apply_kernel, dim3(nwg), dim3(256), lds, s, a);
   kprof_end(s, kProfQ2Apply);
+  if (d_flag) hipLaunchKernelGGL(forward_abort_kernel, dim3(1), dim3(1), 0, s, ctl, d_flag);
 }
 
 }  // namespace ek
