@@ -83,21 +83,48 @@ struct ChaseArgs {
 
 constexpr unsigned kSpinLimit = 1u << 22;
 
+struct ChaseArgs;
+// One wave: DLARFG on x (lane = row, x = 0 beyond the block) -> v into LDS and into the reflector store of
+// the sweep, tau; returns beta in every lane.
+template <typename Args>
+__device__ __forceinline__ double make_reflector(double x, int lane, int L, int i0, int s, int k, const Args &p,
+                                                 double *sv, double *stau) {
+  double ssq = (lane >= 1) ? x * x : 0.0;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) ssq += __shfl_xor(ssq, o, 64);
+  const double alpha0 = __shfl(x, 0, 64);
+  double beta = alpha0, tau = 0.0, scale = 0.0;
+  if (ssq != 0.0) {
+    beta = -copysign(sqrt(alpha0 * alpha0 + ssq), alpha0);   // the path keeps |A| within 1e+-90
+    tau = (beta - alpha0) / beta;
+    scale = 1.0 / (alpha0 - beta);
+  }
+  const double v = (lane == 0) ? 1.0 : x * scale;    // rows >= L carry x = 0
+  sv[lane] = v;
+  if (lane == 0) { *stau = tau; p.tau2[(size_t)k + (size_t)s * p.ldt] = tau; }
+  if (lane < L) p.V2[(size_t)(i0 + lane) + (size_t)s * p.ldv2] = v;
+  return beta;
+}
+
 // Per task the workgroup synchronises three times; the progress word of task k-1 is published in
 // the middle of task k (its stores have drained by then: nobody stalls on the write-through), and
 // the gate of task k+1 is looked at without blocking while task k computes, so that its blocks are
 // already in flight when the task starts.
-__global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
-  __shared__ double s_v[SB];
-  __shared__ double s_p[4][SB], s_q[4][SB];
-  __shared__ double s_t[4][16 * 65];
+// NW waves per workgroup, each with CW = 64 / NW columns of a block (row per lane).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
+  constexpr int CW = SB / NW;            // columns of a block per wave
+  constexpr int LPC = 64 / CW;           // lanes that share one column in the transposed reduction
+  __shared__ double s_v[2][SB];
+  __shared__ double s_p[NW][SB], s_q[NW][SB];
+  __shared__ double s_t[NW][CW * 65];
   __shared__ double s_D[SB * DLD];
   __shared__ double s_z[SB];
-  __shared__ double s_tau;
+  __shared__ double s_tau[2];
   __shared__ int s_sweep, s_ok, s_gate;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n = p.n;
-  const int c0w = 16 * wave;                               // this wave's columns of a block
+  const int c0w = CW * wave;                               // this wave's columns of a block
   const bool immediate = p.extra < 0;                      // publish every task at its end, no look-ahead
   double *AB = p.AB;
   while (true) {
@@ -108,9 +135,9 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
     if (s >= p.nsweeps) break;
     const int K = (n - 3 - s) / SB + 1;
     const int Kprev = (s > 0) ? (n - 2 - s) / SB + 1 : 0;
-    double bp[16], dl[16], bk[16];
+    double bp[CW], dl[CW], bk[CW];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { bp[j] = 0.0; dl[j] = 0.0; bk[j] = 0.0; }
+    for (int j = 0; j < CW; ++j) { bp[j] = 0.0; dl[j] = 0.0; bk[j] = 0.0; }
     bool have_pf = false;
     for (int k = 0; k < K; ++k) {
       const int i0 = s + 1 + k * SB;                       // first index of I_k
@@ -141,7 +168,7 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
         __syncthreads();
         if (!s_ok) return;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < CW; ++j) {
           const int c = c0w + j;
           dl[j] = (lane < L && c <= lane) ? ld_sc1(AB + (size_t)(lane - c) + (size_t)(i0 + c) * LDAB) : 0.0;
           bk[j] = (lane < L1 && c < L) ? ld_sc1(AB + (size_t)(SB + lane - c) + (size_t)(i0 + c) * LDAB) : 0.0;
@@ -152,57 +179,45 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
       unsigned gate_val = 0;
       if (!immediate && t == 0 && s > 0 && k + 1 < K)
         gate_val = __hip_atomic_load(&p.prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // ---- (a) the reflector: x = A(I_k, s) for k = 0, else the first column of B_{k-1}
-      if (wave == 0) {
-        double x = 0.0;
-        if (k == 0) { if (lane < L) x = ld_sc1(AB + (size_t)(1 + lane) + (size_t)s * LDAB); }
-        else x = bp[0];
-        double ssq = (lane >= 1) ? x * x : 0.0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) ssq += __shfl_xor(ssq, o, 64);
-        const double alpha0 = __shfl(x, 0, 64);
-        double beta = alpha0, tau = 0.0, scale = 0.0;
-        if (ssq != 0.0) {
-          beta = -copysign(sqrt(alpha0 * alpha0 + ssq), alpha0);   // the path keeps |A| within 1e+-90
-          tau = (beta - alpha0) / beta;
-          scale = 1.0 / (alpha0 - beta);
+      // ---- (a) the reflector of task 0: x = A(I_0, s).  Those of the later tasks were made at the end of
+      // the previous task (below), beside the drain of its stores.
+      const int cur = k & 1;
+      if (k == 0) {
+        if (wave == 0) {
+          const double x = (lane < L) ? ld_sc1(AB + (size_t)(1 + lane) + (size_t)s * LDAB) : 0.0;
+          const double beta = make_reflector(x, lane, L, i0, s, k, p, s_v[cur], &s_tau[cur]);
+          if (lane < L) st_sc1(AB + (size_t)(1 + lane) + (size_t)s * LDAB, (lane == 0) ? beta : 0.0);
         }
-        const double v = (lane == 0) ? 1.0 : x * scale;    // rows >= L carry x = 0
-        s_v[lane] = v;
-        if (lane == 0) { s_tau = tau; p.tau2[(size_t)k + (size_t)s * p.ldt] = tau; }
-        if (lane < L) p.V2[(size_t)(i0 + lane) + (size_t)s * p.ldv2] = v;
-        const double xnew = (lane == 0) ? beta : 0.0;
-        if (k == 0) { if (lane < L) st_sc1(AB + (size_t)(1 + lane) + (size_t)s * LDAB, xnew); }
-        else bp[0] = xnew;
+        __syncthreads();                                                     // #1 (first task only)
       }
-      __syncthreads();                                                       // #1
+
       if (prof) tc2 = clock64();
-      const double tau = s_tau;
-      const double v_r = s_v[lane];
-      double vc[16];
+      const double tau = s_tau[cur];
+      const double v_r = s_v[cur][lane];
+      double vc[CW];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) vc[j] = s_v[c0w + j];
+      for (int j = 0; j < CW; ++j) vc[j] = s_v[cur][c0w + j];
       // ---- (b) B_{k-1} <- H B_{k-1} (rows I_k, columns I_{k-1}), then it is final for this sweep
       if (k > 0) {
         double *st = s_t[wave];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) st[j * 65 + lane] = v_r * bp[j];
+        for (int j = 0; j < CW; ++j) st[j * 65 + lane] = v_r * bp[j];
         wave_sync();
         {
-          const int j = lane >> 2, q = lane & 3;
-          const double *src = st + j * 65 + 16 * q;
-          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          const int j = lane / LPC, q = lane % LPC;
+          const double *src = st + j * 65 + CW * q;
+          double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-          for (int l = 0; l < 16; l += 4) { a0 += src[l]; a1 += src[l + 1]; a2 += src[l + 2]; a3 += src[l + 3]; }
-          double tot = (a0 + a1) + (a2 + a3);
-          tot += __shfl_xor(tot, 1, 64);
-          tot += __shfl_xor(tot, 2, 64);
+          for (int l = 0; l < CW; l += 2) { a0 += src[l]; a1 += src[l + 1]; }
+          double tot = a0 + a1;
+#pragma unroll
+          for (int o = 1; o < LPC; o <<= 1) tot += __shfl_xor(tot, o, 64);
           if (q == 0) s_z[c0w + j] = tot;
         }
         wave_sync();
         const int ip = i0 - SB;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < CW; ++j) {
           const int c = c0w + j;
           if (c > 0) bp[j] -= tau * v_r * s_z[c];          // column 0 is (beta, 0, ..., 0) already
           if (lane < L) st_sc1(AB + (size_t)(SB + lane - c) + (size_t)(ip + c) * LDAB, bp[j]);
@@ -210,7 +225,7 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
       }
       // ---- D_k as a full symmetric image
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < CW; ++j) {
         const int c = c0w + j;
         if (c <= lane) { s_D[lane * DLD + c] = dl[j]; s_D[c * DLD + lane] = dl[j]; }
       }
@@ -221,11 +236,11 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
       if (t == 0 && k > 0 && !immediate)
         __hip_atomic_store(&p.prog[s], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // ---- partial sums of p = D v and q = B_k v
-      double dd[16];
+      double dd[CW];
       {
         double pp = 0.0, qq = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { dd[j] = s_D[lane * DLD + c0w + j]; pp += dd[j] * vc[j]; qq += bk[j] * vc[j]; }
+        for (int j = 0; j < CW; ++j) { dd[j] = s_D[lane * DLD + c0w + j]; pp += dd[j] * vc[j]; qq += bk[j] * vc[j]; }
         s_p[wave][lane] = pp; s_q[wave][lane] = qq;
       }
       if (t == 0) {
@@ -236,40 +251,49 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
       if (prof) tc4 = clock64();
       // ---- blocks of task k+1 into flight if its gate is already open
       const bool gate = s_gate != 0;
-      double ndl[16], nbk[16];
+      double ndl[CW], nbk[CW];
       if (gate) {
         const int j0 = i0 + SB;
         const int Ln = (n - j0 < SB) ? n - j0 : SB;
         int L1n = n - j0 - SB; if (L1n > SB) L1n = SB; if (L1n < 0) L1n = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < CW; ++j) {
           const int c = c0w + j;
           ndl[j] = (lane < Ln && c <= lane) ? ld_sc1(AB + (size_t)(lane - c) + (size_t)(j0 + c) * LDAB) : 0.0;
           nbk[j] = (lane < L1n && c < Ln) ? ld_sc1(AB + (size_t)(SB + lane - c) + (size_t)(j0 + c) * LDAB) : 0.0;
         }
       }
       // ---- (c) D_k <- H D_k H
-      const double p_r = tau * ((s_p[0][lane] + s_p[1][lane]) + (s_p[2][lane] + s_p[3][lane]));
+      double psum = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) psum += s_p[w][lane];
+      const double p_r = tau * psum;
       double dot = p_r * v_r;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) dot += __shfl_xor(dot, o, 64);
       const double alpha = -0.5 * tau * dot;
       const double w_r = p_r + alpha * v_r;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < CW; ++j) {
         const int c = c0w + j;
-        const double w_c = tau * ((s_p[0][c] + s_p[1][c]) + (s_p[2][c] + s_p[3][c])) + alpha * vc[j];
+        double pc = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) pc += s_p[w][c];
+        const double w_c = tau * pc + alpha * vc[j];
         dd[j] -= v_r * w_c + w_r * vc[j];
         if (c <= lane && lane < L) st_sc1(AB + (size_t)(lane - c) + (size_t)(i0 + c) * LDAB, dd[j]);
       }
       // ---- (d) B_k <- B_k H (rows I_{k+1}, columns I_k); carried to the next task in registers
       if (L1 > 0) {
-        const double q_r = tau * ((s_q[0][lane] + s_q[1][lane]) + (s_q[2][lane] + s_q[3][lane]));
+        double qsum = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bp[j] = bk[j] - q_r * vc[j];
+        for (int w = 0; w < NW; ++w) qsum += s_q[w][lane];
+        const double q_r = tau * qsum;
+#pragma unroll
+        for (int j = 0; j < CW; ++j) bp[j] = bk[j] - q_r * vc[j];
         if (k == K - 1) {                                  // no further task in this sweep: store it now
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
+          for (int j = 0; j < CW; ++j) {
             const int c = c0w + j;
             if (lane < L1 && c < L) st_sc1(AB + (size_t)(SB + lane - c) + (size_t)(i0 + c) * LDAB, bp[j]);
           }
@@ -283,8 +307,16 @@ __global__ __launch_bounds__(256) void chase_kernel(ChaseArgs p) {
       have_pf = gate;
       if (gate) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { dl[j] = ndl[j]; bk[j] = nbk[j]; }
+        for (int j = 0; j < CW; ++j) { dl[j] = ndl[j]; bk[j] = nbk[j]; }
       }
+      // ---- the reflector of task k+1 from the first column of the new B_k, while this task's stores drain
+      if (k + 1 < K && wave == 0) {
+        const int i0n = i0 + SB;
+        const int Ln = (n - i0n < SB) ? n - i0n : SB;
+        const double beta = make_reflector(bp[0], lane, Ln, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
+        bp[0] = (lane == 0) ? beta : 0.0;
+      }
+      if (!immediate && k + 1 < K) __syncthreads();      // the new reflector is in LDS (immediate mode: barrier below)
       if (immediate && k + 1 < K) {        // tell the follower at once (the last task is told below)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -524,16 +556,21 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
     fetch_chunk(0); chunk_to_tiles(za);
     fetch_chunk(1); chunk_to_tiles(zb);
     fetch_ops(0);
+    unsigned early = 0;                                   // thread 0: an early look at the predecessor's progress
     for (int k = 0; k < KS; ++k) {
-      // gate of this group: chunk k+2 is fetched below, it needs the predecessor's chunks <= k+2
-      if (t == 0) s_ok = wait_for((unsigned)(k + 3 + p.extra)) ? 1 : 0;
-      // the stores of chunk k-1 have completed: tell the follower (after the barrier)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // gate of this group: chunk k+2 is fetched below, it needs the predecessor's chunks <= k+2.  The word
+      // was read while the previous group computed; only if that was too early does the thread poll.
+      if (t == 0) {
+        const unsigned need = (unsigned)(k + 3 + p.extra);
+        s_ok = (!pprog || early >= need || wait_for(need)) ? 1 : 0;
+      }
       __syncthreads();
       if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-      if (t == 0 && k > 0) __hip_atomic_store(myprog, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // every wave has passed the drain in front of its stores of chunk k-1, so chunks <= k-2 are in memory
+      if (t == 0 && k > 1) __hip_atomic_store(myprog, (unsigned)(k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       put_ops();
       __syncthreads();
+      if (t == 0 && pprog) early = __hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (k + 1 < KS) { fetch_ops(k + 1); fetch_chunk(k + 2); }
       double4_t w1[2];
       w1[0] = (double4_t){0.0, 0.0, 0.0, 0.0}; w1[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -557,6 +594,9 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xrow[kk], w1[kk >> 4][(kk & 15) >> 2], acc, 0, 0, 0);
         if (tile < 4) za[tile & 3] = acc; else zb[tile & 3] = acc;
       }
+      // (the stores of the previous chunk, issued a whole group ago, have long completed: this wait
+      // only makes that certain before the progress word of the next group tells the follower)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       tiles_to_global(k, za);                            // chunk k is final for this block of sweeps
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) za[tt] = zb[tt];
@@ -620,7 +660,11 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
     if (nwg > L.nsweeps) nwg = L.nsweeps;
     if (const char *ev = getenv("EK_SB2ST_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
     kprof_begin(s, kProfChase);
-    hipLaunchKernelGGL(chase_kernel, dim3(nwg), dim3(256), 0, s, c);
+    static int nw = -1;
+    if (nw < 0) { const char *ev = getenv("EK_SB2ST_WAVES"); nw = ev ? atoi(ev) : 8; }
+    if (nw == 16) hipLaunchKernelGGL(chase_kernel<16>, dim3(nwg), dim3(1024), 0, s, c);
+    else if (nw == 8) hipLaunchKernelGGL(chase_kernel<8>, dim3(nwg), dim3(512), 0, s, c);
+    else hipLaunchKernelGGL(chase_kernel<4>, dim3(nwg), dim3(256), 0, s, c);
     kprof_end(s, kProfChase);
   }
   hipLaunchKernelGGL(unpack_de_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, AB, d, e);
