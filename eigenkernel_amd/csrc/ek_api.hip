@@ -357,19 +357,31 @@ void peer_signal(hipStream_t s, unsigned long long seq, void *) {
   if (e != hipSuccess && !g_comm.err) g_comm.err = (int)ncclSystemError;
 }
 
+// Releases whatever has been allocated, opened or mapped so far: also called on the failure exits of
+// ek_hip_comm_peer_enable, where the windows are not "on" yet.
 void peer_teardown() {
-  if (!g_peer.on) return;
+  const PeerWindow &w = g_peer.win;
+  bool any = g_peer.on || w.done != nullptr;
+  for (int r = 0; r < kMaxTeam; ++r) any = any || g_peer.opened[r] || w.base[r] != nullptr;
+  if (!any) return;
   if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
-  for (int r = 0; r < g_peer.win.nranks; ++r)
-    if (r != g_peer.win.me && g_peer.opened[r]) (void)hipIpcCloseMemHandle(g_peer.win.base[r]);
-  if (g_peer.win.base[g_peer.win.me]) (void)hipFree(g_peer.win.base[g_peer.win.me]);
-  if (g_peer.win.done) (void)hipFree(g_peer.win.done);
+  for (int r = 0; r < w.nranks && r < kMaxTeam; ++r)
+    if (r != w.me && g_peer.opened[r]) (void)hipIpcCloseMemHandle(w.base[r]);
+  if (w.me >= 0 && w.me < kMaxTeam && w.base[w.me]) (void)hipFree(w.base[w.me]);
+  if (w.done) (void)hipFree(w.done);
+  (void)hipGetLastError();
   g_peer = PeerX{};
 }
 
-SytrdExchange team_exchange(int nteam) {
+inline int pad_ld(int n);
+// n: order of the solve the exchange is for.  The peer windows were sized for ek_hip_comm_peer_enable's
+// n_max (slots of 2 * pad(n_max) + 8 doubles in every peer's HBM); a larger order would store past the
+// slots in other processes' memory, so it takes the collective exchange instead (n is the same on every
+// rank: all ranks decide alike).  n = 0: no window exchange will be issued (Cholesky, reduction).
+SytrdExchange team_exchange(int nteam, int n = 0) {
   SytrdExchange x{nteam > 0 ? nteam : g_comm.nranks, nullptr, nullptr};
-  if (nteam == 0 && g_peer.on && g_peer.win.nranks == g_comm.nranks) x.peer = &g_peer.win;
+  const bool fits = 2 * (size_t)pad_ld(n > 0 ? n : 1) + 1 <= g_peer.win.maxcount;
+  if (nteam == 0 && g_peer.on && g_peer.win.nranks == g_comm.nranks && fits) x.peer = &g_peer.win;
   if (nteam > 0) { x.allreduce = sytrd_team_allreduce; x.allgatherv = team_allgatherv; }
   else if (g_comm.host) { x.allreduce = host_allreduce; x.allgatherv = host_allgatherv; }
   else { x.allreduce = rccl_allreduce; x.allgatherv = rccl_allgatherv; }
@@ -505,6 +517,10 @@ int ek_hip_finalize(void) {
   if (g_ctx.ws_alloc) (void)hipFree(g_ctx.ws_alloc);
   g_ctx.ws = nullptr; g_ctx.ws_alloc = nullptr; g_ctx.ws_bytes = 0;
   release_scratch_choice();
+  // a communicator and its peer windows do not outlive the library's device state
+  peer_teardown();
+  if (g_comm.on && !g_comm.host && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_comm.comm);
+  g_comm = Comm{};
   return 0;
 }
 
@@ -866,7 +882,7 @@ int ek_hip_sytrd_team(int n, double *A_loc, const int desc_A[9], double *d, doub
       hipLaunchKernelGGL(poison_foreign_strips_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s,
                          n, dA, ld, P, mem[m].rank);
   }
-  const SytrdExchange x = team_exchange(nteam);
+  const SytrdExchange x = team_exchange(nteam, n);
   g_comm.err = 0;
   sytrd_lower_dist(s, n, nmem, mem, x);
   EK_HIP_CHECK(hipGetLastError());
@@ -1345,7 +1361,7 @@ int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds) {
     double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld);
     mem[m] = SytrdMember{dA, ld, dd, de, dt, nullptr, 0, work, nteam > 0 ? m : g_comm.rank};
   }
-  const SytrdExchange x = team_exchange(nteam);
+  const SytrdExchange x = team_exchange(nteam, n);
   hipEvent_t e0, e1;
   EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
   double tot = 0.0;
@@ -1396,7 +1412,7 @@ int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds) {
     pm[m] = PotrfMember{dB, ld, dInv, dinfo, work, rank};
     sm[m] = SygstMember{dA, ld, dB, ld, dInv, tw, sc, rank};
   }
-  const SytrdExchange x = team_exchange(nteam);
+  const SytrdExchange x = team_exchange(nteam, n);
   hipEvent_t e0, e1, e2;
   EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1)); EK_HIP_CHECK(hipEventCreate(&e2));
   double t1 = 0.0, t2 = 0.0;
@@ -1642,7 +1658,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   bool two_stage_done = false;
   if (dist) {
     const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
-    sytrd_lower_dist(s, n, 1, &me, team_exchange(0));
+    sytrd_lower_dist(s, n, 1, &me, team_exchange(0, n));
   } else if (two_stage) {
     // dense -> band -> tridiagonal.  The panel factorisation of the first stage is CholeskyQR2 with a
     // device-side check; a matrix it cannot handle (rank-deficient or very ill-conditioned panels,

@@ -14,6 +14,11 @@
 !     --binary    one unformatted sequential record of N doubles per file (else `i j value` lines)
 !     --block-size <nb>   block size recorded in the descriptors
 !     --dry-run   read the matrices and stop                             main.f90:89-93
+!     --synthetic <N> [--seed-a 1] [--seed-b 2]   no matrix files: the dense SPD test matrices of
+!                 SURVEY.md 8(d) (the generator of bench.py and of the oracle), made on the GPU by the
+!                 library and fetched into the host arrays; general_* solvers get the pair (A, B).
+!                 Stands where the reference reads + scatters a MatrixMarket file
+!                 (matrix_io.f90:91-144, distribute_matrix.f90:401-422): 4.5 GB of text at N = 16384.
 !
 ! Written from scratch for this repository; it mirrors behaviour, not code.
 module ek_hip_binding
@@ -32,6 +37,27 @@ module ek_hip_binding
       real(c_double) :: A_loc(*), w(*), Z_loc(*), stage_seconds(*)
       type(c_ptr), value :: B_loc, desc_B
       integer(c_int) :: desc_A(9), desc_Z(9)
+    end function
+    integer(c_int) function ek_hip_malloc(dptr, bytes) bind(C, name='ek_hip_malloc')
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr) :: dptr
+      integer(c_long_long), value :: bytes
+    end function
+    integer(c_int) function ek_hip_free(dptr) bind(C, name='ek_hip_free')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: dptr
+    end function
+    integer(c_int) function ek_hip_memcpy_d2h(dst, src, bytes) bind(C, name='ek_hip_memcpy_d2h')
+      import :: c_int, c_ptr, c_long_long, c_double
+      real(c_double) :: dst(*)
+      type(c_ptr), value :: src
+      integer(c_long_long), value :: bytes
+    end function
+    integer(c_int) function ek_hip_synth_matrix_device(n, seed, dM, ldm) bind(C, name='ek_hip_synth_matrix_device')
+      import :: c_int, c_ptr, c_long_long
+      integer(c_int), value :: n, ldm
+      integer(c_long_long), value :: seed
+      type(c_ptr), value :: dM
     end function
     integer(c_int) function ek_hip_check(what, problem, n, n_cols, index1, index2, A_loc, desc_A, B_loc, &
          desc_B, w, Z_loc, desc_Z, res) bind(C, name='ek_hip_check')
@@ -55,6 +81,7 @@ program eigenkernel_hip_app
   integer :: n_ranges, ranges(2, max_ranges), ir
   integer :: nargs, iarg, n_files, n_vec, n_check, ortho_a, ortho_b, block_size, ios, comma
   logical :: dry_run, generalized, is_select
+  integer :: synth_n, seed_a, seed_b
   integer :: n, nb, info, problem, i, j
   integer(c_int), target :: desc_a(9), desc_b(9), desc_z(9)
   real(c_double), allocatable, target :: a_work(:, :), b_work(:, :), a_orig(:, :), b_orig(:, :)
@@ -77,6 +104,7 @@ program eigenkernel_hip_app
   out_ev = 'eigenvalues.dat'; out_ipr = 'ipratios.dat'; out_log = 'log.json'
   n_vec = -1; n_check = 0; ortho_a = 0; ortho_b = 0; block_size = 0
   dry_run = .false.; n_files = 0; n_events = 0
+  synth_n = 0; seed_a = 1; seed_b = 2
   vec_dir = '.'; vec_ranges = ''; binary_out = .false.; n_ranges = 0
   call get_command(cmdline)
 
@@ -96,6 +124,9 @@ program eigenkernel_hip_app
     case ('-p'); call next_arg(vec_ranges)
     case ('-d'); call next_arg(vec_dir)
     case ('--binary'); binary_out = .true.
+    case ('--synthetic'); call next_int(synth_n)
+    case ('--seed-a'); call next_int(seed_a)
+    case ('--seed-b'); call next_int(seed_b)
     case ('-t')
       call next_arg(arg)
       comma = index(arg, ',')
@@ -116,8 +147,10 @@ program eigenkernel_hip_app
     end select
     iarg = iarg + 1
   end do
-  if (n_files == 0) call die('no matrix file given', 1)
+  if (n_files == 0 .and. synth_n <= 0) call die('no matrix file given', 1)
+  if (n_files > 0 .and. synth_n > 0) call die('--synthetic takes no matrix files', 1)
   generalized = (n_files == 2)
+  if (synth_n > 0) generalized = (index(solver, 'general_') == 1)
   select case (trim(solver))
   case ('hip', 'hip_select')
     if (generalized) call die('solver '//trim(solver)//' is for the standard problem (one matrix file)', 1)
@@ -130,10 +163,16 @@ program eigenkernel_hip_app
   if (n_vec >= 0 .and. .not. is_select) call die('-n is only legal for *_select solvers', 1)
 
   call system_clock(clock0, clock_rate)
-  call read_matrix_market(trim(file_a), n, a_orig)
-  if (generalized) then
-    call read_matrix_market(trim(file_b), i, b_orig)
-    if (i /= n) call die('matrix dimensions differ', 1)
+  if (synth_n > 0) then
+    n = synth_n
+    call synthetic_matrix(n, seed_a, a_orig)
+    if (generalized) call synthetic_matrix(n, seed_b, b_orig)
+  else
+    call read_matrix_market(trim(file_a), n, a_orig)
+    if (generalized) then
+      call read_matrix_market(trim(file_b), i, b_orig)
+      if (i /= n) call die('matrix dimensions differ', 1)
+    end if
   end if
   call system_clock(clock1)
   t_read = dble(clock1 - clock0) / dble(clock_rate)
@@ -258,6 +297,28 @@ program eigenkernel_hip_app
   call write_log()
 
 contains
+
+  ! SURVEY.md 8(d) generator, evaluated by the library on the device (bit-identical to the oracle's and to
+  ! bench.py's inputs by construction), fetched into a host array like a matrix read from a file
+  subroutine synthetic_matrix(dim, seed, mat)
+    integer, intent(in) :: dim, seed
+    real(c_double), allocatable, target, intent(out) :: mat(:, :)
+    type(c_ptr) :: dptr
+    integer(c_long_long) :: bytes
+    integer(c_int) :: rc
+    if (dim < 1) call die('--synthetic needs a positive order', 1)
+    allocate (mat(dim, dim))
+    bytes = int(dim, c_long_long) * int(dim, c_long_long) * 8_c_long_long
+    rc = ek_hip_init(0_c_int)
+    if (rc /= 0) call die('ek_hip_init failed', int(rc))
+    rc = ek_hip_malloc(dptr, bytes)
+    if (rc /= 0) call die('ek_hip_malloc failed', int(rc))
+    rc = ek_hip_synth_matrix_device(int(dim, c_int), int(seed, c_long_long), dptr, int(dim, c_int))
+    if (rc /= 0) call die('ek_hip_synth_matrix_device failed', int(rc))
+    rc = ek_hip_memcpy_d2h(mat, dptr, bytes)
+    if (rc /= 0) call die('ek_hip_memcpy_d2h failed', int(rc))
+    rc = ek_hip_free(dptr)
+  end subroutine synthetic_matrix
 
   subroutine next_arg(val)
     character(len=*), intent(out) :: val

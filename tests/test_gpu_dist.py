@@ -553,6 +553,26 @@ def test_peer_windows_with_one_rank_over_rccl(hip, oracle, comm1):
     assert np.array_equal(again[1], ref[1])
 
 
+def test_peer_windows_too_small_for_the_order_fall_back_to_the_collective(hip, oracle, comm1):
+    """The windows hold 2 * pad(n_max) + 8 doubles per slot in every peer's HBM.  An order larger than
+    the n_max they were enabled for must not be stored into them (it would run past the slots in other
+    processes' memory): that solve takes the collective exchange instead and gives the same result."""
+    lib = comm1
+    A = oracle.synth_matrix(900, 1)
+    ref = hip.sytrd_team(A, 0)
+    assert ref[4] == 0
+    assert lib.ek_hip_comm_peer_enable(200) == 0         # slots for orders up to 256
+    got = hip.sytrd_team(A, 0)                            # order 900 > 256
+    assert got[4] == 0
+    for a, b in zip(ref[1:4], got[1:4]):
+        assert np.array_equal(a, b)
+    small = oracle.synth_matrix(200, 1)                  # an order that fits still goes through the windows
+    s1 = hip.sytrd_team(small, 0)
+    assert lib.ek_hip_comm_peer_disable() == 0
+    s2 = hip.sytrd_team(small, 0)
+    assert s1[4] == 0 and np.array_equal(s1[1], s2[1]) and np.array_equal(s1[2], s2[2])
+
+
 @pytest.mark.parametrize("n,P", [(4096, 8), (5000, 3), (6144, 5)])
 def test_sytrd_team_large_orders(hip, oracle, n, P):
     """Many strips per rank (T = 32 .. 48): the strip-stride tile enumeration at sizes the small

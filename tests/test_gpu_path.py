@@ -286,6 +286,42 @@ def test_fortran_host_end_to_end(tmp_path, golden_dir):
     assert bad.returncode != 0 and bad.stderr.startswith("[Error]")
 
 
+def test_fortran_host_at_a_baseline_size(tmp_path, golden_dir):
+    """BASELINE config C2 through the reference-language side of the boundary: the flang-built host
+    makes the SURVEY.md 8(d) matrix with `--synthetic 4096`, solves it with `-s hip`, runs the
+    reference's checks (-c -1 -t 1,4096) and writes eigenvalues.dat; the values are held to the
+    reference's library path (ScaLAPACK fixture) within N eps max|lambda|."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "eigenkernel_hip_app")
+    if not os.path.exists(exe):
+        assert os.path.exists("/opt/rocm/lib/llvm/bin/flang"), "flang missing: cannot build the Fortran host"
+        subprocess.check_call(["make", "-C", os.path.join(root, "host")])
+    n = 4096
+    out = subprocess.run([exe, "-s", "hip", "--synthetic", str(n), "-c", "-1", "-t", "1,%d" % n],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    ev = np.loadtxt(tmp_path / "eigenvalues.dat")
+    assert ev.shape == (n, 2) and np.array_equal(ev[:, 0], np.arange(1, n + 1))
+    w_ref = np.loadtxt(os.path.join(golden_dir, "scalapack_synth_sep_n4096_np8.txt"))
+    assert np.abs(ev[:, 1] - w_ref).max() <= n * EPS * np.abs(w_ref).max()
+    txt = out.stdout
+    res_max = float([l for l in txt.splitlines() if l.startswith("residual norm (max):")][0].split(":")[1])
+    orth = float([l for l in txt.splitlines() if l.startswith("orthogonality criterion:")][0].split(":")[1])
+    assert res_max <= 2e-14 and orth <= 1e-11
+    log = json.load(open(tmp_path / "log.json"))
+    assert log["setting"]["dimension"] == n
+    assert "eigen_solver_scalapack_all:pdsytrd" in {e["name"] for e in log["events"]}
+    # --synthetic and matrix files exclude each other; the generalized pair comes with general_hip
+    bad = subprocess.run([exe, "-s", "hip", "--synthetic", "64", "a.mtx"], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and bad.stderr.startswith("[Error]")
+    gen = subprocess.run([exe, "-s", "general_hip", "--synthetic", "300", "-c", "-1"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=300)
+    assert gen.returncode == 0, gen.stderr
+    assert np.loadtxt(tmp_path / "eigenvalues.dat").shape == (300, 2)
+
+
 @pytest.mark.parametrize("n,gep", [(2048, True), (4096, False)])
 def test_large_sizes_through_invariants(hip, n, gep):
     """Sizes the CPU oracle cannot reach in seconds: parity through size-independent
