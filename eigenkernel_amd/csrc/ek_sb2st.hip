@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 constexpr int QG = 32;                 // sweeps per compact-WY block
 constexpr int QR = QG + SB;            // rows of a block's window (95 used, 96 with padding)
 constexpr int QVLD = QG + 1;           // LDS leading dimension of the V image (row-major)
-constexpr int QREC = 2 * QR * QG;      // doubles per group record: V (96 x 32, column-major), then -(V T)
+constexpr int QREC = 2 * QR * QVLD;    // doubles per group record: the LDS images of V and of -(V T) (96 x 33, row-major)
 
 struct Q2Geom {
   int n, nsweeps, nS, kmax;            // kmax: groups per block of sweeps (uniform index S * kmax + k)
@@ -372,8 +372,9 @@ __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *
     const int rr = idx % QR, i = idx / QR;
     const double v = q2_v_entry(g, V2, ldv2, S, k, rr, i);
     sV[rr * QVLD + i] = v;
-    rec[idx] = v;
+    rec[rr * QVLD + i] = v;
   }
+  for (int rr = lane; rr < QR; rr += 64) { rec[rr * QVLD + QG] = 0.0; rec[QR * QVLD + rr * QVLD + QG] = 0.0; }   // padding column
   for (int idx = lane; idx < QG * QVLD; idx += 64) sT[idx] = 0.0;
   wave_sync();
   for (int i = 0; i < QG; ++i) {
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *
       double a = 0.0;
 #pragma unroll
       for (int l = 0; l < QG; ++l) a += vrow[l] * sT[l * QVLD + j];     // T upper triangular: zeros below
-      rec[QR * QG + rr + QR * j] = -a;
+      rec[QR * QVLD + rr * QVLD + j] = -a;
     }
   }
 }
@@ -487,25 +488,31 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
       return true;
     };
     double4_t za[4], zb[4];
-    double zreg[16], oreg[24];
-    auto fetch_ops = [&](int k) {
+    constexpr int NOP = (QREC + 255) / 256;             // 25 doubles of a record per thread
+    double zreg[16], oreg[NOP];
+    auto fetch_ops = [&](int k) {                        // the record is the LDS image itself: a linear copy
       const double *rec = p.Rec + ((size_t)S * p.g.kmax + k) * QREC;
 #pragma unroll
-      for (int q = 0; q < 24; ++q) oreg[q] = rec[t + 256 * q];
+      for (int q = 0; q < NOP; ++q) oreg[q] = (q < NOP - 1 || t + 256 * q < QREC) ? rec[t + 256 * q] : 0.0;
     };
     auto put_ops = [&]() {
 #pragma unroll
-      for (int q = 0; q < 24; ++q) {
-        const int idx = t + 256 * q, half = idx / (QR * QG), e = idx % (QR * QG), rr = e % QR, i = e / QR;
-        sOp[half * QR * QVLD + rr * QVLD + i] = oreg[q];
-      }
+      for (int q = 0; q < NOP; ++q)
+        if (q < NOP - 1 || t + 256 * q < QREC) sOp[t + 256 * q] = oreg[q];
     };
     // chunk j -> zreg: lane = row of the chunk, 16 columns (sc1: another pass may have written them)
+    const bool cols_in = colw + 16 <= p.ncols;
     auto fetch_chunk = [&](int j) {
       const int row = o0 + SB * j + lane;
+      const double *src = p.Z + (size_t)row + (size_t)colw * p.ldz;
+      if (cols_in && o0 + SB * j + SB <= n) {            // interior chunk: no predicates
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
-        zreg[c] = (row < n && colw + c < p.ncols) ? ld_sc1(p.Z + (size_t)row + (size_t)(colw + c) * p.ldz) : 0.0;
+        for (int c = 0; c < 16; ++c) zreg[c] = ld_sc1(src + (size_t)c * p.ldz);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          zreg[c] = (row < n && colw + c < p.ncols) ? ld_sc1(src + (size_t)c * p.ldz) : 0.0;
+      }
     };
     // zreg (row per lane) -> accumulator layout, through the per-wave buffer in two halves of 32 rows
     auto chunk_to_tiles = [&](double4_t (&z)[4]) {
@@ -535,14 +542,22 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
         {
           const int pr = lane & 15, cg = lane >> 4;      // row pair of this half, 4 columns per lane
           const int row = o0 + SB * j + 32 * h + 2 * pr;
+          double *dst0 = p.Z + (size_t)row + (size_t)(colw + 4 * cg) * p.ldz;
+          if (cols_in && o0 + SB * j + SB <= n) {        // interior chunk: no predicates
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = 4 * cg + q;
-            if (colw + c < p.ncols) {
-              const double a = st[c * QSTLD + 2 * pr], b = st[c * QSTLD + 2 * pr + 1];
-              double *dst = p.Z + (size_t)row + (size_t)(colw + c) * p.ldz;
-              if (row + 1 < n) st_sc1_x2(dst, a, b);
-              else if (row < n) st_sc1(dst, a);
+            for (int q = 0; q < 4; ++q) {
+              const int c = 4 * cg + q;
+              st_sc1_x2(dst0 + (size_t)q * p.ldz, st[c * QSTLD + 2 * pr], st[c * QSTLD + 2 * pr + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int c = 4 * cg + q;
+              if (colw + c < p.ncols) {
+                const double a = st[c * QSTLD + 2 * pr], b = st[c * QSTLD + 2 * pr + 1];
+                if (row + 1 < n) st_sc1_x2(dst0 + (size_t)q * p.ldz, a, b);
+                else if (row < n) st_sc1(dst0 + (size_t)q * p.ldz, a);
+              }
             }
           }
         }
