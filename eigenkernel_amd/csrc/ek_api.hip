@@ -279,7 +279,7 @@ int two_stage_min() {
   if (g_two_stage_min >= 0) return g_two_stage_min;
   static int env = -2;
   if (env == -2) { const char *e = getenv("EK_HIP_TWO_STAGE_MIN"); env = e ? atoi(e) : -1; }
-  return env >= 0 ? env : 12288;
+  return env >= 0 ? env : 10240;
 }
 
 // From how many ranks on the Cholesky factor and the reduction to standard form are distributed
