@@ -85,6 +85,13 @@ __device__ __forceinline__ double dot8(int k0, int k1, FA a, FB b) {
   return ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
 }
 
+// value of lane l (uniform index) in every lane: two v_readlane through scalar registers, no LDS round trip
+__device__ __forceinline__ double bcast_lane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 // Wave 0: upper Cholesky factor in place, G = R^T R (row j of R from rows 0..j-1: lane = column).
 // Returns false (all lanes) when a pivot is not positive.
 __device__ __forceinline__ bool chol64_upper(double *sG, int lane) {
@@ -92,10 +99,10 @@ __device__ __forceinline__ bool chol64_upper(double *sG, int lane) {
   for (int j = 0; j < SB; ++j) {
     const double acc = sG[j * LD + lane] -
         dot8(0, j, [&](int k) { return sG[k * LD + j]; }, [&](int k) { return sG[k * LD + lane]; });
-    double d = __shfl(acc, j, 64);
+    double d = bcast_lane(acc, j);
     if (!(d > 0.0) || !(d < 1.7e308)) { ok = false; d = 1.0; }
-    const double rjj = sqrt(d);
-    if (lane >= j) sG[j * LD + lane] = (lane == j) ? rjj : acc / rjj;
+    const double rinv = rsqrt(d);                        // one reciprocal square root instead of sqrt + divide
+    if (lane >= j) sG[j * LD + lane] = (lane == j) ? d * rinv : acc * rinv;
     wave_sync();
   }
   for (int r = 1; r < SB; ++r)
@@ -109,8 +116,8 @@ __device__ __forceinline__ void triinv64_upper(const double *sR, double *sX, int
   for (int i = SB - 1; i >= 0; --i) {
     const double acc = dot8(i + 1, SB, [&](int k) { return sR[i * LD + k]; },
                             [&](int k) { return sX[k * LD + lane]; });            // X(k, c) = 0 for k > c
-    const double rii = sR[i * LD + i];
-    if (lane >= i) sX[i * LD + lane] = (lane == i) ? 1.0 / rii : -acc / rii;
+    const double rinv = 1.0 / sR[i * LD + i];
+    if (lane >= i) sX[i * LD + lane] = (lane == i) ? rinv : -acc * rinv;
     wave_sync();
   }
 }
@@ -320,15 +327,16 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
     for (int j = 0; j < SB; ++j) {
       double acc = sD[j * LD + lane] -
           dot8(0, j, [&](int k) { return sD[j * LD + k]; }, [&](int k) { return sD[k * LD + lane]; });
-      double piv = __shfl(acc, j, 64);
+      double piv = bcast_lane(acc, j);
       const double sj = (piv >= 0.0) ? -1.0 : 1.0;
       piv -= sj;
+      const double pinv = 1.0 / piv;
       if (lane == j) { acc = piv; s_sign[j] = sj; }
       if (lane >= j) sD[j * LD + lane] = acc;
       wave_sync();
       const double accl = sD[lane * LD + j] -
           dot8(0, j, [&](int k) { return sD[lane * LD + k]; }, [&](int k) { return sD[k * LD + j]; });
-      if (lane > j) sD[lane * LD + j] = accl / piv;
+      if (lane > j) sD[lane * LD + j] = accl * pinv;
       wave_sync();
     }
   }
