@@ -261,7 +261,12 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
 
     def measure(mode):
         m = {}
-        if mode == "peer_windows":
+        # "two_stage": the library's default at this order (dense -> band -> tridiagonal replicated on the
+        # ranks after ONE all-gather of the reduced matrix, back-transformations sharded by columns: no
+        # exchange per Householder column); "one_stage_*": the distributed one-stage PDSYTRD with its
+        # per-column exchange as an all-reduce or through peer windows
+        lib.ek_hip_debug_set_two_stage(-1 if mode == "two_stage" else 0)
+        if mode == "one_stage_peer_windows":
             rc = lib.ek_hip_comm_peer_enable(n)
             if rc != 0:
                 raise RuntimeError("ek_hip_comm_peer_enable: %d" % rc)
@@ -318,27 +323,29 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
         wmax = wt.clone(); wmin = wt.clone()
         dist.all_reduce(wmax, op=dist.ReduceOp.MAX); dist.all_reduce(wmin, op=dist.ReduceOp.MIN)
         m["eigenvalues_identical_on_all_ranks"] = bool(torch.equal(wmax, wmin))
-        if mode == "peer_windows":
+        if mode == "one_stage_peer_windows":
             lib.ek_hip_comm_peer_disable()
+        lib.ek_hip_debug_set_two_stage(-1)
         return m, w.copy()
 
     try:
         threading.Thread(target=watchdog, daemon=True).start()
         attach_communicator(solver, dist, rank, world, args.rehearse_on_one_gpu)
         w_first = None
-        for mode in ("collective", "peer_windows"):
+        for mode in ("two_stage", "one_stage_collective", "one_stage_peer_windows"):
             try:
                 m, w = measure(mode)
-                if w_first is None:
+                if mode == "one_stage_collective":
                     w_first = w
-                else:
+                elif mode == "one_stage_peer_windows" and w_first is not None:
                     same = allreduce(1.0 if bool((w == w_first).all()) else 0.0, dist.ReduceOp.MIN) > 0.5
                     m["eigenvalues_bit_identical_to_collective_path"] = same
                 res["modes"][mode] = m
             except Exception as exc:          # ranks fail alike (collective calls): record and go on
                 res["modes"][mode] = {"error": repr(exc)}
-                if mode == "peer_windows":
+                if mode == "one_stage_peer_windows":
                     lib.ek_hip_comm_peer_disable()
+                lib.ek_hip_debug_set_two_stage(-1)
         solver.comm_destroy()
     except Exception as exc:   # the probe never takes the line down
         res["error"] = repr(exc)
@@ -366,9 +373,9 @@ def promote_grid_mode(out, probe, world):
     out["parity"] = m.get("parity_rank0")
     out["roofline"] = m.get("roofline")
     out["config"]["workload"] = out["config"]["workload"].replace("1 problem per GPU", "ONE problem on all GPUs")
-    out["config"]["parallelism"] = ("1 x %d process grid over RCCL/xGMI, replicated inputs: Cholesky factor, reduction and "
-                                    "tridiagonalisation distributed (1 x P block-cyclic, 128-wide blocks; per-column "
-                                    "exchange: %s), eigenvector stages sharded by columns" % (world, mode))
+    out["config"]["parallelism"] = ("1 x %d process grid over RCCL/xGMI, replicated inputs: Cholesky factor and reduction "
+                                    "distributed (1 x P block-cyclic, 128-wide blocks), tridiagonalisation: %s, eigenvector "
+                                    "stages sharded by columns" % (world, mode))
     out["headline_mode"] = mode
 
 

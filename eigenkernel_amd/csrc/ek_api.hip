@@ -1570,7 +1570,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // two-stage tridiagonalisation: one more matrix for the reflectors of the bulge chasing, a copy of
   // the reduced matrix for the (rare) fall-back to the one-stage path, and the stages' own scratch
   const int ts_min = two_stage_min();
-  const bool two_stage = !dist && ts_min > 0 && n >= ts_min && n >= 3;
+  const bool two_stage = ts_min > 0 && n >= ts_min && n >= 3;
   const size_t wb_sy2sb = two_stage ? al(sy2sb_work_bytes(n)) : 0, wb_sb2st = two_stage ? al(sb2st_work_bytes(n)) : 0;
   const size_t ws_need = 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
                          4 * al((size_t)ld * 8) + sygst_scr + potrf_wb +
@@ -1656,10 +1656,28 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   }
   mark();                                                              // 3
   bool two_stage_done = false;
-  if (dist) {
+  if (dist && !two_stage) {
     const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
     sytrd_lower_dist(s, n, 1, &me, team_exchange(0, n));
   } else if (two_stage) {
+    if (dist && problem == 1 && g_comm.nranks >= dist_min_ranks()) {
+      // the distributed reduction left the reduced matrix on every rank only in the 128-wide column
+      // strips it owns (strip S on rank S mod P): one all-gather per round of P strips completes it.
+      // From here on a team needs no further exchange: both stages of the tridiagonalisation run
+      // replicated (bit-identical on all ranks), the back-transformations on the cell's own columns.
+      const SytrdExchange x = team_exchange(0);
+      const int NRB = ceil_div(n, 128), P = x.nranks;
+      double *bufs[1] = {wA};
+      for (int q = 0; q * P < NRB; ++q) {
+        size_t offs[kMaxTeam], counts[kMaxTeam];
+        for (int r = 0; r < P; ++r) {
+          const int S = q * P + r;
+          const int cols = (S < NRB) ? ((n - S * 128 < 128) ? n - S * 128 : 128) : 0;
+          offs[r] = (S < NRB) ? (size_t)S * 128 * ld : 0; counts[r] = (size_t)cols * ld;
+        }
+        x.allgatherv(s, 1, g_comm.rank, bufs, offs, counts, P, x.user);
+      }
+    }
     // dense -> band -> tridiagonal.  The panel factorisation of the first stage is CholeskyQR2 with a
     // device-side check; a matrix it cannot handle (rank-deficient or very ill-conditioned panels,
     // e.g. an input that is already banded) takes the one-stage path from a copy instead.

@@ -33,3 +33,14 @@ def hip():
     rc = lib.ek_hip_init(0)
     assert rc == 0, "ek_hip_init failed: %d" % rc
     return solver
+
+
+@pytest.fixture(autouse=True)
+def _default_tridiagonalisation_after_each_gpu_test(request):
+    """Tests may force the two-stage tridiagonalisation on (or off) at small orders; the library's
+    default crossover is restored whatever the outcome of the test."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from eigenkernel_amd import solver
+        if solver._lib is not None:
+            solver._lib.ek_hip_debug_set_two_stage(-1)

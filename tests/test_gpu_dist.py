@@ -207,13 +207,17 @@ def test_sytrd_team_zero_needs_communicator(hip, oracle):
     assert hip.sytrd_team(A, 0)[4] == -7
 
 
+@pytest.mark.parametrize("two_stage", [False, True])
 @pytest.mark.parametrize("min_ranks", ["3", "1"])
 @pytest.mark.parametrize("problem,n,n_vec", [("gep", 300, 300), ("sep", 515, 515), ("gep", 400, 37)])
-def test_whole_path_with_communicator_attached(hip, oracle, comm1, monkeypatch, min_ranks, problem, n, n_vec):
+def test_whole_path_with_communicator_attached(hip, oracle, comm1, monkeypatch, min_ranks, problem, n, n_vec, two_stage):
     """ek_hip_solve_device_grid with a communicator of the grid's size takes the distributed
-    tridiagonalisation (here 1 x 1 over RCCL) and must agree with the plain single-GPU solve."""
+    tridiagonalisation (here 1 x 1 over RCCL) and must agree with the plain single-GPU solve.
+    two_stage: the two-stage tridiagonalisation instead (the strips of the distributed reduction are
+    all-gathered over the communicator, nothing is exchanged per column)."""
     import ctypes
     lib = comm1
+    hip.set_two_stage(100 if two_stage else 0)
     # "1": the distributed Cholesky factor and reduction to standard form are taken as well
     monkeypatch.setenv("EK_HIP_DIST_MIN_RANKS", min_ranks)
     A = oracle.synth_matrix(n, 1)
@@ -253,6 +257,7 @@ def test_whole_path_with_communicator_attached(hip, oracle, comm1, monkeypatch, 
     assert np.abs(R).max() <= 1e-12
     G = Z_d.T @ Bm @ Z_d
     assert np.abs(G - np.eye(n_vec)).max() <= 1e-11
+    hip.set_two_stage(-1)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -440,12 +445,14 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
         assert np.abs(Z.T @ Bd @ Z - np.eye(nvec)).max() <= 1e-11
 
 
-def _mp_grid_worker(rank, world, port, q, nprow, npcol, inputs):
+def _mp_grid_worker(rank, world, port, q, nprow, npcol, inputs, two_stage_min=None):
     """Whole path on an nprow x npcol grid, one process per cell, exchanges through the host."""
     import faulthandler
     import sys
     import traceback
     try:
+        if two_stage_min is not None:
+            os.environ["EK_HIP_TWO_STAGE_MIN"] = str(two_stage_min)
         import torch.distributed as dist
         faulthandler.dump_traceback_later(150, exit=True)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -477,21 +484,23 @@ def _mp_grid_worker(rank, world, port, q, nprow, npcol, inputs):
     os._exit(0)
 
 
-@pytest.mark.parametrize("inputs", ["replicated", "distributed"])
-def test_four_processes_on_a_2x2_grid(hip, oracle, inputs):
+@pytest.mark.parametrize("inputs,two_stage_min", [("replicated", None), ("distributed", None), ("replicated", 100)])
+def test_four_processes_on_a_2x2_grid(hip, oracle, inputs, two_stage_min):
     """The reference's near-square grid for four ranks (processes.f90:56-65): rank = myrow*npcol +
     mycol is the team index of the distributed stages whatever the grid's shape; with
     inputs="distributed" the ranks hand in block-cyclic pieces of A and B as the reference does and
-    get back pieces of Z and of L."""
+    get back pieces of Z and of L.  two_stage_min = 100: the tridiagonalisation in two stages -- the
+    team then completes the reduced matrix with one all-gather per round of strips and needs no
+    exchange per Householder column at all."""
     import multiprocessing as mp
     import queue as _queue
     from eigenkernel_amd import descriptor as d
     world, nprow, npcol, n = 4, 2, 2, 450
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 37600 + (os.getpid() % 1000) + (0 if inputs == "replicated" else 1000)
-    procs = [ctx.Process(target=_mp_grid_worker, args=(r, world, port, q, nprow, npcol, inputs), daemon=True)
-             for r in range(world)]
+    port = 37600 + (os.getpid() % 1000) + (0 if inputs == "replicated" else 1000) + (2000 if two_stage_min else 0)
+    procs = [ctx.Process(target=_mp_grid_worker, args=(r, world, port, q, nprow, npcol, inputs, two_stage_min),
+                         daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     got = []
