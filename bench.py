@@ -529,10 +529,11 @@ def main():
         step(i, True)
     barrier()
     total = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([total], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        total = float(tt.item())
+    # whole-job figure: every rank's eigenpairs over the slowest rank's time (eigenkernel_amd/parallel.py);
+    # ONE problem on a grid counts its eigenpairs once
+    from eigenkernel_amd.parallel import aggregate_throughput
+    units_local = float(n_vec * K) if not columns else (float(n_vec * K) if rank == 0 else 0.0)
+    value_all, total = aggregate_throughput(units_local, total, dist, cdev)
 
     symv_s, symv_l, symv_b = ctypes.c_double(0), ctypes.c_longlong(0), ctypes.c_double(0)
     kp_s, kp_l = (ctypes.c_double * 4)(), (ctypes.c_longlong * 4)()
@@ -570,7 +571,7 @@ def main():
     global _pending
     out = None
     if rank == 0:
-        value = (1 if columns else world) * n_vec * K / total
+        value = value_all
         out = {
             "metric": ("eigenpairs/s (full spectrum) + achieved fp64 TFLOP/s vs roofline, N=16384 GEP"
                        if (n == 16384 and problem == 1 and n_vec == n) else

@@ -215,10 +215,10 @@ def _grid_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from eigenkernel_amd.parallel import grid_cell, owned_eigenvector_columns
+    from eigenkernel_amd import descriptor as dsc
     n, n_vec, nb = 100, 37, 8
-    nprow, npcol, myrow, mycol = grid_cell(rank, world, columns_only=True)
-    cols = owned_eigenvector_columns(n_vec, nb, mycol, npcol)
+    nprow, npcol, myrow, mycol = dsc.make_process_grid(rank, world, 1, world)   # the 1 x P grid of bench.py's columns mode
+    cols = dsc.local_indices(n_vec, nb, mycol, npcol)
     out = [None] * world
     dist.all_gather_object(out, (nprow, npcol, myrow, mycol, cols.tolist()))
     q.put((rank, out))
