@@ -170,8 +170,8 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
           const int c = c0w + j;
-          dl[j] = (lane < L && c <= lane) ? ld_sc1(AB + (size_t)(lane - c) + (size_t)(i0 + c) * LDAB) : 0.0;
-          bk[j] = (lane < L1 && c < L) ? ld_sc1(AB + (size_t)(SB + lane - c) + (size_t)(i0 + c) * LDAB) : 0.0;
+          dl[j] = (lane < L && c <= lane) ? ld_sc1(AB + (unsigned)((lane - c) + (i0 + c) * LDAB)) : 0.0;
+          bk[j] = (lane < L1 && c < L) ? ld_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB)) : 0.0;
         }
       }
       if (prof) tc1 = clock64();
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         for (int j = 0; j < CW; ++j) {
           const int c = c0w + j;
           if (c > 0) bp[j] -= tau * v_r * s_z[c];          // column 0 is (beta, 0, ..., 0) already
-          if (lane < L) st_sc1(AB + (size_t)(SB + lane - c) + (size_t)(ip + c) * LDAB, bp[j]);
+          if (lane < L) st_sc1(AB + (unsigned)((SB + lane - c) + (ip + c) * LDAB), bp[j]);
         }
       }
       // ---- D_k as a full symmetric image
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
           const int c = c0w + j;
-          ndl[j] = (lane < Ln && c <= lane) ? ld_sc1(AB + (size_t)(lane - c) + (size_t)(j0 + c) * LDAB) : 0.0;
-          nbk[j] = (lane < L1n && c < Ln) ? ld_sc1(AB + (size_t)(SB + lane - c) + (size_t)(j0 + c) * LDAB) : 0.0;
+          ndl[j] = (lane < Ln && c <= lane) ? ld_sc1(AB + (unsigned)((lane - c) + (j0 + c) * LDAB)) : 0.0;
+          nbk[j] = (lane < L1n && c < Ln) ? ld_sc1(AB + (unsigned)((SB + lane - c) + (j0 + c) * LDAB)) : 0.0;
         }
       }
       // ---- (c) D_k <- H D_k H
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         for (int w = 0; w < NW; ++w) pc += s_p[w][c];
         const double w_c = tau * pc + alpha * vc[j];
         dd[j] -= v_r * w_c + w_r * vc[j];
-        if (c <= lane && lane < L) st_sc1(AB + (size_t)(lane - c) + (size_t)(i0 + c) * LDAB, dd[j]);
+        if (c <= lane && lane < L) st_sc1(AB + (unsigned)((lane - c) + (i0 + c) * LDAB), dd[j]);
       }
       // ---- (d) B_k <- B_k H (rows I_{k+1}, columns I_k); carried to the next task in registers
       if (L1 > 0) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 #pragma unroll
           for (int j = 0; j < CW; ++j) {
             const int c = c0w + j;
-            if (lane < L1 && c < L) st_sc1(AB + (size_t)(SB + lane - c) + (size_t)(i0 + c) * LDAB, bp[j]);
+            if (lane < L1 && c < L) st_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB), bp[j]);
           }
         }
       }
