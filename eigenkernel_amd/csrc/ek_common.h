@@ -38,6 +38,8 @@ struct GemmDesc {
   double *C; int ldc; long long strideC;
   int batch;
   bool lower_only;
+  bool staged_rank_k = false;          // op(A) op(B)^T with K <= 256: the staged 8-wave rank-k kernel (one workgroup per
+                                       // CU: slower alone than the default, but leaves room for a second stream's work)
   const long long *d_offs = nullptr;   // device: per-batch element offsets {A, B, C} (added to strides)
   const int *d_dims = nullptr;         // device: per-batch {M, N, K}; host M, N, K are then upper bounds
 };
@@ -45,8 +47,8 @@ void gemm(hipStream_t s, const GemmDesc &g);
 
 inline void gemm(hipStream_t s, bool ta, bool tb, int M, int N, int K, double alpha,
                  const double *A, int lda, const double *B, int ldb, double beta, double *C,
-                 int ldc, bool lower_only = false) {
-  GemmDesc g{M, N, K, ta, tb, alpha, beta, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, lower_only};
+                 int ldc, bool lower_only = false, bool staged_rank_k = false) {
+  GemmDesc g{M, N, K, ta, tb, alpha, beta, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, lower_only, staged_rank_k};
   gemm(s, g);
 }
 

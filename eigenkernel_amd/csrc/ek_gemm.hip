@@ -375,6 +375,125 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Rank-k update C += alpha A B^T with short K for callers that overlap it with a second stream (the SYR2K
+// of the dense -> band stage, GemmDesc::staged_rank_k).  A workgroup of 8 waves owns a 128x128 tile and
+// takes K in stages of 64: both operand slabs of a stage (2 x 128 x 64) are in LDS at once (one barrier
+// pair per 64 of K), fetched as 16-byte vectors, the next stage and the C tile are in flight in registers
+// while the matrix cores work on the current one.  One workgroup per CU: ALONE it is slower than the
+// 8-wave kernel above (K = 128, n = 16384 lower: 26 vs 32 TFLOP/s -- prologue and epilogue of a tile are not
+// covered by a second workgroup), but the dense -> band stage as a whole is faster with it (0.288 -> 0.268 s
+// at N = 16384): the panel chain of the look-ahead stream gets its workgroups dispatched sooner.
+constexpr int RK = 64;                    // K per stage
+constexpr int RK_LD = BM + 16;            // doubles per k-row of a slab image (conflict-free fragment reads)
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(512) void gemm_rankk_kernel(GemmArgs p) {
+  extern __shared__ double rk_smem[];
+  double *sA = rk_smem, *sB = rk_smem + RK * RK_LD;
+  const int tile = blockIdx.x;
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (p.lower_only && n0 > m0 + BM - 1) return;
+  if (p.dims) {
+    p.M = p.dims[3 * blockIdx.y]; p.N = p.dims[3 * blockIdx.y + 1]; p.K = p.dims[3 * blockIdx.y + 2];
+    if (m0 >= p.M || n0 >= p.N) return;
+  }
+  const double *__restrict__ A = p.A + (size_t)blockIdx.y * p.sA;
+  const double *__restrict__ B = p.B + (size_t)blockIdx.y * p.sB;
+  double *__restrict__ C = p.C + (size_t)blockIdx.y * p.sC;
+  if (p.offs) { A += p.offs[3 * blockIdx.y]; B += p.offs[3 * blockIdx.y + 1]; C += p.offs[3 * blockIdx.y + 2]; }
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // 16-byte operand fetch: thread -> (row pair xp = t & 63, k = t >> 6 + 8 i), 8 per operand and stage;
+  // legal when the leading dimension and the base are even (the library's work arrays are), else scalars
+  const bool vec = ((p.lda | p.ldb) & 1) == 0 && ((((size_t)A | (size_t)B) & 15) == 0);
+  const int xp = 2 * (t & 63), kq = t >> 6;
+  double2_t ra[8], rb[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = k0 + kq + 8 * i;
+      double2_t va = (double2_t){0.0, 0.0}, vb = (double2_t){0.0, 0.0};
+      if (k < p.K) {
+        const double *pa = A + (size_t)(m0 + xp) + (size_t)k * p.lda;
+        const double *pb = B + (size_t)(n0 + xp) + (size_t)k * p.ldb;
+        if (vec && m0 + xp + 1 < p.M) va = *reinterpret_cast<const double2_t *>(pa);
+        else { if (m0 + xp < p.M) va.x = pa[0]; if (m0 + xp + 1 < p.M) va.y = pa[1]; }
+        if (vec && n0 + xp + 1 < p.N) vb = *reinterpret_cast<const double2_t *>(pb);
+        else { if (n0 + xp < p.N) vb.x = pb[0]; if (n0 + xp + 1 < p.N) vb.y = pb[1]; }
+      }
+      ra[i] = va; rb[i] = vb;
+    }
+  };
+  auto put = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = kq + 8 * i;
+      *reinterpret_cast<double2_t *>(&sA[k * RK_LD + xp]) = ra[i];
+      *reinterpret_cast<double2_t *>(&sB[k * RK_LD + xp]) = rb[i];
+    }
+  };
+  double4_t acc[2][4];   // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  fetch(0);
+  // the C tile travels beside the first stage
+  double cval[2][4][4];
+  const double beta = p.beta;
+  if (beta != 0.0) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm + mi * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wn + ni * 16 + l4 + 4 * r;
+          cval[ni][mi][r] = (m < p.M && n < p.N) ? C[(size_t)m + (size_t)n * p.ldc] : 0.0;
+        }
+      }
+  }
+  for (int k0 = 0; k0 < p.K; k0 += RK) {
+    __syncthreads();
+    put();
+    __syncthreads();
+    if (k0 + RK < p.K) fetch(k0 + RK);
+    const int kend = (p.K - k0 < RK) ? p.K - k0 : RK;
+    for (int kk = 0; kk < kend; kk += 4) {
+      double fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = sA[(kk + l4) * RK_LD + wm + i * 16 + l15];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fb[i] = sB[(kk + l4) * RK_LD + wn + i * 16 + l15];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+  }
+  const double alpha = p.alpha;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = m0 + wm + mi * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + ni * 16 + l4 + 4 * r;
+        if (m < p.M && n < p.N) {
+          double v = alpha * acc[ni][mi][r];
+          if (beta != 0.0) v += beta * cval[ni][mi][r];
+          C[(size_t)m + (size_t)n * p.ldc] = v;
+        }
+      }
+    }
+}
+
 }  // namespace
 
 void gemm(hipStream_t s, const GemmDesc &g) {
@@ -407,6 +526,17 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   // the 4-wave kernel (measured 3 % faster there).  EK_GEMM_W8=0/1 forces one of them.
   static int w8 = -2;
   if (w8 == -2) { const char *e = getenv("EK_GEMM_W8"); w8 = e ? atoi(e) : -1; }
+  // rank-k updates with short K: the staged 8-wave kernel (EK_GEMM_RANKK=0 turns it off)
+  static int rankk = -1;
+  if (rankk < 0) {
+    const char *e = getenv("EK_GEMM_RANKK"); rankk = e ? atoi(e) : 1;
+    (void)hipFuncSetAttribute((const void *)gemm_rankk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * RK * RK_LD * (int)sizeof(double));
+  }
+  if (rankk && g.staged_rank_k && !g.transA && g.transB && g.K <= 256 && g.K >= 32 && w8 < 0) {
+    hipLaunchKernelGGL(gemm_rankk_kernel, grid, dim3(512), 2 * RK * RK_LD * sizeof(double), s, p);
+    return;
+  }
   const bool use_w8 = (w8 >= 0) ? (w8 != 0) : (g.K <= 512 && g.beta != 0.0);
   if (use_w8) {
     dim3 b8(512);

@@ -824,7 +824,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
       panel_chain(s2, r0, img[cur ^ 1], Tm[cur ^ 1]);
       (void)hipEventRecord(evB[cur ^ 1], s2);
       gemm(s, false, true, m - SB, m - SB, 2 * SB, -1.0, P1 + SB, ldi, P2 + SB, ldi, 1.0,
-           A22 + (size_t)SB + (size_t)SB * lda, lda, true);
+           A22 + (size_t)SB + (size_t)SB * lda, lda, true, /*staged_rank_k=*/true);
       waited = false;
     } else {
       gemm(s, false, true, m, m, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true);
