@@ -55,6 +55,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # fp64 matrix peak per GPU
 
 
+# BASELINE.json configs by name: (order, problem, n_vec; 0 = full spectrum).  c1 (BNZ30, N = 30) is the
+# reference's own CPU-runnable plumbing case: a parity test (tests/test_gpu_path.py), not a bench line.
+CONFIGS = {"c2": (4096, "sep", 0), "c3": (16384, "gep", 0), "c4": (32768, "gep", 0), "c5": (16384, "gep", 1024)}
+
+
 def flops(problem, n, n_vec):
     """Algorithmic flops F(N) of SURVEY.md 8(d)."""
     n3 = float(n) ** 3
@@ -432,8 +437,7 @@ def main():
                     help="seconds after which a stuck grid probe is abandoned (the main line is still printed)")
     args = ap.parse_args()
     if args.config:
-        args.n, args.problem, args.n_vec = {"c2": (4096, "sep", 0), "c3": (16384, "gep", 0),
-                                            "c4": (32768, "gep", 0), "c5": (16384, "gep", 1024)}[args.config]
+        args.n, args.problem, args.n_vec = CONFIGS[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

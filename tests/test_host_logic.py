@@ -406,3 +406,18 @@ def test_bench_promotes_the_faster_distributed_mode_that_passed():
     out = copy.deepcopy(base)
     bench.promote_grid_mode(out, {"modes": {"collective": good, "peer_windows": {"error": "timeout"}}}, 8)
     assert out["headline_mode"] == "collective" and out["value"] == 20480.0
+
+
+def test_bench_configs_and_flop_counts_follow_baseline_and_survey():
+    """bench.py --config names are BASELINE.json's configs[1..4]; flops() is SURVEY.md 8(d)'s F(N)."""
+    import json
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert bench.CONFIGS["c3"] == (16384, "gep", 0) and "N=16384 generalized" in base["configs"][2]
+    assert bench.CONFIGS["c2"] == (4096, "sep", 0) and "N=4096 standard" in base["configs"][1]
+    assert bench.CONFIGS["c4"] == (32768, "gep", 0) and "N=32768" in base["configs"][3]
+    assert bench.CONFIGS["c5"] == (16384, "gep", 1024) and "-n 1024" in base["configs"][4]
+    assert abs(bench.flops(0, 4096, 4096) - 3.207e11) <= 1e8           # SEP full: 14/3 N^3
+    assert abs(bench.flops(1, 16384, 16384) - 3.079e13) <= 1e10        # GEP full: 7 N^3
+    assert abs(bench.flops(1, 16384, 1024) - 1.255e13) <= 1e10         # partial GEP, k = 1024
+    assert bench.FP64_MFMA_PEAK_TFLOPS == 78.6 and bench.HBM_PEAK_GBS == 8000.0
