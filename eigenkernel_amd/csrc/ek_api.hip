@@ -30,6 +30,7 @@ struct Context {
   void *ws_alloc = nullptr;   // what hipFree gets
   size_t ws_bytes = 0;
   int *d_info = nullptr;
+  double *d_status = nullptr;   // one word for the team's status agreements (comm_agree)
 };
 Context g_ctx;
 std::mutex g_mu;
@@ -52,6 +53,7 @@ int ensure_init() {
     EK_HIP_CHECK(hipStreamCreateWithPriority(&g_ctx.stream2, hipStreamNonBlocking, hi));
   }
   EK_HIP_CHECK(hipMalloc((void **)&g_ctx.d_info, 64 * sizeof(int)));
+  EK_HIP_CHECK(hipMalloc((void **)&g_ctx.d_status, 64));
   g_ctx.ready = true;
   return 0;
 }
@@ -386,6 +388,26 @@ SytrdExchange team_exchange(int nteam, int n = 0) {
   else if (g_comm.host) { x.allreduce = host_allreduce; x.allgatherv = host_allgatherv; }
   else { x.allreduce = rccl_allreduce; x.allgatherv = rccl_allgatherv; }
   return x;
+}
+
+// A rank-local failure (allocation, staging copy) in front of a collective part of a call must not leave
+// the other ranks waiting in that collective: every rank contributes its status to one small all-reduce
+// over the attached communicator and all of them leave together -- the failing rank with its own code,
+// the others with -993.  Returns 0 when every rank is fine.  (The word lives in memory allocated at
+// initialisation, so the agreement itself needs nothing that could fail locally.)
+int comm_agree(int local_rc) {
+  if (!g_comm.on || g_comm.nranks <= 1) return local_rc;
+  const SytrdExchange x = team_exchange(0);
+  double st = local_rc ? 1.0 : 0.0;
+  bool ok = hipMemcpy(g_ctx.d_status, &st, sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  double *bufs[1] = {g_ctx.d_status};
+  g_comm.err = 0;
+  x.allreduce(g_ctx.stream, 1, bufs, 1, x.user);
+  ok = ok && hipStreamSynchronize(g_ctx.stream) == hipSuccess && !g_comm.err;
+  ok = ok && hipMemcpy(&st, g_ctx.d_status, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  if (!ok) return local_rc ? local_rc : -996;
+  if (st != 0.0) return local_rc ? local_rc : -993;
+  return 0;
 }
 
 const char *comm_error_string() {
@@ -1576,6 +1598,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
                          4 * al((size_t)ld * 8) + sygst_scr + potrf_wb +
                          (two_stage ? 2 * mat + wb_sy2sb + wb_sb2st + al((size_t)ld * 8) : 0);
   rc = workspace(ws_need, &ws);
+  if (dist) rc = comm_agree(rc);         // a rank that cannot get its workspace takes the team out with it (-993)
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
   double *wA = a.get<double>((size_t)ld * ld);
@@ -1943,6 +1966,7 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
     if (!rc) rc = mem.alloc(&pk, nn * 8);
     if (!rc) rc = mem.alloc(&uZ, (size_t)ldzl * (ncz > 0 ? ncz : 1) * 8);
     if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
+    rc = comm_agree(rc);                 // nobody enters the all-gathers below unless everybody can
     if (rc) return rc;
     g_comm.err = 0;
     auto assemble = [&](const double *M_loc, const int *desc, double *full) -> int {
@@ -1968,6 +1992,7 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
     if (!info && problem == 1) info = assemble(B_loc, desc_B, uB);
     if (!info) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) info = -1000 - (int)e; }
     if (!info && g_comm.err) info = -996;
+    info = comm_agree(info);             // a staging failure on one rank ends the call on all of them
     const double tg = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
     auto t1 = std::chrono::steady_clock::now();
     if (!info) info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, ldzl, stage_seconds, n_stages, &cell);
