@@ -483,10 +483,14 @@ struct SymmArgs {
   double *Ypart; int ldy; long long sY; // per split: m x 64
   int T, tiles_per_split;
 };
-constexpr int BK = 16, MC_LD = 128 + 16, KC_LD = BK + 1;
+constexpr int BK = 32, MC_LD = 128 + 16, KC_LD = BK + 1;
 constexpr int A_TILE = (BK * MC_LD > 128 * KC_LD) ? BK * MC_LD : 128 * KC_LD;
-constexpr int V_LD = BK + 1;            // V slab: 64 x 16, K-contiguous image s[n][17]
+constexpr int V_LD = BK + 1;            // V slab: 64 x 32, K-contiguous image s[n][33]
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// K is walked in slabs of 32 (one barrier pair per slab); slabs that lie completely inside the matrix
+// and off the diagonal tile are fetched as 16-byte pairs without predicates (A22 starts on a multiple of
+// 64 rows and the leading dimensions are even, so the pairs are aligned), the others element by element.
 __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
   __shared__ double sA[A_TILE], sV[SB * V_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
@@ -500,30 +504,58 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  double ra[8], rv[4];
-  // element (x, k) of the operand slab [m0 + x, kg] with kg = global k index
+  double2_t ra[8], rv[4];
+  // odd leading dimensions (odd n) or an unaligned base take the element path everywhere
+  const bool vec_ok = (((p.lda | p.ldv) & 1) == 0) && ((((size_t)p.A | (size_t)p.V) & 15) == 0);
+  const bool rows_in = vec_ok && m0 + 128 <= p.m;
+  // slab (kt, k0): rows m0 .. m0+127 of the operand, K indices kt*128 + k0 .. + 31.
+  //   direct tile (kt < rb): pair = rows (2 xp, 2 xp + 1) at one k;   thread -> xp = t & 63, k = t >> 6 + 4 i
+  //   transposed (kt > rb):  pair = k indices (2 kp, 2 kp + 1) of one row; thread -> kp = t & 15, x = t >> 4 + 16 i
   auto load_a = [&](int kt, int k0) {
     const int mode = (kt < rb) ? 0 : (kt > rb ? 1 : 2);
+    const int gk0 = kt * 128 + k0;
+    if (mode == 0 && rows_in && gk0 + BK <= p.m) {
+      const double *base = p.A + (size_t)(m0 + 2 * (t & 63)) + (size_t)(gk0 + (t >> 6)) * p.lda;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = t + 256 * i;
-      int x, k;
-      if (mode == 1) { k = idx & 15; x = idx >> 4; } else { x = idx & 127; k = idx >> 7; }
-      const int gx = m0 + x, gk = kt * 128 + k0 + k;
-      double v = 0.0;
-      if (gx < p.m && gk < p.m) {
-        const bool low = (mode == 0) || (mode == 2 && gx >= gk);
-        v = low ? p.A[(size_t)gx + (size_t)gk * p.lda] : p.A[(size_t)gk + (size_t)gx * p.lda];
+      for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const double2_t *>(base + (size_t)(4 * i) * p.lda);
+    } else if (mode == 1 && rows_in && gk0 + BK <= p.m) {
+      const double *base = p.A + (size_t)(gk0 + 2 * (t & 15)) + (size_t)(m0 + (t >> 4)) * p.lda;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const double2_t *>(base + (size_t)(16 * i) * p.lda);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        double v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int x, k;
+          if (mode == 1) { k = 2 * (t & 15) + h; x = (t >> 4) + 16 * i; } else { x = 2 * (t & 63) + h; k = (t >> 6) + 4 * i; }
+          const int gx = m0 + x, gk = gk0 + k;
+          double e = 0.0;
+          if (gx < p.m && gk < p.m) {
+            const bool low = (mode == 0) || (mode == 2 && gx >= gk);
+            e = low ? p.A[(size_t)gx + (size_t)gk * p.lda] : p.A[(size_t)gk + (size_t)gx * p.lda];
+          }
+          v[h] = e;
+        }
+        ra[i] = (double2_t){v[0], v[1]};
       }
-      ra[i] = v;
     }
   };
+  // V slab: pair = k indices (2 kp, 2 kp + 1) of one column n; thread -> kp = t & 15, n = t >> 4 + 16 i
   auto load_v = [&](int kt, int k0) {
+    const int gk0 = kt * 128 + k0;
+    if (vec_ok && gk0 + BK <= p.m) {
+      const double *base = p.V + (size_t)(gk0 + 2 * (t & 15)) + (size_t)(t >> 4) * p.ldv;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = t + 256 * i, k = idx & 15, nn = idx >> 4;
-      const int gk = kt * 128 + k0 + k;
-      rv[i] = (gk < p.m) ? p.V[(size_t)gk + (size_t)nn * p.ldv] : 0.0;
+      for (int i = 0; i < 4; ++i) rv[i] = *reinterpret_cast<const double2_t *>(base + (size_t)(16 * i) * p.ldv);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gk = gk0 + 2 * (t & 15), nn = (t >> 4) + 16 * i;
+        rv[i] = (double2_t){gk < p.m ? p.V[(size_t)gk + (size_t)nn * p.ldv] : 0.0,
+                            gk + 1 < p.m ? p.V[(size_t)gk + 1 + (size_t)nn * p.ldv] : 0.0};
+      }
     }
   };
   if (kt0 < kt1) { load_a(kt0, 0); load_v(kt0, 0); }
@@ -534,12 +566,11 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int idx = t + 256 * i;
-        if (kc) { const int k = idx & 15, x = idx >> 4; sA[x * KC_LD + k] = ra[i]; }
-        else    { const int x = idx & 127, k = idx >> 7; sA[k * MC_LD + x] = ra[i]; }
+        if (kc) { const int k = 2 * (t & 15), x = (t >> 4) + 16 * i; sA[x * KC_LD + k] = ra[i].x; sA[x * KC_LD + k + 1] = ra[i].y; }
+        else    { const int x = 2 * (t & 63), k = (t >> 6) + 4 * i; *reinterpret_cast<double2_t *>(&sA[k * MC_LD + x]) = ra[i]; }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int idx = t + 256 * i, k = idx & 15, nn = idx >> 4; sV[nn * V_LD + k] = rv[i]; }
+      for (int i = 0; i < 4; ++i) { const int k = 2 * (t & 15), nn = (t >> 4) + 16 * i; sV[nn * V_LD + k] = rv[i].x; sV[nn * V_LD + k + 1] = rv[i].y; }
       __syncthreads();
       // next slab (possibly of the next tile) in flight during the MFMAs
       int nkt = kt, nk0 = k0 + BK;
