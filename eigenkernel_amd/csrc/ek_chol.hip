@@ -14,138 +14,114 @@
 // inv(L)^T in the upper triangle of the same 128 KB image), so that every triangular solve
 // against a diagonal block becomes one more MFMA GEMM.
 #include "ek_common.h"
+#include "ek_block64.h"
 
 namespace ek {
 namespace {
 
 constexpr int NB = kDiagNB;   // 128
+constexpr size_t kDiagLds = 4 * b64::IMG * sizeof(double);   // dynamic LDS of potrf_diag_kernel
 
-// One workgroup: B(0:nb,0:nb) = L L^T in LDS, then inv(L).  s is the 128x128 column-major
-// image; positions outside nb are the identity so that short edge blocks need no special
-// casing.  info (device): first non-positive pivot (1-based, global numbering) or 0.
-// Both phases are blocked by 16 so that almost all arithmetic runs on register tiles fed
-// from LDS, with a handful of barriers per 16 columns instead of three per column:
-//   factor : 16x16 diagonal block by one wavefront -> row-per-thread solve of the 16-column
-//            panel -> rank-16 update of the trailing block in 4x4 register tiles;
-//   invert : diagonal 16x16 blocks by forward substitution (a column per thread), then block
-//            row by block row  X_IJ = -inv(L_II) * sum_K L_IK X_KJ.
-// inv(L)(i,c), i > c, lives at s[c + 128*i] (the mirrored, strictly-upper position); its
-// diagonal 1/L(c,c) in sd[].
-// FACTOR = false: B already holds L; only the inverses are formed, one workgroup per
-// diagonal block (blockIdx.x), for stage-level calls that receive L from the host.
+// One workgroup: B(0:nb,0:nb) = L L^T and inv(L), for a 128x128 diagonal block (nb <= 128; positions
+// outside nb behave as the identity so that short edge blocks need no special casing).
+// info (device): first non-positive pivot (1-based, global numbering) or 0.
+//
+// The block is handled as 2 x 2 blocks of 64 in terms of the UPPER factor R = L^T held in row-major
+// LDS images (ek_block64.h): the two 64-step factorisations and the two 64-step triangular inverses
+// run on all four waves with the matrix in registers (one barrier and 16 FMAs per thread and step),
+// everything between them is a 64x64 product on the matrix cores:
+//   R11 = chol(B11), X11 = R11^-1, R12 = X11^T B12, R22 = chol(B22 - R12^T R12), X22 = R22^-1,
+//   X12 = -X11 R12 X22;      L = R^T,  inv(L) = [X11 X12; 0 X22]^T.
+// This kernel is the serial chain of the factorisation (one launch per 128 columns, each waiting for
+// the previous trailing update), which is why it is built for latency.
+// inv (128x128, column-major): inv(L)(i,c) for i > c, 1/L(c,c) on the diagonal, zeros above.
+__global__ __launch_bounds__(256) void potrf_diag_kernel(int nb, double *B, int ldb, double *inv, int *info,
+                                                         int info_base) {
+  using namespace b64;
+  extern __shared__ double smem[];
+  double *sA = smem, *sB = smem + IMG, *sC = smem + 2 * IMG, *sD = smem + 3 * IMG;
+  __shared__ double srow[kLine];
+  const int t = threadIdx.x;
+  // element (gr, gc), gr <= gc, of the symmetric block from its lower triangle
+  auto upper = [&](int gr, int gc) -> double {
+    if (gc < nb) return B[(size_t)gc + (size_t)gr * ldb];
+    return (gr == gc) ? 1.0 : 0.0;
+  };
+  auto fail_exit = [&](int j) {
+    if (t == 0) atomicCAS(info, 0, info_base + j + 1);
+    for (int idx = t; idx < NB * NB; idx += 256)      // a harmless inverse so later kernels stay finite
+      inv[idx] = ((idx & (NB - 1)) == (idx >> 7)) ? 1.0 : 0.0;
+  };
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int c = idx & 63, r = idx >> 6;
+    sA[r * LD + c] = (c >= r) ? upper(r, c) : 0.0;        // B11
+    sC[r * LD + c] = upper(r, 64 + c);                     // B12
+  }
+  __syncthreads();
+  int fail = chol64_upper_wg(sA, srow);                    // sA = R11
+  if (fail >= 0) { fail_exit(fail); return; }
+  triinv64_upper_wg(sA, sB, srow);                         // sB = X11
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    if (i >= j && i < nb) B[(size_t)i + (size_t)j * ldb] = sA[j * LD + i];                  // L11
+    inv[i + NB * j] = (i >= j) ? sB[j * LD + i] : 0.0;
+    inv[i + NB * (64 + j)] = 0.0;
+  }
+  mm64(sB, true, sC, false, sD);                           // sD = R12 = X11^T B12
+  __syncthreads();
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    if (64 + i < nb) B[(size_t)(64 + i) + (size_t)j * ldb] = sD[j * LD + i];                // L21
+  }
+  mm64(sD, true, sD, false, sC);                           // sC = R12^T R12
+  __syncthreads();
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int c = idx & 63, r = idx >> 6;
+    sA[r * LD + c] = (c >= r) ? upper(64 + r, 64 + c) - sC[r * LD + c] : 0.0;
+  }
+  __syncthreads();
+  fail = chol64_upper_wg(sA, srow);                        // sA = R22
+  if (fail >= 0) { fail_exit(64 + fail); return; }
+  triinv64_upper_wg(sA, sC, srow);                         // sC = X22
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    if (i >= j && 64 + i < nb) B[(size_t)(64 + i) + (size_t)(64 + j) * ldb] = sA[j * LD + i];   // L22
+    inv[(64 + i) + NB * (64 + j)] = (i >= j) ? sC[j * LD + i] : 0.0;
+  }
+  __syncthreads();
+  mm64(sB, false, sD, false, sA);                          // sA = X11 R12
+  __syncthreads();
+  mm64(sA, false, sC, false, sD);                          // sD = X11 R12 X22 = -X12
+  __syncthreads();
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, c = idx >> 6;
+    inv[(64 + i) + NB * c] = -sD[c * LD + i];
+  }
+}
+
+// inv(L) of every 128x128 diagonal block of a given factor L (one workgroup per block, all in LDS), for
+// stage-level calls that receive L from the host.  s is the 128x128 column-major image; positions
+// outside nb are the identity.  Blocked by 16: diagonal 16x16 blocks by forward substitution (a column
+// per thread), then block row by block row  X_IJ = -inv(L_II) * sum_K L_IK X_KJ.
+// inv(L)(i,c), i > c, lives at s[c + 128*i] (the mirrored, strictly-upper position); its diagonal
+// 1/L(c,c) in sd[].
 constexpr int PB = 16;
 
-template <bool FACTOR>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(int nb_or_n, double *B, int ldb,
-                                                         double *inv, int *info, int info_base) {
+__global__ __launch_bounds__(256) void trtri_diag_kernel(int n, const double *B, int ldb, double *inv) {
   extern __shared__ double s[];
   double *sd = s + NB * NB;            // 1 / L(i,i)
-  __shared__ int s_fail;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  int nb = nb_or_n;
-  if (!FACTOR) {
-    const int off = blockIdx.x * NB;
-    nb = nb_or_n - off < NB ? nb_or_n - off : NB;
-    B += (size_t)off + (size_t)off * ldb;
-    inv += (size_t)blockIdx.x * NB * NB;
-  }
+  const int t = threadIdx.x;
+  const int off = blockIdx.x * NB;
+  const int nb = n - off < NB ? n - off : NB;
+  B += (size_t)off + (size_t)off * ldb;
+  inv += (size_t)blockIdx.x * NB * NB;
   for (int idx = t; idx < NB * NB; idx += 256) {
     const int i = idx & (NB - 1), j = idx >> 7;
     double v = (i == j) ? 1.0 : 0.0;
     if (i < nb && j < nb && i >= j) v = B[(size_t)i + (size_t)j * ldb];
     s[idx] = v;
   }
-  if (t == 0) s_fail = 0;
   __syncthreads();
-  bool failed = false;
-  if (FACTOR) {
-    for (int p0 = 0; p0 < nb; p0 += PB) {
-      // (a) 16x16 diagonal block, one wavefront (LDS operations of a wave execute in order)
-      if (wave == 0) {
-        for (int j = 0; j < PB; ++j) {
-          const double d = s[(p0 + j) + NB * (p0 + j)];
-          if (!(d > 0.0)) {
-            if (lane == 0) { s_fail = 1; atomicCAS(info, 0, info_base + p0 + j + 1); }
-            break;
-          }
-          const double l = sqrt(d), r = 1.0 / l;
-          if (lane < PB) {
-            if (lane > j) s[(p0 + lane) + NB * (p0 + j)] *= r;
-            else if (lane == j) s[(p0 + j) + NB * (p0 + j)] = l;
-          }
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = lane + 64 * u, i = e & (PB - 1), k = e >> 4;
-            if (k > j && i >= k) s[(p0 + i) + NB * (p0 + k)] -= s[(p0 + i) + NB * (p0 + j)] * s[(p0 + k) + NB * (p0 + j)];
-          }
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      __syncthreads();
-      if (s_fail) { failed = true; break; }
-      const int r0 = p0 + PB;
-      if (r0 >= NB) break;
-      // (b) panel below: row r solves x L11^T = a (forward substitution along the row)
-      if (t < NB - r0) {
-        const int r = r0 + t;
-        double x[PB];
-#pragma unroll
-        for (int c = 0; c < PB; ++c) x[c] = s[r + NB * (p0 + c)];
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-          double a = x[j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) a -= x[k] * s[(p0 + j) + NB * (p0 + k)];
-          x[j] = a / s[(p0 + j) + NB * (p0 + j)];
-        }
-#pragma unroll
-        for (int c = 0; c < PB; ++c) s[r + NB * (p0 + c)] = x[c];
-      }
-      __syncthreads();
-      // (c) trailing block -= X X^T, lower part, 4x4 register tiles
-      const int m = NB - r0, nt = m >> 2;
-      for (int idx = t; idx < nt * nt; idx += 256) {
-        const int ti = idx % nt, tj = idx / nt;
-        if (ti < tj) continue;
-        const int i0 = r0 + 4 * ti, k0 = r0 + 4 * tj;
-        double acc[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll
-        for (int c = 0; c < PB; ++c) {
-          const double4 xi = *reinterpret_cast<const double4 *>(&s[i0 + NB * (p0 + c)]);
-          const double4 xk = *reinterpret_cast<const double4 *>(&s[k0 + NB * (p0 + c)]);
-          const double xiv[4] = {xi.x, xi.y, xi.z, xi.w}, xkv[4] = {xk.x, xk.y, xk.z, xk.w};
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += xiv[a] * xkv[b];
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-            if (i0 + a >= k0 + b) s[(i0 + a) + NB * (k0 + b)] -= acc[a][b];
-      }
-      __syncthreads();
-    }
-    __syncthreads();
-    for (int idx = t; idx < NB * NB; idx += 256) {
-      const int i = idx & (NB - 1), j = idx >> 7;
-      if (i < nb && j < nb && i >= j) B[(size_t)i + (size_t)j * ldb] = s[idx];
-    }
-  }
-  if (failed) {   // leave a harmless inverse so later kernels stay finite
-    for (int idx = t; idx < NB * NB; idx += 256)
-      inv[idx] = ((idx & (NB - 1)) == (idx >> 7)) ? 1.0 : 0.0;
-    return;
-  }
-  // ---- inverse
   if (t < NB) sd[t] = 1.0 / s[t + NB * t];
   __syncthreads();
   // step 1: inverses of the diagonal 16x16 blocks, a column per thread
@@ -224,7 +200,7 @@ void potrf_rec(hipStream_t s, int n, double *B, int ldb, int off, double *invdia
                double *work) {
   double *Bd = B + (size_t)off + (size_t)off * ldb;
   if (n <= NB) {
-    hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), (NB * NB + NB) * sizeof(double), s, n,
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), kDiagLds, s, n,
                        Bd, ldb, invdiag + (size_t)(off / NB) * NB * NB, d_info, off);
     return;
   }
@@ -241,9 +217,8 @@ void potrf_rec(hipStream_t s, int n, double *B, int ldb, int off, double *invdia
 static void set_attrs() {
   static bool attr_set = false;
   if (attr_set) return;
-  (void)hipFuncSetAttribute((const void *)potrf_diag_kernel<true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + NB) * sizeof(double));
-  (void)hipFuncSetAttribute((const void *)potrf_diag_kernel<false>,
+  (void)hipFuncSetAttribute((const void *)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds);
+  (void)hipFuncSetAttribute((const void *)trtri_diag_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + NB) * sizeof(double));
   attr_set = true;
 }
@@ -258,9 +233,8 @@ void potrf_lower(hipStream_t s, int n, double *B, int ldb, double *invdiag, int 
 void trtri_diag_blocks(hipStream_t s, int n, const double *L, int ldl, double *invdiag) {
   set_attrs();
   if (n <= 0) return;
-  hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(ceil_div(n, NB)), dim3(256),
-                     (NB * NB + NB) * sizeof(double), s, n, const_cast<double *>(L), ldl, invdiag,
-                     (int *)nullptr, 0);
+  hipLaunchKernelGGL(trtri_diag_kernel, dim3(ceil_div(n, NB)), dim3(256),
+                     (NB * NB + NB) * sizeof(double), s, n, L, ldl, invdiag);
 }
 
 // invdiag points at the inverse of the FIRST diagonal block of L (blocks follow at
@@ -467,7 +441,7 @@ void potrf_lower_dist(hipStream_t s, int n, int nmem, const PotrfMember *mem, co
       const PotrfMember &M = mem[m];
       double *Bd = M.B + (size_t)off + (size_t)off * M.ldb;
       double *pinv = pbuf[m], *pdiag = pbuf[m] + NB * NB, *ppan = pbuf[m] + 2 * NB * NB;
-      hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), (NB * NB + NB) * sizeof(double), s, nbk,
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), kDiagLds, s, nbk,
                          Bd, M.ldb, pinv, infos[m] + k, off);
       copy_matrix(s, nbk, nbk, Bd, M.ldb, pdiag, NB);
       if (mrows > 0) gemm(s, false, true, mrows, nbk, nbk, 1.0, Bd + nbk, M.ldb, pinv, NB, 0.0, ppan, mrows);
@@ -537,7 +511,7 @@ void potrf_lower_rl(hipStream_t s, hipStream_t s2, int n, double *B, int ldb, do
     const int off = k * NB, nbk = (n - off < NB) ? n - off : NB, mrows = n - off - nbk;
     double *Bd = B + (size_t)off + (size_t)off * ldb;
     double *inv = invdiag + (size_t)k * NB * NB;
-    hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), (NB * NB + NB) * sizeof(double), st, nbk, Bd,
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), kDiagLds, st, nbk, Bd,
                        ldb, inv, infos + k, off);
     if (mrows > 0) {
       gemm(st, false, true, mrows, nbk, nbk, 1.0, Bd + nbk, ldb, inv, NB, 0.0, ppan, mrows);

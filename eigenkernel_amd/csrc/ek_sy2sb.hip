@@ -23,103 +23,20 @@
 //   4. A22 -= W V^T + V W^T (one GEMM with K = 128 on the image [W | V | W])
 // The band is left in the lower band of A, R (with the signs of the reconstruction) in the panel.
 #include "ek_common.h"
+#include "ek_block64.h"
 
 #include <cstdlib>
 
 namespace ek {
 namespace {
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-constexpr int SB = kBandW;   // 64: band half-width = panel width
-constexpr int LD = 66;       // leading dimension of 64x64 LDS images, row-major s[r * LD + c]
-constexpr int IMG = SB * LD; // doubles per image
+using namespace b64;          // 64x64 LDS images and the workgroup-wide factorisations on them
+static_assert(SB == kBandW, "the panel width is the width of the 64x64 building blocks");
 constexpr int CH = 128;      // rows per workgroup of the tall-skinny kernels (two 64-row slabs)
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS operations have completed
   __builtin_amdgcn_wave_barrier();
-}
-
-// ---------------------------------------------------------------- 64x64 building blocks in LDS
-// C = op(A) op(B), all 64x64 LDS images, on the matrix cores, by the 4 waves of the workgroup:
-// wave w owns rows 16 w .. 16 w + 15 of C.  Callers synchronise before and after.
-// out_g != nullptr: C goes to global memory (column-major, ld 64), row i scaled by rs[i] if rs.
-__device__ __forceinline__ void mm64(const double *sA, bool ta, const double *sB, bool tb, double *sC,
-                                     double *out_g = nullptr, const double *rs = nullptr) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int i0 = 16 * wave;
-  double4_t acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  for (int kk = 0; kk < SB; kk += 4) {
-    const double x = ta ? sA[(kk + l4) * LD + i0 + l15] : sA[(i0 + l15) * LD + kk + l4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      const double y = tb ? sB[(16 * jt + l15) * LD + kk + l4] : sB[(kk + l4) * LD + 16 * jt + l15];
-      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[jt], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + l4 + 4 * r, j = 16 * jt + l15;
-      if (out_g) out_g[i + SB * j] = rs ? rs[i] * acc[jt][r] : acc[jt][r];
-      else sC[i * LD + j] = acc[jt][r];
-    }
-}
-
-// sum_{k in [k0, k1)} a(k) b(k) with eight independent partial sums: the LDS reads of eight terms are
-// in flight together (the plain loop waits for every pair of reads: 50 cycles per term)
-template <typename FA, typename FB>
-__device__ __forceinline__ double dot8(int k0, int k1, FA a, FB b) {
-  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, c4 = 0.0, c5 = 0.0, c6 = 0.0, c7 = 0.0;
-  int k = k0;
-  for (; k + 7 < k1; k += 8) {
-    const double x0 = a(k), x1 = a(k + 1), x2 = a(k + 2), x3 = a(k + 3), x4 = a(k + 4), x5 = a(k + 5), x6 = a(k + 6), x7 = a(k + 7);
-    const double y0 = b(k), y1 = b(k + 1), y2 = b(k + 2), y3 = b(k + 3), y4 = b(k + 4), y5 = b(k + 5), y6 = b(k + 6), y7 = b(k + 7);
-    c0 += x0 * y0; c1 += x1 * y1; c2 += x2 * y2; c3 += x3 * y3; c4 += x4 * y4; c5 += x5 * y5; c6 += x6 * y6; c7 += x7 * y7;
-  }
-  for (; k < k1; ++k) c0 += a(k) * b(k);
-  return ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
-}
-
-// value of lane l (uniform index) in every lane: two v_readlane through scalar registers, no LDS round trip
-__device__ __forceinline__ double bcast_lane(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
-
-// Wave 0: upper Cholesky factor in place, G = R^T R (row j of R from rows 0..j-1: lane = column).
-// Returns false (all lanes) when a pivot is not positive.
-__device__ __forceinline__ bool chol64_upper(double *sG, int lane) {
-  bool ok = true;
-  for (int j = 0; j < SB; ++j) {
-    const double acc = sG[j * LD + lane] -
-        dot8(0, j, [&](int k) { return sG[k * LD + j]; }, [&](int k) { return sG[k * LD + lane]; });
-    double d = bcast_lane(acc, j);
-    if (!(d > 0.0) || !(d < 1.7e308)) { ok = false; d = 1.0; }
-    const double rinv = rsqrt(d);                        // one reciprocal square root instead of sqrt + divide
-    if (lane >= j) sG[j * LD + lane] = (lane == j) ? d * rinv : acc * rinv;
-    wave_sync();
-  }
-  for (int r = 1; r < SB; ++r)
-    if (lane < r) sG[r * LD + lane] = 0.0;
-  wave_sync();
-  return ok;
-}
-
-// Wave 0: X = R^-1 for upper triangular R (only its upper triangle is read).  sX must be zero.
-__device__ __forceinline__ void triinv64_upper(const double *sR, double *sX, int lane) {
-  for (int i = SB - 1; i >= 0; --i) {
-    const double acc = dot8(i + 1, SB, [&](int k) { return sR[i * LD + k]; },
-                            [&](int k) { return sX[k * LD + lane]; });            // X(k, c) = 0 for k > c
-    const double rinv = 1.0 / sR[i * LD + i];
-    if (lane >= i) sX[i * LD + lane] = (lane == i) ? rinv : -acc * rinv;
-    wave_sync();
-  }
 }
 
 // ---------------------------------------------------------------- tall-skinny passes over a panel
@@ -251,19 +168,15 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(int npart, const doub
 // first CholeskyQR pass: G (64x64, symmetric, stored j + 64 i) -> R1 (column-major) and R1^-1
 __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G, double *__restrict__ R,
                                                    double *__restrict__ Rinv, int *flag) {
-  __shared__ double sA[IMG], sB[IMG];
-  const int t = threadIdx.x, lane = t & 63;
+  __shared__ double sA[IMG], sB[IMG], srow[kLine];
+  const int t = threadIdx.x;
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int j = idx & 63, i = idx >> 6;
     sA[i * LD + j] = G[idx];
-    sB[i * LD + j] = 0.0;
   }
   __syncthreads();
-  if (t < 64) {
-    if (!chol64_upper(sA, lane) && lane == 0) atomicExch(flag, 1);
-    triinv64_upper(sA, sB, lane);
-  }
-  __syncthreads();
+  if (chol64_upper_wg(sA, srow) >= 0 && t == 0) atomicExch(flag, 1);
+  triinv64_upper_wg(sA, sB, srow);
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     R[idx] = sA[i * LD + j];
@@ -284,6 +197,7 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   double *sA = smem, *sB = smem + IMG, *sC = smem + 2 * IMG, *sD = smem + 3 * IMG;
   __shared__ double s_sign[SB];
   __shared__ double s_red[4];
+  __shared__ double srow[kLine], scol[kLine];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   long long tc[10]; int nt = 0;
   const bool prof = p.prof && t == 0;
@@ -294,9 +208,12 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
     const int j = idx & 63, i = idx >> 6;
     const double g = p.G2[idx];
     sA[i * LD + j] = g;
-    sB[i * LD + j] = 0.0;
     const double e = fabs(g - (i == j ? 1.0 : 0.0));
     dev = (e > dev || e != e) ? e : dev;
+  }
+  for (int idx = t; idx < SB * SB; idx += 256) {                        // sC = top block of Qt
+    const int i = idx & 63, j = idx >> 6;
+    sC[i * LD + j] = p.Qt[(size_t)i + (size_t)j * p.ldq];
   }
   for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(dev, o, 64); dev = (y > dev || y != y) ? y : dev; }
   if (lane == 0) s_red[wave] = dev;
@@ -307,83 +224,37 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
     if (!(dmax <= 0.25)) atomicExch(p.flag, 2);
   }
   if (prof) tc[nt++] = clock64();
-  if (t < 64) {
-    if (!chol64_upper(sA, lane) && lane == 0) atomicExch(p.flag, 1);   // sA = R2
-    if (prof) tc[nt++] = clock64();
-    triinv64_upper(sA, sB, lane);                                       // sB = R2^-1
-    if (prof) tc[nt++] = clock64();
-  }
-  for (int idx = t; idx < SB * SB; idx += 256) {                        // sC = top block of Qt
-    const int i = idx & 63, j = idx >> 6;
-    sC[i * LD + j] = p.Qt[(size_t)i + (size_t)j * p.ldq];
-  }
-  __syncthreads();
+  if (chol64_upper_wg(sA, srow) >= 0 && t == 0) atomicExch(p.flag, 1);      // sA = R2
+  if (prof) tc[nt++] = clock64();
+  triinv64_upper_wg(sA, sB, srow);                                      // sB = R2^-1
+  if (prof) tc[nt++] = clock64();
   mm64(sC, false, sB, false, sD);                                       // sD = Q top = Qt_top R2^-1
   __syncthreads();
   if (prof) tc[nt++] = clock64();
-  if (t < 64) {
-    // LU of (Q_top - S) without pivoting, S(j,j) = -sign(pivot) so that |pivot| >= 1 (in place:
-    // strictly lower = L1, upper = U)
-    for (int j = 0; j < SB; ++j) {
-      double acc = sD[j * LD + lane] -
-          dot8(0, j, [&](int k) { return sD[j * LD + k]; }, [&](int k) { return sD[k * LD + lane]; });
-      double piv = bcast_lane(acc, j);
-      const double sj = (piv >= 0.0) ? -1.0 : 1.0;
-      piv -= sj;
-      const double pinv = 1.0 / piv;
-      if (lane == j) { acc = piv; s_sign[j] = sj; }
-      if (lane >= j) sD[j * LD + lane] = acc;
-      wave_sync();
-      const double accl = sD[lane * LD + j] -
-          dot8(0, j, [&](int k) { return sD[lane * LD + k]; }, [&](int k) { return sD[k * LD + j]; });
-      if (lane > j) sD[lane * LD + j] = accl * pinv;
-      wave_sync();
-    }
-  }
+  lu64_signed_wg(sD, s_sign, srow, scol);                               // sD = L1 \ U of (Q_top - S)
   if (prof) tc[nt++] = clock64();
-  __syncthreads();
-  // T = -U S L1^-T (wave 0, into sC transposed) and U^-1 (wave 1, into sA: R2 is no longer needed
-  // there -- it is kept in global memory for S R2 R1) side by side: both only read sD
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     p.L1[idx] = (i > j) ? sD[i * LD + j] : (i == j ? 1.0 : 0.0);
-    p.M2[idx] = sA[i * LD + j];                                          // R2, parked in M2 for a moment
   }
-  __syncthreads();
-  for (int idx = t; idx < IMG; idx += 256) sA[idx] = 0.0;
-  __syncthreads();
-  if (wave == 0) {
-    // by rows: L1 t^T = c^T; kept transposed (sC(j, i) = T(i, j)), lane = i
-    for (int j = 0; j < SB; ++j) {
-      const double acc = ((lane <= j) ? -sD[lane * LD + j] * s_sign[j] : 0.0) -
-          dot8(0, j, [&](int k) { return sD[j * LD + k]; }, [&](int k) { return sC[k * LD + lane]; });
-      sC[j * LD + lane] = acc;
-      wave_sync();
-    }
-  } else if (wave == 1) {
-    triinv64_upper(sD, sA, lane);                                       // sA = U^-1
-  }
-  if (prof) tc[nt++] = clock64();
-  __syncthreads();
+  // T = -U S L1^-T (into sC transposed: sC(j, i) = T(i, j)); the top block of Qt is no longer needed
+  tsolve64_wg(sD, s_sign, sC, srow);
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     p.T[idx] = sC[j * LD + i];
     if (i == j) p.tau[i] = sC[i * LD + i];
   }
   __syncthreads();
-  for (int idx = t; idx < SB * SB; idx += 256) {                        // sD = R2 back from its parking place
+  triinv64_upper_wg(sD, sC, srow);                                      // sC = U^-1
+  if (prof) tc[nt++] = clock64();
+  for (int idx = t; idx < SB * SB; idx += 256) {                        // sD = R1
     const int i = idx & 63, j = idx >> 6;
-    sD[i * LD + j] = p.M2[idx];
+    sD[i * LD + j] = p.R1[idx];
   }
   if (prof) tc[nt++] = clock64();
   __syncthreads();
-  for (int idx = t; idx < SB * SB; idx += 256) {                        // sC = R1
-    const int i = idx & 63, j = idx >> 6;
-    sC[i * LD + j] = p.R1[idx];
-  }
-  __syncthreads();
-  mm64(sB, false, sA, false, nullptr, p.M2);                            // M2 = R2^-1 U^-1
-  mm64(sD, false, sC, false, nullptr, p.Rband, s_sign);                 // S R2 R1
+  mm64(sB, false, sC, false, nullptr, p.M2);                            // M2 = R2^-1 U^-1
+  mm64(sA, false, sD, false, nullptr, p.Rband, s_sign);                 // S R2 R1
   if (prof) { tc[nt++] = clock64(); for (int q = 0; q + 1 < nt; ++q) p.prof[q] += tc[q + 1] - tc[q]; p.prof[9] += 1; }
 }
 
@@ -868,8 +739,8 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     (void)hipMemcpyAsync(h, sm + 10 * 4096, sizeof(h), hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);
     if (h[9] > 0)
-      fprintf(stderr, "[hr_kernel prof] calls %lld; cycles: load %.0f chol %.0f inv %.0f qtop-mm %.0f lu %.0f tsolve+out %.0f "
-              "uinv %.0f mm2 %.0f\n", h[9], (double)h[0] / h[9], (double)h[1] / h[9], (double)h[2] / h[9], (double)h[3] / h[9],
+      fprintf(stderr, "[hr_kernel prof] calls %lld; cycles: load %.0f chol %.0f inv %.0f qtop-mm %.0f lu %.0f tsolve+uinv %.0f "
+              "r1-load %.0f mm2 %.0f\n", h[9], (double)h[0] / h[9], (double)h[1] / h[9], (double)h[2] / h[9], (double)h[3] / h[9],
               (double)h[4] / h[9], (double)h[5] / h[9], (double)h[6] / h[9], (double)h[7] / h[9]);
   }
 }
