@@ -10,8 +10,8 @@
 // first column of the bulge is annihilated by the next reflector of the sweep, and so on to the end
 // of the band.  Task (s, k): reflector k of sweep s on I_k = [s+1+64k, s+64(k+1)], applied from the
 // left to B_{k-1} = A(I_k, I_{k-1}), from both sides to D_k = A(I_k, I_k), from the right to
-// B_k = A(I_{k+1}, I_k).  Task (s+1, j) may run once task (s, j+2) is done: the sweeps form a
-// pipeline.
+// B_k = A(I_{k+1}, I_k).  Task (s+1, j) may run once task (s, j+1) is done (see chase_kernel): the
+// sweeps form a pipeline.
 //
 // MI355X shape: ONE persistent launch; a workgroup takes sweeps from a ticket counter (in order, so
 // a workgroup only ever waits for a sweep whose owner is already running) and walks down the band,
@@ -77,7 +77,7 @@ struct ChaseArgs {
   double *tau2; int ldt;
   unsigned *prog;        // [nsweeps] tasks completed per sweep
   unsigned *ctl;         // [0] ticket, [1] abort
-  int extra;             // extra distance (tasks) a sweep keeps from its predecessor beyond the 3 it must
+  int extra;             // extra distance (tasks) a sweep keeps from its predecessor beyond the 2 it must
   long long *prof;       // optional: [0..5] shader cycles per phase of a task summed over workgroup 0's tasks, [6] tasks
 };
 
@@ -106,10 +106,17 @@ __device__ __forceinline__ double make_reflector(double x, int lane, int L, int 
   return beta;
 }
 
-// Per task the workgroup synchronises three times; the progress word of task k-1 is published in
-// the middle of task k (its stores have drained by then: nobody stalls on the write-through), and
-// the gate of task k+1 is looked at without blocking while task k computes, so that its blocks are
-// already in flight when the task starts.
+// Dependencies between sweeps.  Task (s, k) works on rows and columns s+1+64k .. s+64(k+2) of the lower
+// band.  The only entry in that range which task (s-1, k+2) of the previous sweep changes is the corner
+// A(s+64(k+2), s+64(k+1)) -- entry (0,0) of ITS block B_{k+1}, which the reflector of that task turns
+// into beta, a number already known when the reflector is made at the end of task (s-1, k+1).  So the
+// maker stores column 0 of the new block, (beta, 0, ..., 0), right then, the later store of the block
+// leaves column 0 alone, and task (s, k) may run as soon as task (s-1, k+1) is done: sweeps follow each
+// other TWO tasks apart, not three (the pipeline is latency-bound: its length is the number of sweeps
+// times that distance).
+//
+// Per task the workgroup synchronises three times; its completion is published after its stores have
+// drained (s_waitcnt vmcnt(0) in every wave, barrier, sc1 store of the progress word).
 // NW waves per workgroup, each with CW = 64 / NW columns of a block (row per lane).
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
@@ -121,11 +128,10 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
   __shared__ double s_D[SB * DLD];
   __shared__ double s_z[SB];
   __shared__ double s_tau[2];
-  __shared__ int s_sweep, s_ok, s_gate;
+  __shared__ int s_sweep, s_ok;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n = p.n;
   const int c0w = CW * wave;                               // this wave's columns of a block
-  const bool immediate = p.extra < 0;                      // publish every task at its end, no look-ahead
   double *AB = p.AB;
   while (true) {
     __syncthreads();
@@ -138,7 +144,6 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
     double bp[CW], dl[CW], bk[CW];
 #pragma unroll
     for (int j = 0; j < CW; ++j) { bp[j] = 0.0; dl[j] = 0.0; bk[j] = 0.0; }
-    bool have_pf = false;
     for (int k = 0; k < K; ++k) {
       const int i0 = s + 1 + k * SB;                       // first index of I_k
       const int L = (n - i0 < SB) ? n - i0 : SB;           // its length (>= 2)
@@ -146,39 +151,32 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
       const bool prof = p.prof && blockIdx.x == 0 && t == 0;
       if (prof) tc0 = clock64();
-      if (!have_pf) {
-        // ---- blocking wait until sweep s-1 is far enough ahead, then fetch D_k and B_k
-        if (t == 0) {
-          int ok = 1;
-          if (s > 0) {
-            const int ex = immediate ? 0 : p.extra;
-            const unsigned need = (unsigned)((k + 3 + ex < Kprev) ? k + 3 + ex : Kprev);
-            unsigned spins = 0;
-            while (__hip_atomic_load(&p.prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-              __builtin_amdgcn_s_sleep(1);
-              if ((++spins & 63u) == 0u &&
-                  (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                ok = 0; break;
-              }
+      // ---- wait until sweep s-1 has finished its task k+1 (+ p.extra for experiments), then fetch D_k and B_k
+      if (t == 0) {
+        int ok = 1;
+        if (s > 0) {
+          const unsigned need = (unsigned)((k + 2 + p.extra < Kprev) ? k + 2 + p.extra : Kprev);
+          unsigned spins = 0;
+          while (__hip_atomic_load(&p.prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0u &&
+                (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+              ok = 0; break;
             }
           }
-          if (!ok) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_ok = ok;
         }
-        __syncthreads();
-        if (!s_ok) return;
+        if (!ok) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = ok;
+      }
+      __syncthreads();
+      if (!s_ok) return;
 #pragma unroll
-        for (int j = 0; j < CW; ++j) {
-          const int c = c0w + j;
-          dl[j] = (lane < L && c <= lane) ? ld_sc1(AB + (unsigned)((lane - c) + (i0 + c) * LDAB)) : 0.0;
-          bk[j] = (lane < L1 && c < L) ? ld_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB)) : 0.0;
-        }
+      for (int j = 0; j < CW; ++j) {
+        const int c = c0w + j;
+        dl[j] = (lane < L && c <= lane) ? ld_sc1(AB + (unsigned)((lane - c) + (i0 + c) * LDAB)) : 0.0;
+        bk[j] = (lane < L1 && c < L) ? ld_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB)) : 0.0;
       }
       if (prof) tc1 = clock64();
-      // a first, non-blocking look at the gate of task k+1 (the value arrives while this task computes)
-      unsigned gate_val = 0;
-      if (!immediate && t == 0 && s > 0 && k + 1 < K)
-        gate_val = __hip_atomic_load(&p.prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // ---- (a) the reflector of task 0: x = A(I_0, s).  Those of the later tasks were made at the end of
       // the previous task (below), beside the drain of its stores.
       const int cur = k & 1;
@@ -219,8 +217,10 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
           const int c = c0w + j;
-          if (c > 0) bp[j] -= tau * v_r * s_z[c];          // column 0 is (beta, 0, ..., 0) already
-          if (lane < L) st_sc1(AB + (unsigned)((SB + lane - c) + (ip + c) * LDAB), bp[j]);
+          if (c > 0) {           // column 0 is (beta, 0, ..., 0) and in memory since the reflector was made
+            bp[j] -= tau * v_r * s_z[c];
+            if (lane < L) st_sc1(AB + (unsigned)((SB + lane - c) + (ip + c) * LDAB), bp[j]);
+          }
         }
       }
       // ---- D_k as a full symmetric image
@@ -229,12 +229,8 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         const int c = c0w + j;
         if (c <= lane) { s_D[lane * DLD + c] = dl[j]; s_D[c * DLD + lane] = dl[j]; }
       }
-      // everything task k-1 stored (and the blocks of this task) has arrived: its progress can be told
-      if (k > 0 && !immediate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                                       // #2
       if (prof) tc3 = clock64();
-      if (t == 0 && k > 0 && !immediate)
-        __hip_atomic_store(&p.prog[s], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // ---- partial sums of p = D v and q = B_k v
       double dd[CW];
       {
@@ -243,26 +239,8 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         for (int j = 0; j < CW; ++j) { dd[j] = s_D[lane * DLD + c0w + j]; pp += dd[j] * vc[j]; qq += bk[j] * vc[j]; }
         s_p[wave][lane] = pp; s_q[wave][lane] = qq;
       }
-      if (t == 0) {
-        const unsigned need = (unsigned)((k + 4 + p.extra < Kprev) ? k + 4 + p.extra : Kprev);
-        s_gate = !immediate && (k + 1 < K) && (s == 0 || gate_val >= need);
-      }
       __syncthreads();                                                       // #3
       if (prof) tc4 = clock64();
-      // ---- blocks of task k+1 into flight if its gate is already open
-      const bool gate = s_gate != 0;
-      double ndl[CW], nbk[CW];
-      if (gate) {
-        const int j0 = i0 + SB;
-        const int Ln = (n - j0 < SB) ? n - j0 : SB;
-        int L1n = n - j0 - SB; if (L1n > SB) L1n = SB; if (L1n < 0) L1n = 0;
-#pragma unroll
-        for (int j = 0; j < CW; ++j) {
-          const int c = c0w + j;
-          ndl[j] = (lane < Ln && c <= lane) ? ld_sc1(AB + (unsigned)((lane - c) + (j0 + c) * LDAB)) : 0.0;
-          nbk[j] = (lane < L1n && c < Ln) ? ld_sc1(AB + (unsigned)((SB + lane - c) + (j0 + c) * LDAB)) : 0.0;
-        }
-      }
       // ---- (c) D_k <- H D_k H
       double psum = 0.0;
 #pragma unroll
@@ -304,20 +282,17 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         p.prof[0] += tc1 - tc0; p.prof[1] += tc2 - tc1; p.prof[2] += tc3 - tc2; p.prof[3] += tc4 - tc3;
         p.prof[4] += tc5 - tc4; p.prof[6] += 1;
       }
-      have_pf = gate;
-      if (gate) {
-#pragma unroll
-        for (int j = 0; j < CW; ++j) { dl[j] = ndl[j]; bk[j] = nbk[j]; }
-      }
-      // ---- the reflector of task k+1 from the first column of the new B_k, while this task's stores drain
-      if (k + 1 < K && wave == 0) {
-        const int i0n = i0 + SB;
-        const int Ln = (n - i0n < SB) ? n - i0n : SB;
-        const double beta = make_reflector(bp[0], lane, Ln, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
-        bp[0] = (lane == 0) ? beta : 0.0;
-      }
-      if (!immediate && k + 1 < K) __syncthreads();      // the new reflector is in LDS (immediate mode: barrier below)
-      if (immediate && k + 1 < K) {        // tell the follower at once (the last task is told below)
+      // ---- the reflector of task k+1 from the first column of the new B_k, which goes to memory at once as
+      // (beta, 0, ..., 0): it holds the one entry the next sweep needs from task k+1 (see above)
+      if (k + 1 < K) {
+        if (wave == 0) {
+          const int i0n = i0 + SB;
+          const int Ln = (n - i0n < SB) ? n - i0n : SB;
+          const double beta = make_reflector(bp[0], lane, Ln, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
+          bp[0] = (lane == 0) ? beta : 0.0;
+          if (lane < Ln) st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), bp[0]);
+        }
+        // tell the follower (the last task is told below)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) __hip_atomic_store(&p.prog[s], (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -666,11 +641,11 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
   (void)hipMemsetAsync(prog, 0, (size_t)(L.nsweeps + 1) * 4 + 0, s);
   (void)hipMemsetAsync(ctl, 0, 256, s);
   if (L.nsweeps > 0) {
-    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, -1, nullptr};
+    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, 0, nullptr};
     if (getenv("EK_SB2ST_PROF")) { c.prof = (long long *)(ctl + 16); }
-    if (const char *ev = getenv("EK_SB2ST_EXTRA")) c.extra = atoi(ev);
-    // enough workgroups for the pipeline (a sweep can start three tasks behind its predecessor)
-    int nwg = n / ((3 + (c.extra > 0 ? c.extra : 0)) * SB) + 8;
+    if (const char *ev = getenv("EK_SB2ST_EXTRA")) { c.extra = atoi(ev); if (c.extra < 0) c.extra = 0; }
+    // enough workgroups for the pipeline (a sweep can start two tasks behind its predecessor)
+    int nwg = n / ((2 + c.extra) * SB) + 8;
     if (nwg > 256) nwg = 256;
     if (nwg > L.nsweeps) nwg = L.nsweeps;
     if (const char *ev = getenv("EK_SB2ST_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
