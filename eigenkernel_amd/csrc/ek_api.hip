@@ -276,12 +276,14 @@ constexpr int kPotrfRlMin = 1024;
 // Orders from which the whole-path call tridiagonalises in two stages (dense -> band on the matrix
 // cores, band -> tridiagonal by bulge chasing; ek_sy2sb.hip, ek_sb2st.hip) instead of the one-stage
 // Householder reduction.  EK_HIP_TWO_STAGE_MIN overrides (0 = never); ek_hip_debug_set_two_stage too.
+// Measured with tools/crossover.py (standard problem, full spectrum, one-stage / two-stage seconds):
+// 4096: 0.0915 / 0.0946, 6144: 0.1765 / 0.1626, 8192: 0.3054 / 0.2528.
 int g_two_stage_min = -1;
 int two_stage_min() {
   if (g_two_stage_min >= 0) return g_two_stage_min;
   static int env = -2;
   if (env == -2) { const char *e = getenv("EK_HIP_TWO_STAGE_MIN"); env = e ? atoi(e) : -1; }
-  return env >= 0 ? env : 10240;
+  return env >= 0 ? env : 5120;
 }
 
 // From how many ranks on the Cholesky factor and the reduction to standard form are distributed

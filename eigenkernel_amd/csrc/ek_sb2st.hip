@@ -49,6 +49,33 @@ __device__ __forceinline__ void st_sc1(double *p, double v) {
   __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
+// Sums across lanes with DPP moves (a few cycles each) instead of __shfl_xor (an LDS-crossbar round trip
+// per step): in the latency-bound chase every such chain is on the critical path of a task.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of W consecutive lanes (W = 2, 4, 8, 16), result in every lane of the group
+template <int W>
+__device__ __forceinline__ double group_sum(double v) {
+  if (W >= 2) v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+  if (W >= 4) v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+  if (W >= 8) v += dpp_mov<0x141>(v);      // row_half_mirror
+  if (W >= 16) v += dpp_mov<0x140>(v);     // row_mirror
+  return v;
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// sum over the wave, result in every lane
+__device__ __forceinline__ double wave_sum(double v) {
+  v = group_sum<16>(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
@@ -89,10 +116,8 @@ struct ChaseArgs;
 template <typename Args>
 __device__ __forceinline__ double make_reflector(double x, int lane, int L, int i0, int s, int k, const Args &p,
                                                  double *sv, double *stau) {
-  double ssq = (lane >= 1) ? x * x : 0.0;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) ssq += __shfl_xor(ssq, o, 64);
-  const double alpha0 = __shfl(x, 0, 64);
+  const double ssq = wave_sum((lane >= 1) ? x * x : 0.0);
+  const double alpha0 = lane_value(x, 0);
   double beta = alpha0, tau = 0.0, scale = 0.0;
   if (ssq != 0.0) {
     beta = -copysign(sqrt(alpha0 * alpha0 + ssq), alpha0);   // the path keeps |A| within 1e+-90
@@ -207,9 +232,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
           double a0 = 0.0, a1 = 0.0;
 #pragma unroll
           for (int l = 0; l < CW; l += 2) { a0 += src[l]; a1 += src[l + 1]; }
-          double tot = a0 + a1;
-#pragma unroll
-          for (int o = 1; o < LPC; o <<= 1) tot += __shfl_xor(tot, o, 64);
+          const double tot = group_sum<LPC>(a0 + a1);
           if (q == 0) s_z[c0w + j] = tot;
         }
         wave_sync();
@@ -246,9 +269,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 #pragma unroll
       for (int w = 0; w < NW; ++w) psum += s_p[w][lane];
       const double p_r = tau * psum;
-      double dot = p_r * v_r;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      const double dot = wave_sum(p_r * v_r);
       const double alpha = -0.5 * tau * dot;
       const double w_r = p_r + alpha * v_r;
 #pragma unroll
