@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs p) {
 // 8-wave kernel above (K = 128, n = 16384 lower: 26 vs 32 TFLOP/s -- prologue and epilogue of a tile are not
 // covered by a second workgroup), but the dense -> band stage as a whole is faster with it (0.288 -> 0.268 s
 // at N = 16384): the panel chain of the look-ahead stream gets its workgroups dispatched sooner.
-constexpr int RK = 64;                    // K per stage
+constexpr int RK = 32;                    // K per stage (64: 0.2335 s, 32: 0.2276 s for sy2sb at N = 16384)
 constexpr int RK_LD = BM + 16;            // doubles per k-row of a slab image (conflict-free fragment reads)
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
@@ -406,14 +406,15 @@ __global__ __launch_bounds__(512) void gemm_rankk_kernel(GemmArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
   const int l15 = lane & 15, l4 = lane >> 4;
-  // 16-byte operand fetch: thread -> (row pair xp = t & 63, k = t >> 6 + 8 i), 8 per operand and stage;
+  // 16-byte operand fetch: thread -> (row pair xp = t & 63, k = t >> 6 + 8 i), RK / 8 per operand and stage;
   // legal when the leading dimension and the base are even (the library's work arrays are), else scalars
   const bool vec = ((p.lda | p.ldb) & 1) == 0 && ((((size_t)A | (size_t)B) & 15) == 0);
   const int xp = 2 * (t & 63), kq = t >> 6;
-  double2_t ra[8], rb[8];
+  constexpr int NF = RK / 8;            // row pairs per thread, operand and stage
+  double2_t ra[NF], rb[NF];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NF; ++i) {
       const int k = k0 + kq + 8 * i;
       double2_t va = (double2_t){0.0, 0.0}, vb = (double2_t){0.0, 0.0};
       if (k < p.K) {
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(512) void gemm_rankk_kernel(GemmArgs p) {
   };
   auto put = [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NF; ++i) {
       const int k = kq + 8 * i;
       *reinterpret_cast<double2_t *>(&sA[k * RK_LD + xp]) = ra[i];
       *reinterpret_cast<double2_t *>(&sB[k * RK_LD + xp]) = rb[i];
