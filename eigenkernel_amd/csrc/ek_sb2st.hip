@@ -30,6 +30,7 @@
 #include "ek_common.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace ek {
@@ -412,13 +413,17 @@ __global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *
 }
 
 // ------------------------------------------------------------------------ Q2: application
-// Z <- Q2 Z as a two-dimensional pipeline of PASSES (S, slab): pass = one block of sweeps S applied to
-// one slab of 64 columns, walking down the rows in chunks of 64 (window k = chunk k + half of chunk
-// k+1, sliding by one chunk per group).  Pass (S, slab) may touch chunk j once pass (S+1, slab) has
-// finished it, so passes of one slab follow each other a few chunks apart: few columns (the *_select
-// arms) still fill the chip, and many columns run two passes per CU (two waves per SIMD is what
-// the fp64 matrix pipe needs, profiles/r02_mfma_peak.txt).  Persistent workgroups take passes from
-// a ticket counter in dependency order (S descending), so a workgroup only waits for passes whose
+// Z <- Q2 Z as a two-dimensional pipeline of PASSES (pair of blocks of sweeps, slab): a pass applies the
+// blocks of sweeps S+1 and S (S even) to one slab of 64 columns, walking down the rows in chunks of 64
+// starting at row 32 S.  In step k the window [chunk k | chunk k+1] (128 rows) sits in registers; group
+// (S+1, k) acts on its rows 32 .. 127, then group (S, k) on its rows 0 .. 95, after which chunk k is
+// final for both blocks and leaves.  Z is streamed once per PAIR of blocks: the stream of Z, not the
+// arithmetic, is what bounds this kernel (HBM traffic n^3/8 bytes instead of n^3/4 for all columns).
+// The pass of the pair above works 64 rows further down, so its chunk j-1 is our chunk j: passes of one
+// slab follow each other a few chunks apart, few columns (the *_select arms) still fill the chip, and many
+// columns run two passes per CU (two waves per SIMD is what the fp64 matrix pipe needs,
+// profiles/r02_mfma_peak.txt).  Persistent workgroups take passes from a ticket counter in dependency
+// order (S descending), so a workgroup only waits for passes whose
 // owners are running; a finished chunk is handed over through memory with agent-scope (sc1) stores,
 // a drain, a barrier and one progress word per pass, like the sweeps of chase_kernel.
 //
@@ -437,8 +442,8 @@ struct Q2ApplyArgs {
   Q2Geom g;
   const double *Rec;
   double *Z; int ldz; int ncols;
-  int nslab, npass;
-  unsigned *prog;        // [npass] chunks stored by pass (S, slab) at index (nS-1-S) * nslab + slab
+  int nslab, npass, npair;   // npair = ceil(nS / 2) pairs of blocks of sweeps (2 q, 2 q + 1); pair q = 0 is the lowest
+  unsigned *prog;        // [npass] chunks stored by pass (pair, slab) at index (npair-1-pair) * nslab + slab
   unsigned *ctl;         // [2] ticket, [1] abort (shared with the chase)
   int extra;             // chunks a pass keeps behind its predecessor beyond the two it must
 };
@@ -463,15 +468,18 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
     __syncthreads();
     const int pass = s_pass;
     if (pass >= p.npass) break;
-    const int S = p.g.nS - 1 - pass / p.nslab, slab = pass % p.nslab;
+    const int pair = p.npair - 1 - pass / p.nslab, slab = pass % p.nslab;
+    const int S = 2 * pair;                              // lower block of the pair; the upper one may not exist
+    const bool has_hi = S + 1 < p.g.nS;
     const int KS = q2_groups_of_block(n, S);
+    const int KSH = has_hi ? q2_groups_of_block(n, S + 1) : 0;     // KS or KS - 1
     const int colw = slab * QNC + 16 * wave;
-    const unsigned *pprog = (S + 1 < p.g.nS) ? p.prog + (size_t)(pass - p.nslab) : nullptr;   // predecessor (S+1, slab)
+    const unsigned *pprog = (pair + 1 < p.npair) ? p.prog + (size_t)(pass - p.nslab) : nullptr;   // the pair above, same slab
     unsigned *myprog = p.prog + pass;
     if (KS <= 0) { if (t == 0) __hip_atomic_store(myprog, kQ2Done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
     const int o0 = S * QG;                               // first row of chunk 0 (even)
-    // chunks of the predecessor are offset by +32 rows: chunk j of this pass is final once the predecessor
-    // has stored its chunks <= j; waiting for `need` stored chunks, bounded
+    // the pair above works 64 rows further down: its chunk j - 1 is our chunk j, which is therefore final
+    // once it has stored j chunks; waiting for `need` stored chunks, bounded
     auto wait_for = [&](unsigned need) -> bool {         // thread 0 only
       if (!pprog) return true;
       unsigned spins = 0;
@@ -486,8 +494,8 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
     double4_t za[4], zb[4];
     constexpr int NOP = (QREC + 255) / 256;             // 25 doubles of a record per thread
     double zreg[16], oreg[NOP];
-    auto fetch_ops = [&](int k) {                        // the record is the LDS image itself: a linear copy
-      const double *rec = p.Rec + ((size_t)S * p.g.kmax + k) * QREC;
+    auto fetch_ops = [&](int Sb, int k) {                // the record is the LDS image itself: a linear copy
+      const double *rec = p.Rec + ((size_t)Sb * p.g.kmax + k) * QREC;
 #pragma unroll
       for (int q = 0; q < NOP; ++q) oreg[q] = (q < NOP - 1 || t + 256 * q < QREC) ? rec[t + 256 * q] : 0.0;
     };
@@ -560,29 +568,9 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
         wave_sync();
       }
     };
-    // ---- prologue: chunks 0 and 1 need the predecessor's chunks <= 1 (+ slack)
-    if (t == 0) s_ok = wait_for((unsigned)(2 + p.extra)) ? 1 : 0;
-    __syncthreads();
-    if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    fetch_chunk(0); chunk_to_tiles(za);
-    fetch_chunk(1); chunk_to_tiles(zb);
-    fetch_ops(0);
-    unsigned early = 0;                                   // thread 0: an early look at the predecessor's progress
-    for (int k = 0; k < KS; ++k) {
-      // gate of this group: chunk k+2 is fetched below, it needs the predecessor's chunks <= k+2.  The word
-      // was read while the previous group computed; only if that was too early does the thread poll.
-      if (t == 0) {
-        const unsigned need = (unsigned)(k + 3 + p.extra);
-        s_ok = (!pprog || early >= need || wait_for(need)) ? 1 : 0;
-      }
-      __syncthreads();
-      if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-      // every wave has passed the drain in front of its stores of chunk k-1, so chunks <= k-2 are in memory
-      if (t == 0 && k > 1) __hip_atomic_store(myprog, (unsigned)(k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      put_ops();
-      __syncthreads();
-      if (t == 0 && pprog) early = __hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (k + 1 < KS) { fetch_ops(k + 1); fetch_chunk(k + 2); }
+    // one group on the window [za | zb]: row tiles OFF .. OFF + 5 of its eight (16 rows each)
+    auto apply_group = [&](auto off_c) {
+      constexpr int OFF = decltype(off_c)::value;
       double4_t w1[2];
       w1[0] = (double4_t){0.0, 0.0, 0.0, 0.0}; w1[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -591,24 +579,64 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
         for (int r = 0; r < 4; ++r) {
           // the image is a parallelogram: reflector i lives in rows i .. i + 63, so rows 80.. hold
           // nothing of reflectors 0..15 and rows 0..15 nothing of reflectors 16..31
-          const double y = (tile < 4) ? za[tile & 3][r] : zb[tile & 3][r];
+          const double y = (tile + OFF < 4) ? za[(tile + OFF) & 3][r] : zb[(tile + OFF) & 3][r];
           const double *vrow = sV + (16 * tile + 4 * r + l4) * QVLD + l15;
           if (tile < 5) w1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[0], y, w1[0], 0, 0, 0);
           if (tile > 0) w1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[16], y, w1[1], 0, 0, 0);
         }
 #pragma unroll
       for (int tile = 0; tile < 6; ++tile) {
-        double4_t acc = (tile < 4) ? za[tile & 3] : zb[tile & 3];
+        double4_t acc = (tile + OFF < 4) ? za[(tile + OFF) & 3] : zb[(tile + OFF) & 3];
         const double *xrow = sVT + (16 * tile + l15) * QVLD + l4;
 #pragma unroll
         for (int kk = (tile == 5 ? 16 : 0); kk < QG; kk += 4)      // rows 80.. of V T: columns 16.. only
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xrow[kk], w1[kk >> 4][(kk & 15) >> 2], acc, 0, 0, 0);
-        if (tile < 4) za[tile & 3] = acc; else zb[tile & 3] = acc;
+        if (tile + OFF < 4) za[(tile + OFF) & 3] = acc; else zb[(tile + OFF) & 3] = acc;
       }
-      // (the stores of the previous chunk, issued a whole group ago, have long completed: this wait
-      // only makes that certain before the progress word of the next group tells the follower)
+    };
+    // ---- prologue: chunk 1 is chunk 0 of the pair above (+ slack)
+    if (t == 0) s_ok = wait_for((unsigned)(1 + p.extra)) ? 1 : 0;
+    __syncthreads();
+    if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    fetch_chunk(0); chunk_to_tiles(za);
+    fetch_chunk(1); chunk_to_tiles(zb);
+    if (KSH > 0) fetch_ops(S + 1, 0); else fetch_ops(S, 0);
+    unsigned early = 0;                                   // thread 0: an early look at the predecessor's progress
+    for (int k = 0; k < KS; ++k) {
+      // gate of this step: chunk k+2 is fetched below, it is chunk k+1 of the pair above.  The word
+      // was read while the previous group computed; only if that was too early does the thread poll.
+      if (t == 0) {
+        const unsigned need = (unsigned)(k + 2 + p.extra);
+        s_ok = (!pprog || early >= need || wait_for(need)) ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+      // every wave has passed the drain in front of its stores of chunk k-1, so chunks <= k-2 are in memory
+      if (t == 0 && k > 1) __hip_atomic_store(myprog, (unsigned)(k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool hi = k < KSH;
+      if (hi) {
+        // group (S+1, k) on rows 32 .. 127 of the window, the record of (S, k) in flight meanwhile
+        put_ops();
+        __syncthreads();
+        if (t == 0 && pprog) early = __hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fetch_ops(S, k);
+        if (k + 1 < KS) fetch_chunk(k + 2);
+        apply_group(std::integral_constant<int, 2>());
+        __syncthreads();                                  // all waves have read the images of (S+1, k)
+      }
+      // group (S, k) on rows 0 .. 95
+      put_ops();
+      __syncthreads();
+      if (!hi && t == 0 && pprog) early = __hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k + 1 < KS) {
+        if (k + 1 < KSH) fetch_ops(S + 1, k + 1); else fetch_ops(S, k + 1);
+        if (!hi) fetch_chunk(k + 2);
+      }
+      apply_group(std::integral_constant<int, 0>());
+      // (the stores of the previous chunk, issued a whole step ago, have long completed: this wait
+      // only makes that certain before the progress word of the next step tells the follower)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      tiles_to_global(k, za);                            // chunk k is final for this block of sweeps
+      tiles_to_global(k, za);                            // chunk k is final for both blocks of sweeps
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) za[tt] = zb[tt];
       if (k + 1 < KS) chunk_to_tiles(zb);                // chunk k+2
@@ -704,10 +732,10 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   constexpr size_t lds = (size_t)(QOPSZ + 4 * 16 * QSTLD) * sizeof(double);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)q2_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  const int nslab = ceil_div(ncols, QNC), npass = L.nS * nslab;
+  const int nslab = ceil_div(ncols, QNC), npair = ceil_div(L.nS, 2), npass = npair * nslab;
   (void)hipMemsetAsync(qprog, 0, (size_t)npass * 4, s);
   (void)hipMemsetAsync(ctl + 2, 0, 4, s);
-  Q2ApplyArgs a{g, Rec, Z, ldz, ncols, nslab, npass, qprog, ctl, 2};
+  Q2ApplyArgs a{g, Rec, Z, ldz, ncols, nslab, npass, npair, qprog, ctl, 2};
   if (const char *ev = getenv("EK_Q2_EXTRA")) a.extra = atoi(ev);
   int nwg = 512;
   if (const char *ev = getenv("EK_Q2_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
