@@ -28,7 +28,7 @@ the ranks there are).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline"        : the dominant kernel, timed live with HIP events on its launch stream in the
-                      timed region: with the two-stage tridiagonalisation (orders >= 10240) the
+                      timed region: with the two-stage tridiagonalisation (orders >= 5120) the
                       MFMA-bound application of the bulge-chasing reflectors (q2_apply_kernel),
                       else the HBM-bound symv of the one-stage reduction;
   "roofline_stages" : per stage of the path, algorithmic flops / device seconds
@@ -620,7 +620,7 @@ def main():
                     pass
             out["roofline"] = {
                 "kernel": "q2_apply_kernel (Z <- Q2 Z: reflectors of the band->tridiagonal stage, compact-WY blocks of 32 "
-                          "sweeps, window of Z resident in MFMA accumulator registers)",
+                          "sweeps applied two blocks per pass, window of Z resident in MFMA accumulator registers)",
                 "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                 "launches": int(kp_l[0]), "avg_launch_us": 1e6 * dur, "algorithmic_flops_per_launch": fl,
