@@ -16,6 +16,15 @@ import os
 import numpy as np
 import pytest
 
+
+def _free_port():
+    """A TCP port nobody is listening on (127.0.0.1): fixed port numbers collide with sockets of earlier tests."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 pytestmark = pytest.mark.gpu
 EPS = 2.220446049250313e-16
 
@@ -369,7 +378,7 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
     world = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_mp_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
@@ -498,7 +507,7 @@ def test_four_processes_on_a_2x2_grid(hip, oracle, inputs, two_stage_min):
     world, nprow, npcol, n = 4, 2, 2, 450
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 37600 + (os.getpid() % 1000) + (0 if inputs == "replicated" else 1000) + (2000 if two_stage_min else 0)
+    port = _free_port()
     procs = [ctx.Process(target=_mp_grid_worker, args=(r, world, port, q, nprow, npcol, inputs, two_stage_min),
                          daemon=True) for r in range(world)]
     for p in procs:
@@ -612,3 +621,54 @@ def test_plain_c_host_with_forked_ranks(hip, argv):
     out = subprocess.run(["timeout", "-k", "5", "120", exe] + argv, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "max |A z - lambda B z|" in out.stdout
+
+
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+@pytest.mark.parametrize("nranks,solver,n,extra,comm", [
+    (4, "general_hip", 700, [], "hook"),          # 2 x 2 grid, the library borrows MPI_Allgatherv, runs replicated
+    (4, "general_hip", 700, [], "host"),          # distributed stages, every exchange through the hook
+    (4, "hip_select", 1000, ["-n", "60"], "host"),   # lowest 60 pairs (the test process holds the GPU too:
+                                                     # at most 6 processes may, so no 2 x 3 grid here)
+    (2, "general_hip_select", 500, ["-n", "17"], "host"),   # 1 x 2 grid
+    (3, "hip", 333, ["--block-size", "15"], "hook"),  # 1 x 3 grid, ragged blocks
+])
+def test_fortran_mpi_host_on_a_process_grid(tmp_path, nranks, solver, n, extra, comm):
+    """The reference's host shape (main.f90:29-35, 84-104; processes.f90:17-36, 56-65;
+    distribute_matrix.f90:92-148) in its own language: host/eigenkernel_hip_mpi_app.f90 under mpiexec,
+    several MPI ranks sharing the one GPU, each with the block-cyclic pieces of its grid cell.  Eigenvalues
+    against the single-process Fortran host on the same synthetic input; residuals from the gathered Z."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "eigenkernel_hip_mpi_app")
+    one = os.path.join(root, "host", "eigenkernel_hip_app")
+    assert os.path.exists(MPIEXEC), "MPICH (the oracle's ScaLAPACK path uses it too) is missing from this image"
+    if not (os.path.exists(exe) and os.path.exists(one)):
+        subprocess.check_call(["make", "-C", os.path.join(root, "host")])
+    n_vec = int(extra[extra.index("-n") + 1]) if "-n" in extra else n
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "HSA_TOOLS")) and k != "LD_PRELOAD"}
+    ref = subprocess.run([one, "-s", solver, "--synthetic", str(n), "-o", "ev_one.dat"] + extra,
+                         cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+    assert ref.returncode == 0, ref.stderr
+    out = subprocess.run([MPIEXEC, "-np", str(nranks), exe, "-s", solver, "--synthetic", str(n), "--comm", comm,
+                          "-c", "-1", "-o", "ev_mpi.dat", "-l", "log_mpi.json"] + extra,
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    nprow = int((nranks + 1) ** 0.5)
+    while nranks % nprow:
+        nprow -= 1
+    assert "BLACS process grid: %d x %d (%d)" % (nprow, nranks // nprow, nranks) in txt
+    w1 = np.loadtxt(tmp_path / "ev_one.dat")[:, 1]
+    w2 = np.loadtxt(tmp_path / "ev_mpi.dat")[:, 1]
+    assert w1.shape == w2.shape == (n_vec,)
+    assert np.abs(w1 - w2).max() <= n * EPS * np.abs(w1).max()
+    spread = float([l for l in txt.splitlines() if l.startswith("eigenvalue spread across ranks:")][0].split(":")[1])
+    assert spread == 0.0
+    res_max = float([l for l in txt.splitlines() if l.startswith("residual norm (max):")][0].split(":")[1])
+    assert res_max <= 2e-14
+    import json
+    log = json.load(open(tmp_path / "log_mpi.json"))
+    assert log["n_procs"] == nranks and log["grid"] == [nprow, nranks // nprow] and log["comm"] == comm
+    assert {"eigen_solver", "eigen_solver_scalapack_all:pdsytrd"} <= {e["name"] for e in log["events"]}

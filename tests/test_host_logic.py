@@ -8,6 +8,15 @@ import re
 import numpy as np
 import pytest
 
+
+def _free_port():
+    """A TCP port nobody is listening on (127.0.0.1): fixed port numbers collide with sockets of earlier tests."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 import eigenkernel_amd as ek
 from eigenkernel_amd import descriptor as dsc
 from eigenkernel_amd import solver
@@ -173,7 +182,7 @@ def test_multi_rank_aggregation_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_bench_agg_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -232,7 +241,7 @@ def test_column_sharding_of_eigenvectors_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_grid_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -362,7 +371,7 @@ def test_gather_matrix_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -421,3 +430,23 @@ def test_bench_configs_and_flop_counts_follow_baseline_and_survey():
     assert abs(bench.flops(1, 16384, 16384) - 3.079e13) <= 1e10        # GEP full: 7 N^3
     assert abs(bench.flops(1, 16384, 1024) - 1.255e13) <= 1e10         # partial GEP, k = 1024
     assert bench.FP64_MFMA_PEAK_TFLOPS == 78.6 and bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_fortran_mpi_host_argument_contract(tmp_path):
+    """host/eigenkernel_hip_mpi_app.f90 under mpiexec, the part that needs no GPU: an unknown solver ends every
+    rank with "[Error] eigen_solver: Unknown solver ..." (solver_main.f90:98) and a non-zero exit code, -n is
+    refused for solvers that are not *_select (command_argument.f90:186-200)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "eigenkernel_hip_mpi_app")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(mpiexec) and os.path.exists("/opt/rocm/lib/llvm/bin/flang")):
+        pytest.skip("needs MPICH and flang")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "host"), "eigenkernel_hip_mpi_app"])
+    bad = subprocess.run([mpiexec, "-np", "2", exe, "-s", "general_elpa1", "--synthetic", "64"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "[Error] eigen_solver: Unknown solver general_elpa1" in bad.stderr
+    bad = subprocess.run([mpiexec, "-np", "2", exe, "-s", "hip", "-n", "5", "--synthetic", "64"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "-n is only legal" in bad.stderr
