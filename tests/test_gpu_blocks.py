@@ -74,13 +74,14 @@ def test_potrf_lookahead_reports_first_bad_pivot(hip, oracle):
     assert info == 701
 
 
-def test_potrf_reports_first_bad_pivot(hip, oracle):
+@pytest.mark.parametrize("bad", [150, 100, 63, 64, 0, 199])   # both 64-blocks of a 128x128 diagonal block, its edges
+def test_potrf_reports_first_bad_pivot(hip, oracle, bad):
     n = 200
     B = oracle.synth_matrix(n, 2)
-    B[150, 150] = -1.0
+    B[bad, bad] = -1.0
     _, info_or = oracle.potrf_lower(B)
     _, info = hip.potrf(B)
-    assert info == info_or == 151
+    assert info == info_or == bad + 1
 
 
 @pytest.mark.parametrize("n", [3, 100, 257, 600])
