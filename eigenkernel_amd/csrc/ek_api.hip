@@ -1596,9 +1596,10 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   const int ts_min = two_stage_min();
   const bool two_stage = ts_min > 0 && n >= ts_min && n >= 3;
   const size_t wb_sy2sb = two_stage ? al(sy2sb_work_bytes(n)) : 0, wb_sb2st = two_stage ? al(sb2st_work_bytes(n)) : 0;
+  const size_t wb_q1prep = two_stage ? al(ormtr_prep_bytes(n)) : 0;
   const size_t ws_need = 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
                          4 * al((size_t)ld * 8) + sygst_scr + potrf_wb +
-                         (two_stage ? 2 * mat + wb_sy2sb + wb_sb2st + al((size_t)ld * 8) : 0);
+                         (two_stage ? 2 * mat + wb_sy2sb + wb_sb2st + wb_q1prep + al((size_t)ld * 8) : 0);
   rc = workspace(ws_need, &ws);
   if (dist) rc = comm_agree(rc);         // a rank that cannot get its workspace takes the team out with it (-993)
   if (rc) return rc;
@@ -1617,6 +1618,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   double *wA0 = two_stage ? a.get<double>((size_t)ld * ld) : nullptr;
   char *work_sy2sb = two_stage ? a.get<char>(wb_sy2sb) : nullptr;
   char *work_sb2st = two_stage ? a.get<char>(wb_sb2st) : nullptr;
+  char *q1prep = two_stage ? a.get<char>(wb_q1prep) : nullptr;
   double *dt1 = two_stage ? a.get<double>(ld) : nullptr;
   // where the tridiagonalisation keeps x, the panel and its partial sums (probed once per workspace)
   void *sytrd_work = two_stage ? (void *)work : choose_sytrd_scratch(n, ld, wA, work, dd, wb_sytrd);
@@ -1710,7 +1712,20 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     EK_HIP_CHECK(hipMemsetAsync(wV2, 0, (size_t)ld * ld * 8, s));
     EK_HIP_CHECK(hipMemsetAsync(dt1, 0, (size_t)ld * 8, s));
     sy2sb_lower(s, g_ctx.stream2, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
+    // The T factors of the first stage's block reflectors (Gram matrices of the reflector blocks: 26 ms of
+    // skinny GEMMs at N = 16384) need nothing but those reflectors: second stream, beside the bulge chasing,
+    // a latency-bound pipeline on half of the CUs.
+    static hipEvent_t evP0 = nullptr, evP1 = nullptr;
+    if (!evP0) {
+      EK_HIP_CHECK(hipEventCreateWithFlags(&evP0, hipEventDisableTiming));
+      EK_HIP_CHECK(hipEventCreateWithFlags(&evP1, hipEventDisableTiming));
+    }
+    EK_HIP_CHECK(hipEventRecord(evP0, s));
+    EK_HIP_CHECK(hipStreamWaitEvent(g_ctx.stream2, evP0, 0));
+    ormtr_prepare(g_ctx.stream2, n, wV, ld, dt1, q1prep);
+    EK_HIP_CHECK(hipEventRecord(evP1, g_ctx.stream2));
     sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st);
+    EK_HIP_CHECK(hipStreamWaitEvent(s, evP1, 0));
     int flag = 0;
     EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
     EK_HIP_CHECK(hipStreamSynchronize(s));
@@ -1734,7 +1749,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   double *zc = wZ;
   if (two_stage_done) {
     sb2st_apply_q2(s, n, nc_loc, wV2, ld, zc, ld, g_ctx.d_info + 2, work_sb2st);
-    ormtr_lower(s, n, nc_loc, wV, ld, dt1, zc, ld, work);
+    ormtr_apply(s, n, nc_loc, wV, ld, q1prep, zc, ld, work);
   } else {
     ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work);
   }

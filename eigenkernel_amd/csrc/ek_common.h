@@ -247,6 +247,12 @@ size_t ormtr_work_bytes(int n, int ncols);
 // Z(:, 0:ncols) <- Q Z with Q = H(0)...H(n-2) given by explicit V (see sytrd_lower) and tau.
 void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, const double *tau,
                  double *Z, int ldz, void *work);
+// the same in two parts: the T factors of the block reflectors (independent of Z; prep >= ormtr_prep_bytes(n)),
+// then their application (work >= ormtr_work_bytes(n, ncols) - ormtr_prep_bytes(n))
+size_t ormtr_prep_bytes(int n);
+void ormtr_prepare(hipStream_t s, int n, const double *V, int ldv, const double *tau, void *prep);
+void ormtr_apply(hipStream_t s, int n, int ncols, const double *V, int ldv, const void *prep, double *Z, int ldz,
+                 void *work);
 // explicit V from the PDSYTRD storage (reflectors below the sub-diagonal of A)
 void build_explicit_v(hipStream_t s, int n, const double *A, int lda, double *V, int ldv);
 // synthetic SPD generator of SURVEY.md 8(d) on the device

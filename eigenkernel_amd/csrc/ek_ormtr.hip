@@ -83,10 +83,18 @@ size_t ormtr_work_bytes(int n, int ncols) {
          2 * al256((size_t)KB * (ncols > 0 ? ncols : 1) * 8);
 }
 
-void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, const double *tau,
-                 double *Z, int ldz, void *work) {
+// The block reflectors' T factors do not depend on the vectors they are applied to: ormtr_prepare forms them
+// (Gram matrices, 128x128 diagonal parts, couplings) into `prep` (>= ormtr_prep_bytes(n)), ormtr_apply then
+// needs three GEMMs per block of KB reflectors.  The whole-path call runs the preparation on its second
+// stream beside the bulge chasing, which leaves half of the chip idle.
+size_t ormtr_prep_bytes(int n) {
+  const int nblk = ceil_div(n > 1 ? n - 1 : 1, KB);
+  return 2 * al256((size_t)nblk * KB * KB * 8) + al256((size_t)nblk * (KB / 2) * (KB / 2) * 8);
+}
+
+void ormtr_prepare(hipStream_t s, int n, const double *V, int ldv, const double *tau, void *prep) {
   const int nrefl = n - 1;
-  if (nrefl <= 0 || ncols <= 0) return;
+  if (nrefl <= 0) return;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void *)larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -94,12 +102,10 @@ void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
     attr = true;
   }
   const int nblk = ceil_div(nrefl, KB);
-  char *w = (char *)work;
-  double *G = (double *)w; w += al256((size_t)nblk * KB * KB * 8);
+  char *w = (char *)prep;
   double *T = (double *)w; w += al256((size_t)nblk * KB * KB * 8);
-  double *Tmp = (double *)w; w += al256((size_t)nblk * (KB / 2) * (KB / 2) * 8);
-  double *W1 = (double *)w; w += al256((size_t)KB * ncols * 8);
-  double *W2 = (double *)w;
+  double *G = (double *)w; w += al256((size_t)nblk * KB * KB * 8);
+  double *Tmp = (double *)w;
 
   // all Gram matrices G_b = V_b^T V_b in one batched GEMM (rows above a block's reflectors
   // are zero in V, so the full column height can be used for every block); a short last
@@ -141,6 +147,18 @@ void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
       gemm(s, g);
     }
   }
+}
+
+// prep: what ormtr_prepare left (its T factors come first); work: >= 2 * KB * ncols doubles
+void ormtr_apply(hipStream_t s, int n, int ncols, const double *V, int ldv, const void *prep, double *Z, int ldz,
+                 void *work) {
+  const int nrefl = n - 1;
+  if (nrefl <= 0 || ncols <= 0) return;
+  const int nblk = ceil_div(nrefl, KB);
+  const double *T = (const double *)prep;
+  char *w = (char *)work;
+  double *W1 = (double *)w; w += al256((size_t)KB * ncols * 8);
+  double *W2 = (double *)w;
   for (int b = nblk - 1; b >= 0; --b) {
     const int c0 = b * KB;
     const int kb = (nrefl - c0 < KB) ? nrefl - c0 : KB;
@@ -151,6 +169,14 @@ void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
     gemm(s, false, false, kb, ncols, kb, 1.0, T + (size_t)b * KB * KB, KB, W1, KB, 0.0, W2, KB);
     gemm(s, false, false, m, ncols, kb, -1.0, Vb, ldv, W2, KB, 1.0, Zb, ldz);
   }
+}
+
+void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, const double *tau,
+                 double *Z, int ldz, void *work) {
+  if (n - 1 <= 0 || ncols <= 0) return;
+  char *prep = (char *)work;
+  ormtr_prepare(s, n, V, ldv, tau, prep);
+  ormtr_apply(s, n, ncols, V, ldv, prep, Z, ldz, prep + ormtr_prep_bytes(n));
 }
 
 }  // namespace ek
