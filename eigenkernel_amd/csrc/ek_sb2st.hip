@@ -104,8 +104,9 @@ struct ChaseArgs {
   double *V2; int ldv2;
   double *tau2; int ldt;
   unsigned *prog;        // [nsweeps] tasks completed per sweep
+  unsigned *progA;       // [nsweeps] tasks whose phase (b) has drained per sweep (kDoneAll when the sweep is finished)
   unsigned *ctl;         // [0] ticket, [1] abort
-  int extra;             // extra distance (tasks) a sweep keeps from its predecessor beyond the 2 it must
+  double *mail; int kmax;   // mailbox lines [4][kmax][MAILW]
   long long *prof;       // optional: [0..5] shader cycles per phase of a task summed over workgroup 0's tasks, [6] tasks
 };
 
@@ -137,13 +138,33 @@ __device__ __forceinline__ double make_reflector(double x, int lane, int L, int 
 // A(s+64(k+2), s+64(k+1)) -- entry (0,0) of ITS block B_{k+1}, which the reflector of that task turns
 // into beta, a number already known when the reflector is made at the end of task (s-1, k+1).  So the
 // maker stores column 0 of the new block, (beta, 0, ..., 0), right then, the later store of the block
-// leaves column 0 alone, and task (s, k) may run as soon as task (s-1, k+1) is done: sweeps follow each
-// other TWO tasks apart, not three (the pipeline is latency-bound: its length is the number of sweeps
-// times that distance).
+// leaves column 0 alone, and task (s, k) depends on task (s-1, k+1) only: sweeps follow each other TWO
+// tasks apart, not three (the pipeline is latency-bound: its length is the number of sweeps times that
+// distance).
 //
-// Per task the workgroup synchronises three times; its completion is published after its stores have
-// drained (s_waitcnt vmcnt(0) in every wave, barrier, sc1 store of the progress word).
-// NW waves per workgroup, each with CW = 64 / NW columns of a block (row per lane).
+// Of task (s-1, k+1) in turn, task (s, k) needs early only what its phase (b) leaves (the block B_k of
+// that sweep); from its later phases it needs 65 numbers -- column 0 of ITS diagonal block (our last
+// column of B_k and the corner of D_k) and that beta --, and it needs them only when its own phase (b)
+// is over.  So a sweep publishes two things per task: a progress word after phase (b) has drained
+// (progA), on which the follower starts, and those 65 numbers through a MAILBOX line the follower's last
+// wave polls directly (an "empty" bit pattern marks a slot; the reader empties it again; four lines per
+// task index in rotation) -- data that is its own flag costs no drain, no barrier and no second round
+// trip.  The completion word (prog) remains for what must not be overtaken: the one store of a task that
+// lands on an entry the previous sweep's task also stores (the corner of D_k).
+//
+// Per task the workgroup synchronises three times.  NW waves per workgroup, each with CW = 64 / NW
+// columns of a block (row per lane).
+constexpr unsigned kDoneAll = 0x7fffffffu;
+constexpr int MAILW = 72;                              // doubles per mailbox line: 64 (column 0 of D_k) + beta + padding
+constexpr unsigned long long kMailEmpty = 0x7ff8dead0000beefull;   // a NaN no computation produces
+
+__device__ __forceinline__ bool mail_empty(double v) { return (unsigned long long)__double_as_longlong(v) == kMailEmpty; }
+
+__global__ void mail_init_kernel(double *mail, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) mail[i] = __longlong_as_double((long long)kMailEmpty);
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
   constexpr int CW = SB / NW;            // columns of a block per wave
@@ -159,6 +180,19 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
   const int n = p.n;
   const int c0w = CW * wave;                               // this wave's columns of a block
   double *AB = p.AB;
+  if (t == 0) s_ok = 1;
+  auto give_up = [&]() { __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // bounded wait until *w >= need
+  auto wait_word = [&](const unsigned *w, unsigned need) -> bool {
+    unsigned spins = 0;
+    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 63u) == 0u &&
+          (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        return false;
+    }
+    return true;
+  };
   while (true) {
     __syncthreads();
     if (t == 0) s_sweep = (int)atomicAdd(&p.ctl[0], 1u);
@@ -167,6 +201,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
     if (s >= p.nsweeps) break;
     const int K = (n - 3 - s) / SB + 1;
     const int Kprev = (s > 0) ? (n - 2 - s) / SB + 1 : 0;
+    const bool has_follower = s + 1 < p.nsweeps;
     double bp[CW], dl[CW], bk[CW];
 #pragma unroll
     for (int j = 0; j < CW; ++j) { bp[j] = 0.0; dl[j] = 0.0; bk[j] = 0.0; }
@@ -177,22 +212,12 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
       const bool prof = p.prof && blockIdx.x == 0 && t == 0;
       if (prof) tc0 = clock64();
-      // ---- wait until sweep s-1 has finished its task k+1 (+ p.extra for experiments), then fetch D_k and B_k
-      if (t == 0) {
-        int ok = 1;
-        if (s > 0) {
-          const unsigned need = (unsigned)((k + 2 + p.extra < Kprev) ? k + 2 + p.extra : Kprev);
-          unsigned spins = 0;
-          while (__hip_atomic_load(&p.prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63u) == 0u &&
-                (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-              ok = 0; break;
-            }
-          }
-        }
-        if (!ok) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ok = ok;
+      // the previous sweep's task k+1, if it has one: its late numbers come through the mailbox
+      const bool lead = s > 0 && k + 1 < Kprev;
+      double *mail = p.mail + ((size_t)((s - 1) & 3) * p.kmax + (k + 1)) * MAILW;
+      // ---- gate: phase (b) of that task has drained (or the previous sweep is finished); fetch D_k and B_k
+      if (t == 0 && s > 0) {
+        if (!wait_word(&p.progA[s - 1], lead ? (unsigned)(k + 2) : kDoneAll)) { give_up(); s_ok = 0; }
       }
       __syncthreads();
       if (!s_ok) return;
@@ -202,9 +227,16 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         dl[j] = (lane < L && c <= lane) ? ld_sc1(AB + (unsigned)((lane - c) + (i0 + c) * LDAB)) : 0.0;
         bk[j] = (lane < L1 && c < L) ? ld_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB)) : 0.0;
       }
+      // a first look into the mailbox travels with the blocks (last wave: lane r takes entry r+1, the last lane
+      // beta and entry 0)
+      double m_a = 0.0, m_b = 0.0;
+      if (lead && wave == NW - 1) {
+        m_a = ld_sc1(mail + ((lane < 63) ? lane + 1 : 64));
+        if (lane == 63) m_b = ld_sc1(mail);
+      }
       if (prof) tc1 = clock64();
-      // ---- (a) the reflector of task 0: x = A(I_0, s).  Those of the later tasks were made at the end of
-      // the previous task (below), beside the drain of its stores.
+      // ---- (a) the reflector of task 0: x = A(I_0, s) (final: the previous sweep's task 0 is complete).  Those of
+      // the later tasks were made at the end of the previous task (below), beside the drain of its stores.
       const int cur = k & 1;
       if (k == 0) {
         if (wave == 0) {
@@ -247,6 +279,29 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
           }
         }
       }
+      // ---- the late numbers of the previous sweep's task k+1: our last column of B_k and the corner of D_k
+      if (lead && wave == NW - 1) {
+        unsigned spins = 0;
+        bool ok = true;
+        while (__any(mail_empty(m_a) || (lane == 63 && mail_empty(m_b)))) {
+          if ((++spins & 63u) == 0u &&
+              (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            ok = false; break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          if (mail_empty(m_a)) m_a = ld_sc1(mail + ((lane < 63) ? lane + 1 : 64));
+          if (lane == 63 && mail_empty(m_b)) m_b = ld_sc1(mail);
+        }
+        if (!ok) { if (lane == 0) { give_up(); s_ok = 0; } }
+        else {
+          bk[CW - 1] = (lane < L1 && SB - 1 < L) ? m_a : 0.0;
+          if (lane == 63 && SB - 1 < L) dl[CW - 1] = m_b;
+          // the line is empty again for the task that uses it four sweeps on (drained before this task completes)
+          const double e = __longlong_as_double((long long)kMailEmpty);
+          st_sc1(mail + ((lane < 63) ? lane + 1 : 64), e);
+          if (lane == 63) st_sc1(mail, e);
+        }
+      }
       // ---- D_k as a full symmetric image
 #pragma unroll
       for (int j = 0; j < CW; ++j) {
@@ -254,6 +309,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         if (c <= lane) { s_D[lane * DLD + c] = dl[j]; s_D[c * DLD + lane] = dl[j]; }
       }
       __syncthreads();                                                       // #2
+      if (!s_ok) return;
       if (prof) tc3 = clock64();
       // ---- partial sums of p = D v and q = B_k v
       double dd[CW];
@@ -263,7 +319,11 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         for (int j = 0; j < CW; ++j) { dd[j] = s_D[lane * DLD + c0w + j]; pp += dd[j] * vc[j]; qq += bk[j] * vc[j]; }
         s_p[wave][lane] = pp; s_q[wave][lane] = qq;
       }
+      // the stores of phase (b) were issued a good while ago: B_{k-1} is in memory once every wave has seen
+      // its own complete, and the follower may start on it
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                                       // #3
+      if (t == 0) __hip_atomic_store(&p.progA[s], (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (prof) tc4 = clock64();
       // ---- (c) D_k <- H D_k H
       double psum = 0.0;
@@ -281,7 +341,16 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         for (int w = 0; w < NW; ++w) pc += s_p[w][c];
         const double w_c = tau * pc + alpha * vc[j];
         dd[j] -= v_r * w_c + w_r * vc[j];
-        if (c <= lane && lane < L) st_sc1(AB + (unsigned)((lane - c) + (i0 + c) * LDAB), dd[j]);
+        if (c == 0 && k > 0 && has_follower)               // column 0 of D_k: the follower's late numbers (entries >= L are 0)
+          st_sc1(p.mail + ((size_t)(s & 3) * p.kmax + k) * MAILW + lane, dd[j]);
+        if (c <= lane && lane < L) {
+          if (c == SB - 1 && lead) {
+            // the corner: the previous sweep's task k+1 stores this entry too (as entry (0,0) of its diagonal
+            // block); ours must come second
+            if (!wait_word(&p.prog[s - 1], (unsigned)(k + 2))) give_up();
+          }
+          st_sc1(AB + (unsigned)((lane - c) + (i0 + c) * LDAB), dd[j]);
+        }
       }
       // ---- (d) B_k <- B_k H (rows I_{k+1}, columns I_k); carried to the next task in registers
       if (L1 > 0) {
@@ -305,16 +374,22 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         p.prof[4] += tc5 - tc4; p.prof[6] += 1;
       }
       // ---- the reflector of task k+1 from the first column of the new B_k, which goes to memory at once as
-      // (beta, 0, ..., 0): it holds the one entry the next sweep needs from task k+1 (see above)
-      if (k + 1 < K) {
-        if (wave == 0) {
+      // (beta, 0, ..., 0) and, beta, into the mailbox (in the last task: entry (0,0) of the final B_k, or nothing)
+      if (wave == 0) {
+        double b00 = (L1 > 0) ? bp[0] : 0.0;               // lane 0: entry (0,0) of the new B_k
+        if (k + 1 < K) {
           const int i0n = i0 + SB;
           const int Ln = (n - i0n < SB) ? n - i0n : SB;
           const double beta = make_reflector(bp[0], lane, Ln, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
           bp[0] = (lane == 0) ? beta : 0.0;
+          b00 = beta;
           if (lane < Ln) st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), bp[0]);
         }
-        // tell the follower (the last task is told below)
+        if (lane == 0 && k > 0 && has_follower)
+          st_sc1(p.mail + ((size_t)(s & 3) * p.kmax + k) * MAILW + 64, b00);
+      }
+      if (k + 1 < K) {
+        // the task is complete once its stores are (the last task is told below)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) __hip_atomic_store(&p.prog[s], (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -323,7 +398,10 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
     // ---- the last task of the sweep: publish once its stores have completed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) __hip_atomic_store(&p.prog[s], (unsigned)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) {
+      __hip_atomic_store(&p.prog[s], (unsigned)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&p.progA[s], kDoneAll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -654,7 +732,7 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Layout {
   int nsweeps, nS, kmax, ldt;
-  size_t off_ab, off_tau, off_prog, off_ctl, off_T, off_qprog, total;
+  size_t off_ab, off_tau, off_prog, off_progA, off_mail, off_ctl, off_T, off_qprog, total;
   explicit Layout(int n) {
     nsweeps = n > 2 ? n - 2 : 0;
     nS = ceil_div((nsweeps > 0 ? nsweeps : 1) + 1, QG);   // block S = sweeps 32 S - 1 .. 32 S + 30
@@ -664,6 +742,8 @@ struct Layout {
     off_ab = o; o += al256((size_t)LDAB * (n + 1) * 8);
     off_tau = o; o += al256((size_t)ldt * (nsweeps + 1) * 8);
     off_prog = o; o += al256((size_t)(nsweeps + 1) * 4);
+    off_progA = o; o += al256((size_t)(nsweeps + 1) * 4);
+    off_mail = o; o += al256((size_t)4 * (kmax + 1) * MAILW * 8);
     off_ctl = o; o += 256;
     off_T = o; o += al256((size_t)nS * kmax * QREC * 8);
     off_qprog = o; o += al256((size_t)nS * ceil_div(n, QNC) * 4);
@@ -684,17 +764,20 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
   const Layout L(n);
   char *w = (char *)work;
   double *AB = (double *)(w + L.off_ab), *tau2 = (double *)(w + L.off_tau);
-  unsigned *prog = (unsigned *)(w + L.off_prog), *ctl = (unsigned *)(w + L.off_ctl);
+  unsigned *prog = (unsigned *)(w + L.off_prog), *progA = (unsigned *)(w + L.off_progA), *ctl = (unsigned *)(w + L.off_ctl);
+  double *mail = (double *)(w + L.off_mail);
+  const int nmail = 4 * (L.kmax + 1) * MAILW;
   hipLaunchKernelGGL(pack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB);
   (void)hipMemsetAsync(tau2, 0, (size_t)L.ldt * (L.nsweeps + 1) * 8, s);
   (void)hipMemsetAsync(prog, 0, (size_t)(L.nsweeps + 1) * 4 + 0, s);
+  (void)hipMemsetAsync(progA, 0, (size_t)(L.nsweeps + 1) * 4 + 0, s);
+  hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(nmail, 256)), dim3(256), 0, s, mail, nmail);
   (void)hipMemsetAsync(ctl, 0, 256, s);
   if (L.nsweeps > 0) {
-    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, 0, nullptr};
+    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, progA, ctl, mail, L.kmax + 1, nullptr};
     if (getenv("EK_SB2ST_PROF")) { c.prof = (long long *)(ctl + 16); }
-    if (const char *ev = getenv("EK_SB2ST_EXTRA")) { c.extra = atoi(ev); if (c.extra < 0) c.extra = 0; }
-    // enough workgroups for the pipeline (a sweep can start two tasks behind its predecessor)
-    int nwg = n / ((2 + c.extra) * SB) + 8;
+    // enough workgroups for the pipeline (a sweep starts about one task and a half behind its predecessor)
+    int nwg = n / 96 + 8;
     if (nwg > 256) nwg = 256;
     if (nwg > L.nsweeps) nwg = L.nsweeps;
     if (const char *ev = getenv("EK_SB2ST_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
