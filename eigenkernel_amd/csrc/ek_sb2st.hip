@@ -104,7 +104,6 @@ struct ChaseArgs {
   double *V2; int ldv2;
   double *tau2; int ldt;
   unsigned *prog;        // [nsweeps] tasks completed per sweep
-  unsigned *progA;       // [nsweeps] tasks whose phase (b) has drained per sweep (kDoneAll when the sweep is finished)
   unsigned *ctl;         // [0] ticket, [1] abort
   double *mail; int kmax;   // mailbox lines [4][kmax][MAILW]
   long long *prof;       // optional: [0..5] shader cycles per phase of a task summed over workgroup 0's tasks, [6] tasks
@@ -134,27 +133,25 @@ __device__ __forceinline__ double make_reflector(double x, int lane, int L, int 
 }
 
 // Dependencies between sweeps.  Task (s, k) works on rows and columns s+1+64k .. s+64(k+2) of the lower
-// band.  The only entry in that range which task (s-1, k+2) of the previous sweep changes is the corner
-// A(s+64(k+2), s+64(k+1)) -- entry (0,0) of ITS block B_{k+1}, which the reflector of that task turns
-// into beta, a number already known when the reflector is made at the end of task (s-1, k+1).  So the
-// maker stores column 0 of the new block, (beta, 0, ..., 0), right then, the later store of the block
-// leaves column 0 alone, and task (s, k) depends on task (s-1, k+1) only: sweeps follow each other TWO
-// tasks apart, not three (the pipeline is latency-bound: its length is the number of sweeps times that
-// distance).
+// band.  The textbook rule is "task (s, k) after task (s-1, k+2)"; what is really needed is less:
+//  * of task (s-1, k+2): one entry, the corner A(s+64(k+2), s+64(k+1)) -- entry (0,0) of ITS block
+//    B_{k+1}, which its reflector turns into beta, a number known when that reflector is made, at the end
+//    of task (s-1, k+1);
+//  * of task (s-1, k+1): column 0 of ITS diagonal block (our last column of B_k and the corner of D_k) and
+//    that beta -- 65 numbers, and only when our own block images are being put together;
+//  * everything else is final when task (s-1, k) ends, PROVIDED a task finishes the block it hands on:
+//    so a task applies the NEXT reflector from the left to the new B_k at its own end (it holds both),
+//    instead of the next task doing that first.
+// Hence: task (s, k) starts when task (s-1, k) is complete (one progress word per sweep); the 65 late
+// numbers of task (s-1, k+1) come through a MAILBOX line its last wave polls directly (an "empty" bit
+// pattern marks a slot; the reader empties it again; four lines per task index in rotation) -- data that
+// is its own flag costs no drain, no barrier and no second round trip.  Sweeps follow each other ONE task
+// apart (plus the hand-off), not three; the pipeline is latency-bound and its length is the number of
+// sweeps times that distance.  The one store of a task that lands on an entry the previous sweep's task
+// k+1 also stores (the corner of D_k) waits for that task's completion word.
 //
-// Of task (s-1, k+1) in turn, task (s, k) needs early only what its phase (b) leaves (the block B_k of
-// that sweep); from its later phases it needs 65 numbers -- column 0 of ITS diagonal block (our last
-// column of B_k and the corner of D_k) and that beta --, and it needs them only when its own phase (b)
-// is over.  So a sweep publishes two things per task: a progress word after phase (b) has drained
-// (progA), on which the follower starts, and those 65 numbers through a MAILBOX line the follower's last
-// wave polls directly (an "empty" bit pattern marks a slot; the reader empties it again; four lines per
-// task index in rotation) -- data that is its own flag costs no drain, no barrier and no second round
-// trip.  The completion word (prog) remains for what must not be overtaken: the one store of a task that
-// lands on an entry the previous sweep's task also stores (the corner of D_k).
-//
-// Per task the workgroup synchronises three times.  NW waves per workgroup, each with CW = 64 / NW
+// Per task the workgroup synchronises four times.  NW waves per workgroup, each with CW = 64 / NW
 // columns of a block (row per lane).
-constexpr unsigned kDoneAll = 0x7fffffffu;
 constexpr int MAILW = 72;                              // doubles per mailbox line: 64 (column 0 of D_k) + beta + padding
 constexpr unsigned long long kMailEmpty = 0x7ff8dead0000beefull;   // a NaN no computation produces
 
@@ -202,9 +199,6 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
     const int K = (n - 3 - s) / SB + 1;
     const int Kprev = (s > 0) ? (n - 2 - s) / SB + 1 : 0;
     const bool has_follower = s + 1 < p.nsweeps;
-    double bp[CW], dl[CW], bk[CW];
-#pragma unroll
-    for (int j = 0; j < CW; ++j) { bp[j] = 0.0; dl[j] = 0.0; bk[j] = 0.0; }
     for (int k = 0; k < K; ++k) {
       const int i0 = s + 1 + k * SB;                       // first index of I_k
       const int L = (n - i0 < SB) ? n - i0 : SB;           // its length (>= 2)
@@ -215,12 +209,13 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       // the previous sweep's task k+1, if it has one: its late numbers come through the mailbox
       const bool lead = s > 0 && k + 1 < Kprev;
       double *mail = p.mail + ((size_t)((s - 1) & 3) * p.kmax + (k + 1)) * MAILW;
-      // ---- gate: phase (b) of that task has drained (or the previous sweep is finished); fetch D_k and B_k
+      // ---- gate: the previous sweep's task k is complete (or that sweep is finished); fetch D_k and B_k
       if (t == 0 && s > 0) {
-        if (!wait_word(&p.progA[s - 1], lead ? (unsigned)(k + 2) : kDoneAll)) { give_up(); s_ok = 0; }
+        if (!wait_word(&p.prog[s - 1], (unsigned)(k + 1 < Kprev ? k + 1 : Kprev))) { give_up(); s_ok = 0; }
       }
       __syncthreads();
       if (!s_ok) return;
+      double dl[CW], bk[CW];
 #pragma unroll
       for (int j = 0; j < CW; ++j) {
         const int c = c0w + j;
@@ -236,7 +231,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       }
       if (prof) tc1 = clock64();
       // ---- (a) the reflector of task 0: x = A(I_0, s) (final: the previous sweep's task 0 is complete).  Those of
-      // the later tasks were made at the end of the previous task (below), beside the drain of its stores.
+      // the later tasks were made at the end of the previous task (below).
       const int cur = k & 1;
       if (k == 0) {
         if (wave == 0) {
@@ -246,39 +241,12 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         }
         __syncthreads();                                                     // #1 (first task only)
       }
-
       if (prof) tc2 = clock64();
       const double tau = s_tau[cur];
       const double v_r = s_v[cur][lane];
       double vc[CW];
 #pragma unroll
       for (int j = 0; j < CW; ++j) vc[j] = s_v[cur][c0w + j];
-      // ---- (b) B_{k-1} <- H B_{k-1} (rows I_k, columns I_{k-1}), then it is final for this sweep
-      if (k > 0) {
-        double *st = s_t[wave];
-#pragma unroll
-        for (int j = 0; j < CW; ++j) st[j * 65 + lane] = v_r * bp[j];
-        wave_sync();
-        {
-          const int j = lane / LPC, q = lane % LPC;
-          const double *src = st + j * 65 + CW * q;
-          double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-          for (int l = 0; l < CW; l += 2) { a0 += src[l]; a1 += src[l + 1]; }
-          const double tot = group_sum<LPC>(a0 + a1);
-          if (q == 0) s_z[c0w + j] = tot;
-        }
-        wave_sync();
-        const int ip = i0 - SB;
-#pragma unroll
-        for (int j = 0; j < CW; ++j) {
-          const int c = c0w + j;
-          if (c > 0) {           // column 0 is (beta, 0, ..., 0) and in memory since the reflector was made
-            bp[j] -= tau * v_r * s_z[c];
-            if (lane < L) st_sc1(AB + (unsigned)((SB + lane - c) + (ip + c) * LDAB), bp[j]);
-          }
-        }
-      }
       // ---- the late numbers of the previous sweep's task k+1: our last column of B_k and the corner of D_k
       if (lead && wave == NW - 1) {
         unsigned spins = 0;
@@ -319,11 +287,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         for (int j = 0; j < CW; ++j) { dd[j] = s_D[lane * DLD + c0w + j]; pp += dd[j] * vc[j]; qq += bk[j] * vc[j]; }
         s_p[wave][lane] = pp; s_q[wave][lane] = qq;
       }
-      // the stores of phase (b) were issued a good while ago: B_{k-1} is in memory once every wave has seen
-      // its own complete, and the follower may start on it
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                                       // #3
-      if (t == 0) __hip_atomic_store(&p.progA[s], (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (prof) tc4 = clock64();
       // ---- (c) D_k <- H D_k H
       double psum = 0.0;
@@ -352,7 +316,10 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
           st_sc1(AB + (unsigned)((lane - c) + (i0 + c) * LDAB), dd[j]);
         }
       }
-      // ---- (d) B_k <- B_k H (rows I_{k+1}, columns I_k); carried to the next task in registers
+      // ---- (d) B_k <- B_k H (rows I_{k+1}, columns I_k)
+      double bp[CW];
+#pragma unroll
+      for (int j = 0; j < CW; ++j) bp[j] = 0.0;
       if (L1 > 0) {
         double qsum = 0.0;
 #pragma unroll
@@ -360,7 +327,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         const double q_r = tau * qsum;
 #pragma unroll
         for (int j = 0; j < CW; ++j) bp[j] = bk[j] - q_r * vc[j];
-        if (k == K - 1) {                                  // no further task in this sweep: store it now
+        if (k == K - 1) {                                  // no further task in this sweep: the block is final
 #pragma unroll
           for (int j = 0; j < CW; ++j) {
             const int c = c0w + j;
@@ -379,16 +346,40 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         double b00 = (L1 > 0) ? bp[0] : 0.0;               // lane 0: entry (0,0) of the new B_k
         if (k + 1 < K) {
           const int i0n = i0 + SB;
-          const int Ln = (n - i0n < SB) ? n - i0n : SB;
-          const double beta = make_reflector(bp[0], lane, Ln, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
-          bp[0] = (lane == 0) ? beta : 0.0;
+          const double beta = make_reflector(bp[0], lane, L1, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
           b00 = beta;
-          if (lane < Ln) st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), bp[0]);
+          if (lane < L1) st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), (lane == 0) ? beta : 0.0);
         }
         if (lane == 0 && k > 0 && has_follower)
           st_sc1(p.mail + ((size_t)(s & 3) * p.kmax + k) * MAILW + 64, b00);
       }
       if (k + 1 < K) {
+        __syncthreads();                                                     // #4: the new reflector is in LDS
+        // ---- (b) B_k <- H' B_k with the NEW reflector (rows I_{k+1}): the block is final for this sweep
+        const double tau_n = s_tau[cur ^ 1];
+        const double vn_r = s_v[cur ^ 1][lane];
+        double *st = s_t[wave];
+#pragma unroll
+        for (int j = 0; j < CW; ++j) st[j * 65 + lane] = vn_r * bp[j];
+        wave_sync();
+        {
+          const int j = lane / LPC, q = lane % LPC;
+          const double *src = st + j * 65 + CW * q;
+          double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+          for (int l = 0; l < CW; l += 2) { a0 += src[l]; a1 += src[l + 1]; }
+          const double tot = group_sum<LPC>(a0 + a1);
+          if (q == 0) s_z[c0w + j] = tot;
+        }
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+          const int c = c0w + j;
+          if (c > 0) {           // column 0 is (beta, 0, ..., 0) and went to memory with the reflector
+            const double b = bp[j] - tau_n * vn_r * s_z[c];
+            if (lane < L1) st_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB), b);
+          }
+        }
         // the task is complete once its stores are (the last task is told below)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -398,10 +389,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
     // ---- the last task of the sweep: publish once its stores have completed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) {
-      __hip_atomic_store(&p.prog[s], (unsigned)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&p.progA[s], kDoneAll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (t == 0) __hip_atomic_store(&p.prog[s], (unsigned)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -732,7 +720,7 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Layout {
   int nsweeps, nS, kmax, ldt;
-  size_t off_ab, off_tau, off_prog, off_progA, off_mail, off_ctl, off_T, off_qprog, total;
+  size_t off_ab, off_tau, off_prog, off_mail, off_ctl, off_T, off_qprog, total;
   explicit Layout(int n) {
     nsweeps = n > 2 ? n - 2 : 0;
     nS = ceil_div((nsweeps > 0 ? nsweeps : 1) + 1, QG);   // block S = sweeps 32 S - 1 .. 32 S + 30
@@ -742,7 +730,6 @@ struct Layout {
     off_ab = o; o += al256((size_t)LDAB * (n + 1) * 8);
     off_tau = o; o += al256((size_t)ldt * (nsweeps + 1) * 8);
     off_prog = o; o += al256((size_t)(nsweeps + 1) * 4);
-    off_progA = o; o += al256((size_t)(nsweeps + 1) * 4);
     off_mail = o; o += al256((size_t)4 * (kmax + 1) * MAILW * 8);
     off_ctl = o; o += 256;
     off_T = o; o += al256((size_t)nS * kmax * QREC * 8);
@@ -764,20 +751,19 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
   const Layout L(n);
   char *w = (char *)work;
   double *AB = (double *)(w + L.off_ab), *tau2 = (double *)(w + L.off_tau);
-  unsigned *prog = (unsigned *)(w + L.off_prog), *progA = (unsigned *)(w + L.off_progA), *ctl = (unsigned *)(w + L.off_ctl);
+  unsigned *prog = (unsigned *)(w + L.off_prog), *ctl = (unsigned *)(w + L.off_ctl);
   double *mail = (double *)(w + L.off_mail);
   const int nmail = 4 * (L.kmax + 1) * MAILW;
   hipLaunchKernelGGL(pack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB);
   (void)hipMemsetAsync(tau2, 0, (size_t)L.ldt * (L.nsweeps + 1) * 8, s);
   (void)hipMemsetAsync(prog, 0, (size_t)(L.nsweeps + 1) * 4 + 0, s);
-  (void)hipMemsetAsync(progA, 0, (size_t)(L.nsweeps + 1) * 4 + 0, s);
   hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(nmail, 256)), dim3(256), 0, s, mail, nmail);
   (void)hipMemsetAsync(ctl, 0, 256, s);
   if (L.nsweeps > 0) {
-    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, progA, ctl, mail, L.kmax + 1, nullptr};
+    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, mail, L.kmax + 1, nullptr};
     if (getenv("EK_SB2ST_PROF")) { c.prof = (long long *)(ctl + 16); }
-    // enough workgroups for the pipeline (a sweep starts about one task and a half behind its predecessor)
-    int nwg = n / 96 + 8;
+    // enough workgroups for the pipeline (a sweep starts one task behind its predecessor)
+    int nwg = n / SB + 8;
     if (nwg > 256) nwg = 256;
     if (nwg > L.nsweeps) nwg = L.nsweeps;
     if (const char *ev = getenv("EK_SB2ST_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
