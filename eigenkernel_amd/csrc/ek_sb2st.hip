@@ -289,6 +289,24 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       }
       __syncthreads();                                                       // #3
       if (prof) tc4 = clock64();
+      // ---- the reflector of task k+1 first: it needs column 0 of the new B_k = B_k H only (first wave), and the
+      // next sweep is waiting for its beta.  The column goes to memory at once as (beta, 0, ..., 0), beta into
+      // the mailbox (in the last task: entry (0,0) of the final B_k, or nothing).
+      if (wave == 0) {
+        double qs = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) qs += s_q[w][lane];
+        const double col0 = (L1 > 0) ? bk[0] - tau * qs * vc[0] : 0.0;
+        double b00 = col0;                                 // lane 0: entry (0,0) of the new B_k
+        if (k + 1 < K) {
+          const int i0n = i0 + SB;
+          const double beta = make_reflector(col0, lane, L1, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
+          b00 = beta;
+          if (lane < L1) st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), (lane == 0) ? beta : 0.0);
+        }
+        if (lane == 0 && k > 0 && has_follower)
+          st_sc1(p.mail + ((size_t)(s & 3) * p.kmax + k) * MAILW + 64, b00);
+      }
       // ---- (c) D_k <- H D_k H
       double psum = 0.0;
 #pragma unroll
@@ -339,19 +357,6 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         const long long tc5 = clock64();
         p.prof[0] += tc1 - tc0; p.prof[1] += tc2 - tc1; p.prof[2] += tc3 - tc2; p.prof[3] += tc4 - tc3;
         p.prof[4] += tc5 - tc4; p.prof[6] += 1;
-      }
-      // ---- the reflector of task k+1 from the first column of the new B_k, which goes to memory at once as
-      // (beta, 0, ..., 0) and, beta, into the mailbox (in the last task: entry (0,0) of the final B_k, or nothing)
-      if (wave == 0) {
-        double b00 = (L1 > 0) ? bp[0] : 0.0;               // lane 0: entry (0,0) of the new B_k
-        if (k + 1 < K) {
-          const int i0n = i0 + SB;
-          const double beta = make_reflector(bp[0], lane, L1, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
-          b00 = beta;
-          if (lane < L1) st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), (lane == 0) ? beta : 0.0);
-        }
-        if (lane == 0 && k > 0 && has_follower)
-          st_sc1(p.mail + ((size_t)(s & 3) * p.kmax + k) * MAILW + 64, b00);
       }
       if (k + 1 < K) {
         __syncthreads();                                                     // #4: the new reflector is in LDS
