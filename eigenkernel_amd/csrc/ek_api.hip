@@ -277,13 +277,16 @@ constexpr int kPotrfRlMin = 1024;
 // cores, band -> tridiagonal by bulge chasing; ek_sy2sb.hip, ek_sb2st.hip) instead of the one-stage
 // Householder reduction.  EK_HIP_TWO_STAGE_MIN overrides (0 = never); ek_hip_debug_set_two_stage too.
 // Measured with tools/crossover.py (standard problem, full spectrum, one-stage / two-stage seconds):
-// 4096: 0.0915 / 0.0946, 6144: 0.1765 / 0.1626, 8192: 0.3054 / 0.2528.
+// 512: 0.0099 / 0.0090, 1024: 0.0190 / 0.0174, 2048: 0.0388 / 0.0357, 4096: 0.0914 / 0.0799,
+// 8192: 0.3065 / 0.2193 -- the two-stage form is ahead at every order; below 2048 the difference is a
+// millisecond or two and the whole-path call keeps the one-stage form, whose by-products (PDSYTRD's
+// reflectors in A) are what a caller of the reference finds there.
 int g_two_stage_min = -1;
 int two_stage_min() {
   if (g_two_stage_min >= 0) return g_two_stage_min;
   static int env = -2;
   if (env == -2) { const char *e = getenv("EK_HIP_TWO_STAGE_MIN"); env = e ? atoi(e) : -1; }
-  return env >= 0 ? env : 5120;
+  return env >= 0 ? env : 2048;
 }
 
 // From how many ranks on the Cholesky factor and the reduction to standard form are distributed
@@ -1712,20 +1715,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     EK_HIP_CHECK(hipMemsetAsync(wV2, 0, (size_t)ld * ld * 8, s));
     EK_HIP_CHECK(hipMemsetAsync(dt1, 0, (size_t)ld * 8, s));
     sy2sb_lower(s, g_ctx.stream2, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
-    // The T factors of the first stage's block reflectors (Gram matrices of the reflector blocks: 26 ms of
-    // skinny GEMMs at N = 16384) need nothing but those reflectors: second stream, beside the bulge chasing,
-    // a latency-bound pipeline on half of the CUs.
-    static hipEvent_t evP0 = nullptr, evP1 = nullptr;
-    if (!evP0) {
-      EK_HIP_CHECK(hipEventCreateWithFlags(&evP0, hipEventDisableTiming));
-      EK_HIP_CHECK(hipEventCreateWithFlags(&evP1, hipEventDisableTiming));
-    }
-    EK_HIP_CHECK(hipEventRecord(evP0, s));
-    EK_HIP_CHECK(hipStreamWaitEvent(g_ctx.stream2, evP0, 0));
-    ormtr_prepare(g_ctx.stream2, n, wV, ld, dt1, q1prep);
-    EK_HIP_CHECK(hipEventRecord(evP1, g_ctx.stream2));
     sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st);
-    EK_HIP_CHECK(hipStreamWaitEvent(s, evP1, 0));
     int flag = 0;
     EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
     EK_HIP_CHECK(hipStreamSynchronize(s));
@@ -1749,6 +1739,10 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   double *zc = wZ;
   if (two_stage_done) {
     sb2st_apply_q2(s, n, nc_loc, wV2, ld, zc, ld, g_ctx.d_info + 2, work_sb2st);
+    // (the T factors of the block reflectors do not depend on Z; forming them on the second stream beside the
+    // bulge chasing was measured: the skinny GEMMs take CUs and issue slots from the latency-bound pipeline,
+    // which loses 11 ms to gain 6)
+    ormtr_prepare(s, n, wV, ld, dt1, q1prep);
     ormtr_apply(s, n, nc_loc, wV, ld, q1prep, zc, ld, work);
   } else {
     ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work);

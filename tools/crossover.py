@@ -27,7 +27,8 @@ def run(n, gep, force):
     for p in bufs: lib.ek_hip_free(p)
     lib.ek_hip_finalize()
     return best, st
-for n in (2048, 3072, 4096, 6144, 8192):
+import sys as _s
+for n in ([int(a) for a in _s.argv[1:]] or [2048, 3072, 4096, 6144, 8192]):
     for gep in (False,):
         a, sa = run(n, gep, 0)
         b, sb = run(n, gep, 1)
