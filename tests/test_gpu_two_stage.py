@@ -106,6 +106,33 @@ def test_bulge_chasing_is_bitwise_reproducible(hip):
         assert f == 0 and np.array_equal(d0, d1) and np.array_equal(e0, e1)
 
 
+@pytest.mark.parametrize("n", [130, 777, 1500])
+def test_bulge_chasing_does_not_depend_on_the_width_of_the_pipeline(hip, n):
+    """A sweep starts as soon as the previous sweep's task of the same index is complete and takes the 65 late
+    numbers of the task after it from a mailbox line (ek_sb2st.hip): with 3 workgroups the pipeline is almost
+    serial, with 7 or 40 its sweeps overtake each other's stores in other orders than at full width.  d, e and
+    the applied Q2 must be the same bits every time (tools/chase_stress.py is the longer form)."""
+    Bd = _random_band(n, n)
+    Z0 = np.eye(n)[:, ::max(n // 16, 1)][:, :16].copy()
+    ref = None
+    try:
+        for wgs in (None, 3, 7, 40, None):
+            if wgs is None:
+                os.environ.pop("EK_SB2ST_WGS", None)
+            else:
+                os.environ["EK_SB2ST_WGS"] = str(wgs)
+            d, e, Z, f = hip.sb2st(Bd, Z0)
+            assert f == 0
+            if ref is None:
+                ref = (d, e, Z)
+                T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+                assert np.abs(np.linalg.eigvalsh(Bd) - np.linalg.eigvalsh(T)).max() <= 8 * n * EPS * np.abs(d).max()
+            else:
+                assert np.array_equal(ref[0], d) and np.array_equal(ref[1], e) and np.array_equal(ref[2], Z)
+    finally:
+        os.environ.pop("EK_SB2ST_WGS", None)
+
+
 @pytest.fixture()
 def forced_two_stage(hip):
     hip.set_two_stage(100)
