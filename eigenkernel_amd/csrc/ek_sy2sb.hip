@@ -354,16 +354,17 @@ struct SymmArgs {
   double *Ypart; int ldy; long long sY; // per split: m x 64
   int T, tiles_per_split;
 };
-constexpr int BK = 32, MC_LD = 128 + 16, KC_LD = BK + 1;
+constexpr int BK = 32, MC_LD = 128 + 16, KC_LD = BK + 2;   // K-contiguous images: 34 keeps (x, k) and (x + 1, k - 1) in different banks and row pairs 16-byte aligned
 constexpr int A_TILE = (BK * MC_LD > 128 * KC_LD) ? BK * MC_LD : 128 * KC_LD;
-constexpr int V_LD = BK + 1;            // V slab: 64 x 32, K-contiguous image s[n][33]
+constexpr int V_LD = BK + 2;            // V slab: 64 x 32, K-contiguous image s[n][34]
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 // K is walked in slabs of 32 (one barrier pair per slab); slabs that lie completely inside the matrix
 // and off the diagonal tile are fetched as 16-byte pairs without predicates (A22 starts on a multiple of
 // 64 rows and the leading dimensions are even, so the pairs are aligned), the others element by element.
 __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
-  __shared__ double sA[A_TILE], sV[SB * V_LD];
+  __shared__ __attribute__((aligned(16))) double sA[A_TILE];
+  __shared__ __attribute__((aligned(16))) double sV[SB * V_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int rb = blockIdx.x, ks = blockIdx.y;
   const int kt0 = ks * p.tiles_per_split;
@@ -437,11 +438,11 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if (kc) { const int k = 2 * (t & 15), x = (t >> 4) + 16 * i; sA[x * KC_LD + k] = ra[i].x; sA[x * KC_LD + k + 1] = ra[i].y; }
+        if (kc) { const int k = 2 * (t & 15), x = (t >> 4) + 16 * i; *reinterpret_cast<double2_t *>(&sA[x * KC_LD + k]) = ra[i]; }
         else    { const int x = 2 * (t & 63), k = (t >> 6) + 4 * i; *reinterpret_cast<double2_t *>(&sA[k * MC_LD + x]) = ra[i]; }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int k = 2 * (t & 15), nn = (t >> 4) + 16 * i; sV[nn * V_LD + k] = rv[i].x; sV[nn * V_LD + k + 1] = rv[i].y; }
+      for (int i = 0; i < 4; ++i) { const int k = 2 * (t & 15), nn = (t >> 4) + 16 * i; *reinterpret_cast<double2_t *>(&sV[nn * V_LD + k]) = rv[i]; }
       __syncthreads();
       // next slab (possibly of the next tile) in flight during the MFMAs
       int nkt = kt, nk0 = k0 + BK;
