@@ -1546,14 +1546,16 @@ int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int l
 // Whole path on device-resident data.
 namespace {
 
-struct StageTimer {
+struct StageTimer {      // events are released when the timer goes out of scope, whichever way the call ends
   hipEvent_t ev[EK_HIP_N_STAGES + 1];
+  int made = 0;
   bool on = false;
   int init() {
-    for (auto &e : ev) EK_HIP_CHECK(hipEventCreate(&e));
+    for (auto &e : ev) { EK_HIP_CHECK(hipEventCreate(&e)); ++made; }
     on = true; return 0;
   }
-  void destroy() { if (on) for (auto &e : ev) (void)hipEventDestroy(e); on = false; }
+  void destroy() { for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]); made = 0; on = false; }
+  ~StageTimer() { destroy(); }
 };
 
 // Runs the path on user device arrays dA, dB, dZ (column-major, any ld >= n) by way of padded
