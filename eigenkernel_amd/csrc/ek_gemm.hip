@@ -75,14 +75,57 @@ __device__ __forceinline__ void store_slab(const double (&r)[8], double *s, int 
   }
 }
 
+// The same slab in PAIRS (the VEC variant of gemm_kernel: operands with even leading dimension and 16-byte
+// aligned base): MC: pair = rows (2 xp, 2 xp + 1) at one k, thread -> xp = idx & 63, k = idx >> 6;
+// KC: pair = k indices (2 kp, 2 kp + 1) of one row, thread -> kp = idx & 7, x = idx >> 3 (idx = t + 256 i).
+// Interior slabs are fetched as 16-byte loads without predicates, edge slabs element by element into the
+// same registers.
+typedef double double2g_t __attribute__((ext_vector_type(2)));
+template <bool KCONTIG>
+__device__ __forceinline__ void load_slab_v(double (&r)[8], const double *__restrict__ P, int ld, int x0, int X,
+                                            int k0, int K, int t) {
+  if (x0 + BM <= X && k0 + BK <= K) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + 256 * i;
+      double2g_t v;
+      if (KCONTIG) v = *reinterpret_cast<const double2g_t *>(P + (size_t)(k0 + 2 * (idx & 7)) + (size_t)(x0 + (idx >> 3)) * ld);
+      else         v = *reinterpret_cast<const double2g_t *>(P + (size_t)(x0 + 2 * (idx & 63)) + (size_t)(k0 + (idx >> 6)) * ld);
+      r[2 * i] = v.x; r[2 * i + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + 256 * i;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gx = x0 + (KCONTIG ? (idx >> 3) : 2 * (idx & 63) + h);
+        const int gk = k0 + (KCONTIG ? 2 * (idx & 7) + h : (idx >> 6));
+        double v = 0.0;
+        if (gx < X && gk < K) v = KCONTIG ? P[(size_t)gk + (size_t)gx * ld] : P[(size_t)gx + (size_t)gk * ld];
+        r[2 * i + h] = v;
+      }
+    }
+  }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void store_slab_v(const double (&r)[8], double *s, int t) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 256 * i;
+    if (KCONTIG) { const int k = 2 * (idx & 7), x = idx >> 3; s[x * KC_LD + k] = r[2 * i]; s[x * KC_LD + k + 1] = r[2 * i + 1]; }
+    else { const int x = 2 * (idx & 63), k = idx >> 6; *reinterpret_cast<double2g_t *>(&s[k * MC_LD + x]) = (double2g_t){r[2 * i], r[2 * i + 1]}; }
+  }
+}
+
 template <bool KCONTIG>
 __device__ __forceinline__ double frag(const double *s, int x, int k) {
   return KCONTIG ? s[x * KC_LD + k] : s[k * MC_LD + x];
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
-  __shared__ double smem[2 * TILE_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double smem[2 * TILE_DOUBLES];
   double *sA = smem, *sB = smem + TILE_DOUBLES;
 
   // tile index: consecutive workgroups walk down M first (they share the B slab in L2)
@@ -115,17 +158,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   double ra[8], rb[8];
   // op(A) is M x K: not transposed -> M-contiguous (MC); transposed -> K-contiguous (KC)
   // op(B) is K x N: not transposed -> K-contiguous (KC); transposed -> N-contiguous (MC)
-  load_slab<TA>(ra, A, p.lda, m0, p.M, 0, p.K, t);
-  load_slab<!TB>(rb, B, p.ldb, n0, p.N, 0, p.K, t);
+  if (VEC) {
+    load_slab_v<TA>(ra, A, p.lda, m0, p.M, 0, p.K, t);
+    load_slab_v<!TB>(rb, B, p.ldb, n0, p.N, 0, p.K, t);
+  } else {
+    load_slab<TA>(ra, A, p.lda, m0, p.M, 0, p.K, t);
+    load_slab<!TB>(rb, B, p.ldb, n0, p.N, 0, p.K, t);
+  }
 
   for (int k0 = 0; k0 < p.K; k0 += BK) {
     __syncthreads();
-    store_slab<TA>(ra, sA, t);
-    store_slab<!TB>(rb, sB, t);
+    if (VEC) { store_slab_v<TA>(ra, sA, t); store_slab_v<!TB>(rb, sB, t); }
+    else { store_slab<TA>(ra, sA, t); store_slab<!TB>(rb, sB, t); }
     __syncthreads();
     if (k0 + BK < p.K) {
-      load_slab<TA>(ra, A, p.lda, m0, p.M, k0 + BK, p.K, t);
-      load_slab<!TB>(rb, B, p.ldb, n0, p.N, k0 + BK, p.K, t);
+      if (VEC) {
+        load_slab_v<TA>(ra, A, p.lda, m0, p.M, k0 + BK, p.K, t);
+        load_slab_v<!TB>(rb, B, p.ldb, n0, p.N, k0 + BK, p.K, t);
+      } else {
+        load_slab<TA>(ra, A, p.lda, m0, p.M, k0 + BK, p.K, t);
+        load_slab<!TB>(rb, B, p.ldb, n0, p.N, k0 + BK, p.K, t);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
@@ -547,10 +600,23 @@ void gemm(hipStream_t s, const GemmDesc &g) {
     else hipLaunchKernelGGL((gemm_kernel_w8<true, true>), grid, b8, 0, s, p);
     return;
   }
-  if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, p);
-  else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, p);
-  else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, s, p);
+  // 16-byte operand fetch: every slab start must be 16-byte aligned -- even leading dimensions, aligned bases,
+  // even batch strides, no per-batch offsets from device memory (EK_GEMM_VEC=0 turns the variant off)
+  static int vec_env = -1;
+  if (vec_env < 0) { const char *e = getenv("EK_GEMM_VEC"); vec_env = e ? atoi(e) : 1; }
+  const bool vec = vec_env && !g.d_offs && !g.d_dims && ((g.lda | g.ldb) & 1) == 0 &&
+                   ((((size_t)g.A | (size_t)g.B) & 15) == 0) && (g.batch == 1 || ((g.strideA | g.strideB) & 1) == 0);
+  if (vec) {
+    if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<false, false, true>), grid, block, 0, s, p);
+    else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel<false, true, true>), grid, block, 0, s, p);
+    else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<true, false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<true, true, true>), grid, block, 0, s, p);
+    return;
+  }
+  if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<false, false, false>), grid, block, 0, s, p);
+  else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel<false, true, false>), grid, block, 0, s, p);
+  else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<true, false, false>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_kernel<true, true, false>), grid, block, 0, s, p);
 }
 
 }  // namespace ek

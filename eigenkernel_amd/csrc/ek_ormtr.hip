@@ -162,7 +162,9 @@ void ormtr_apply(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
   for (int b = nblk - 1; b >= 0; --b) {
     const int c0 = b * KB;
     const int kb = (nrefl - c0 < KB) ? nrefl - c0 : KB;
-    const int row0 = c0 + 1, m = n - row0;
+    // rows from c0 on: row c0 of these reflectors is zero (reflector j starts below row j), and starting on an
+    // even row keeps the operands 16-byte aligned for the GEMM's paired loads
+    const int row0 = c0, m = n - row0;
     const double *Vb = V + (size_t)row0 + (size_t)c0 * ldv;
     double *Zb = Z + row0;
     gemm(s, true, false, kb, ncols, m, 1.0, Vb, ldv, Zb, ldz, 0.0, W1, KB);
