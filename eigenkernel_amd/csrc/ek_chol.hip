@@ -528,6 +528,7 @@ void potrf_lower_rl(hipStream_t s, hipStream_t s2, int n, double *B, int ldb, do
     GemmDesc g{};
     g.N = NB; g.K = nbk; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
     g.A = B; g.lda = ldb; g.B = B; g.ldb = ldb; g.C = B; g.ldc = ldb; g.lower_only = true;
+    g.even_offs = true;                                        // offsets are multiples of 128 rows and columns
     const long long *po = offs + (size_t)k * Ly.maxb * 3;
     const int *pd = dims + (size_t)k * Ly.maxb * 3;
     // block column k+1 first, so that its factorisation can start ...

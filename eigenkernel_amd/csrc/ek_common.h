@@ -42,6 +42,7 @@ struct GemmDesc {
                                        // CU: slower alone than the default, but leaves room for a second stream's work)
   const long long *d_offs = nullptr;   // device: per-batch element offsets {A, B, C} (added to strides)
   const int *d_dims = nullptr;         // device: per-batch {M, N, K}; host M, N, K are then upper bounds
+  bool even_offs = false;              // the caller's promise that every d_offs entry for A and B is even (16-byte loads stay aligned)
 };
 void gemm(hipStream_t s, const GemmDesc &g);
 

@@ -245,9 +245,47 @@ __device__ __forceinline__ void store_slab8(const double (&r)[4], double *s, int
   }
 }
 
-template <bool TA, bool TB>
+// paired form for the VEC variant (see load_slab_v): idx = t + 512 i, i < 2
+template <bool KCONTIG>
+__device__ __forceinline__ void load_slab8_v(double (&r)[4], const double *__restrict__ P, int ld, int x0, int X,
+                                             int k0, int K, int t) {
+  if (x0 + BM <= X && k0 + BK <= K) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = t + 512 * i;
+      double2g_t v;
+      if (KCONTIG) v = *reinterpret_cast<const double2g_t *>(P + (size_t)(k0 + 2 * (idx & 7)) + (size_t)(x0 + (idx >> 3)) * ld);
+      else         v = *reinterpret_cast<const double2g_t *>(P + (size_t)(x0 + 2 * (idx & 63)) + (size_t)(k0 + (idx >> 6)) * ld);
+      r[2 * i] = v.x; r[2 * i + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = t + 512 * i;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gx = x0 + (KCONTIG ? (idx >> 3) : 2 * (idx & 63) + h);
+        const int gk = k0 + (KCONTIG ? 2 * (idx & 7) + h : (idx >> 6));
+        double v = 0.0;
+        if (gx < X && gk < K) v = KCONTIG ? P[(size_t)gk + (size_t)gx * ld] : P[(size_t)gx + (size_t)gk * ld];
+        r[2 * i + h] = v;
+      }
+    }
+  }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void store_slab8_v(const double (&r)[4], double *s, int t) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + 512 * i;
+    if (KCONTIG) { const int k = 2 * (idx & 7), x = idx >> 3; s[x * KC_LD + k] = r[2 * i]; s[x * KC_LD + k + 1] = r[2 * i + 1]; }
+    else { const int x = 2 * (idx & 63), k = idx >> 6; *reinterpret_cast<double2g_t *>(&s[k * MC_LD + x]) = (double2g_t){r[2 * i], r[2 * i + 1]}; }
+  }
+}
+
+template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(512, 4) void gemm_kernel_w8(GemmArgs p) {
-  __shared__ double smem[2 * TILE_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double smem[2 * TILE_DOUBLES];
   double *sA = smem, *sB = smem + TILE_DOUBLES;
   const int tile = blockIdx.x;
   const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
@@ -272,16 +310,26 @@ __global__ __launch_bounds__(512, 4) void gemm_kernel_w8(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   double ra0[4], rb0[4];
-  load_slab8<TA>(ra0, A, p.lda, m0, p.M, 0, p.K, t);
-  load_slab8<!TB>(rb0, B, p.ldb, n0, p.N, 0, p.K, t);
+  if (VEC) {
+    load_slab8_v<TA>(ra0, A, p.lda, m0, p.M, 0, p.K, t);
+    load_slab8_v<!TB>(rb0, B, p.ldb, n0, p.N, 0, p.K, t);
+  } else {
+    load_slab8<TA>(ra0, A, p.lda, m0, p.M, 0, p.K, t);
+    load_slab8<!TB>(rb0, B, p.ldb, n0, p.N, 0, p.K, t);
+  }
   for (int k0 = 0; k0 < p.K; k0 += BK) {
     __syncthreads();
-    store_slab8<TA>(ra0, sA, t);
-    store_slab8<!TB>(rb0, sB, t);
+    if (VEC) { store_slab8_v<TA>(ra0, sA, t); store_slab8_v<!TB>(rb0, sB, t); }
+    else { store_slab8<TA>(ra0, sA, t); store_slab8<!TB>(rb0, sB, t); }
     __syncthreads();
     if (k0 + BK < p.K) {
-      load_slab8<TA>(ra0, A, p.lda, m0, p.M, k0 + BK, p.K, t);
-      load_slab8<!TB>(rb0, B, p.ldb, n0, p.N, k0 + BK, p.K, t);
+      if (VEC) {
+        load_slab8_v<TA>(ra0, A, p.lda, m0, p.M, k0 + BK, p.K, t);
+        load_slab8_v<!TB>(rb0, B, p.ldb, n0, p.N, k0 + BK, p.K, t);
+      } else {
+        load_slab8<TA>(ra0, A, p.lda, m0, p.M, k0 + BK, p.K, t);
+        load_slab8<!TB>(rb0, B, p.ldb, n0, p.N, k0 + BK, p.K, t);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
@@ -591,21 +639,28 @@ void gemm(hipStream_t s, const GemmDesc &g) {
     hipLaunchKernelGGL(gemm_rankk_kernel, grid, dim3(512), 2 * RK * RK_LD * sizeof(double), s, p);
     return;
   }
+  // 16-byte operand fetch: every slab start must be 16-byte aligned -- even leading dimensions, aligned bases,
+  // even batch strides, no per-batch offsets from device memory (EK_GEMM_VEC=0 turns the variants off)
+  static int vec_env = -1;
+  if (vec_env < 0) { const char *e = getenv("EK_GEMM_VEC"); vec_env = e ? atoi(e) : 1; }
+  const bool vec = vec_env && (!g.d_offs || g.even_offs) && ((g.lda | g.ldb) & 1) == 0 &&
+                   ((((size_t)g.A | (size_t)g.B) & 15) == 0) && (g.batch == 1 || ((g.strideA | g.strideB) & 1) == 0);
   const bool use_w8 = (w8 >= 0) ? (w8 != 0) : (g.K <= 512 && g.beta != 0.0);
   if (use_w8) {
     dim3 b8(512);
-    if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel_w8<false, false>), grid, b8, 0, s, p);
-    else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel_w8<false, true>), grid, b8, 0, s, p);
-    else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel_w8<true, false>), grid, b8, 0, s, p);
-    else hipLaunchKernelGGL((gemm_kernel_w8<true, true>), grid, b8, 0, s, p);
+    if (vec) {
+      if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel_w8<false, false, true>), grid, b8, 0, s, p);
+      else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel_w8<false, true, true>), grid, b8, 0, s, p);
+      else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel_w8<true, false, true>), grid, b8, 0, s, p);
+      else hipLaunchKernelGGL((gemm_kernel_w8<true, true, true>), grid, b8, 0, s, p);
+      return;
+    }
+    if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel_w8<false, false, false>), grid, b8, 0, s, p);
+    else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel_w8<false, true, false>), grid, b8, 0, s, p);
+    else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel_w8<true, false, false>), grid, b8, 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel_w8<true, true, false>), grid, b8, 0, s, p);
     return;
   }
-  // 16-byte operand fetch: every slab start must be 16-byte aligned -- even leading dimensions, aligned bases,
-  // even batch strides, no per-batch offsets from device memory (EK_GEMM_VEC=0 turns the variant off)
-  static int vec_env = -1;
-  if (vec_env < 0) { const char *e = getenv("EK_GEMM_VEC"); vec_env = e ? atoi(e) : 1; }
-  const bool vec = vec_env && !g.d_offs && !g.d_dims && ((g.lda | g.ldb) & 1) == 0 &&
-                   ((((size_t)g.A | (size_t)g.B) & 15) == 0) && (g.batch == 1 || ((g.strideA | g.strideB) & 1) == 0);
   if (vec) {
     if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_kernel<false, false, true>), grid, block, 0, s, p);
     else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_kernel<false, true, true>), grid, block, 0, s, p);
