@@ -262,9 +262,10 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
         long long *go = b.goffs + 6 * (size_t)mi;
         int *gd = b.gdims + 6 * (size_t)mi;
         go[0] = o + o * b.ldw;                       go[1] = o + o * b.lds;        go[2] = o + o * b.ldq;
-        go[3] = o + mg.n1 + (o + k1f) * b.ldw;       go[4] = o + k1f + o * b.lds;  go[5] = o + mg.n1 + o * b.ldq;
+        const int k1e = k1f & ~1;                    // even start of the second product (see below)
+        go[3] = o + mg.n1 + (o + k1e) * b.ldw;       go[4] = o + k1e + o * b.lds;  go[5] = o + mg.n1 + o * b.ldq;
         gd[0] = mg.n1;        gd[1] = kf; gd[2] = k1f;
-        gd[3] = n - mg.n1;    gd[4] = kf; gd[5] = k3f;
+        gd[3] = n - mg.n1;    gd[4] = kf; gd[5] = k3f + (k1f - k1e);
         b.k[mi] = kf; b.nrot[mi] = 0; b.rho[mi] = rho;
       }
       return;
@@ -321,9 +322,13 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
     long long *go = b.goffs + 6 * (size_t)mi;
     int *gd = b.gdims + 6 * (size_t)mi;
     go[0] = o + o * b.ldw;                       go[1] = o + o * b.lds;        go[2] = o + o * b.ldq;
-    go[3] = o + mg.n1 + (o + k1) * b.ldw;        go[4] = o + k1 + o * b.lds;   go[5] = o + mg.n1 + o * b.ldq;
+    // (the second product starts on an EVEN column of W / row of S: if k1 is odd it takes the last top-only
+    // column along, whose bottom rows are zero -- the operands of both products then start on even offsets
+    // whenever off and n1 are even, which is what the GEMM's 16-byte loads need)
+    const int k1e = k1 & ~1;
+    go[3] = o + mg.n1 + (o + k1e) * b.ldw;       go[4] = o + k1e + o * b.lds;  go[5] = o + mg.n1 + o * b.ldq;
     gd[0] = mg.n1;        gd[1] = k; gd[2] = k12;
-    gd[3] = n - mg.n1;    gd[4] = k; gd[5] = k23;
+    gd[3] = n - mg.n1;    gd[4] = k; gd[5] = k23 + (k1 - k1e);
   }
   b.k[mi] = k; b.nrot[mi] = nrot; b.rho[mi] = rho;
 }
@@ -713,7 +718,8 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
   for (size_t lv = 0; lv < plan.levels.size(); ++lv) {
     const int mbeg = lvl_beg[lv], cnt = lvl_beg[lv + 1] - mbeg;
     int maxn = 0;
-    for (auto &m : plan.levels[lv]) maxn = std::max(maxn, m.n);
+    bool even = ((ldz | ldq | lds) & 1) == 0;      // every merge of this height starts on even rows and columns
+    for (auto &m : plan.levels[lv]) { maxn = std::max(maxn, m.n); even = even && ((m.off | m.n1) & 1) == 0; }
     const int gx = ceil_div(maxn, 256);
     hipLaunchKernelGGL(dc_sort_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, Q, ldq);
     hipLaunchKernelGGL(dc_deflate_kernel, dim3(cnt), dim3(256), 0, s, mbeg, b);
@@ -738,7 +744,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
       g.alpha = 1.0; g.beta = 0.0;
       g.A = W; g.lda = ldz; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
       g.C = Q; g.ldc = ldq; g.strideC = 0; g.batch = 2; g.lower_only = false;
-      g.d_offs = b.goffs + 6 * (size_t)mbeg; g.d_dims = b.gdims + 6 * (size_t)mbeg;
+      g.d_offs = b.goffs + 6 * (size_t)mbeg; g.d_dims = b.gdims + 6 * (size_t)mbeg; g.even_offs = even;
       gemm(s, g);
       const int gys = std::min(sel->nsel, std::max(1, 4096 / gx));
       hipLaunchKernelGGL(dc_copy_deflated_sel_kernel, dim3(gx, gys), dim3(256), 0, s, mbeg, b, sel->nsel, selcol,
@@ -755,7 +761,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     g.alpha = 1.0; g.beta = 0.0;
     g.A = W; g.lda = ldz; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
     g.C = Q; g.ldc = ldq; g.strideC = 0; g.batch = 2 * cnt; g.lower_only = false;
-    g.d_offs = b.goffs + 6 * (size_t)mbeg; g.d_dims = b.gdims + 6 * (size_t)mbeg;
+    g.d_offs = b.goffs + 6 * (size_t)mbeg; g.d_dims = b.gdims + 6 * (size_t)mbeg; g.even_offs = even;
     gemm(s, g);
     hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldz, Q, ldq);
   }
