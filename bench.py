@@ -624,7 +624,7 @@ def main():
                 "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                 "launches": int(kp_l[0]), "avg_launch_us": 1e6 * dur, "algorithmic_flops_per_launch": fl,
-                "measured_mfma_ceiling_tflops": 61.0,   # largest GEMM shapes of this library (profiles/r02_gemm_shapes_n16384.txt); register-only loop: 49.6
+                "measured_mfma_ceiling_tflops": 69.0,   # largest GEMM shapes of this library (profiles/r02_gemm_shapes_n16384_v6.txt); register-only loop: 49.6
                 "other_kernels": {
                     "chase_kernel (band -> tridiagonal, latency-bound pipeline of sweeps)":
                         {"launches": int(kp_l[1]), "avg_launch_us": 1e6 * kp_s[1] / max(kp_l[1], 1)},
