@@ -526,7 +526,7 @@ __device__ __forceinline__ void st_sc1_x2(double *p, double a, double b) {
 }
 
 __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
-  extern __shared__ double q2smem[];
+  extern __shared__ __attribute__((aligned(16))) double q2smem[];
   double *sOp = q2smem;
   __shared__ int s_pass, s_ok;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
@@ -563,17 +563,20 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
       return true;
     };
     double4_t za[4], zb[4];
-    constexpr int NOP = (QREC + 255) / 256;             // 25 doubles of a record per thread
-    double zreg[16], oreg[NOP];
+    static_assert(QREC % 2 == 0, "records travel as 16-byte pairs");
+    constexpr int NPAIR = QREC / 2, NOP = (NPAIR + 255) / 256;   // 13 pairs of a record per thread
+    double zreg[16];
+    d2_t oreg[NOP];
     auto fetch_ops = [&](int Sb, int k) {                // the record is the LDS image itself: a linear copy
-      const double *rec = p.Rec + ((size_t)Sb * p.g.kmax + k) * QREC;
+      const d2_t *rec = reinterpret_cast<const d2_t *>(p.Rec + ((size_t)Sb * p.g.kmax + k) * QREC);
 #pragma unroll
-      for (int q = 0; q < NOP; ++q) oreg[q] = (q < NOP - 1 || t + 256 * q < QREC) ? rec[t + 256 * q] : 0.0;
+      for (int q = 0; q < NOP; ++q) oreg[q] = (q < NOP - 1 || t + 256 * q < NPAIR) ? rec[t + 256 * q] : (d2_t){0.0, 0.0};
     };
     auto put_ops = [&]() {
+      d2_t *dst = reinterpret_cast<d2_t *>(sOp);
 #pragma unroll
       for (int q = 0; q < NOP; ++q)
-        if (q < NOP - 1 || t + 256 * q < QREC) sOp[t + 256 * q] = oreg[q];
+        if (q < NOP - 1 || t + 256 * q < NPAIR) dst[t + 256 * q] = oreg[q];
     };
     // chunk j -> zreg: lane = row of the chunk, 16 columns (sc1: another pass may have written them)
     const bool cols_in = colw + 16 <= p.ncols;
