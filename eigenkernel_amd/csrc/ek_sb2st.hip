@@ -147,8 +147,9 @@ __device__ __forceinline__ double make_reflector(double x, int lane, int L, int 
 // pattern marks a slot; the reader empties it again; four lines per task index in rotation) -- data that
 // is its own flag costs no drain, no barrier and no second round trip.  Sweeps follow each other ONE task
 // apart (plus the hand-off), not three; the pipeline is latency-bound and its length is the number of
-// sweeps times that distance.  The one store of a task that lands on an entry the previous sweep's task
-// k+1 also stores (the corner of D_k) waits for that task's completion word.
+// sweeps times that distance.  The 65 mailbox numbers are exactly the entries BOTH sweeps would store (the
+// follower rewrites them in the same task): the sender leaves them to the follower, so no store of one
+// sweep ever has to wait for a store of another.
 //
 // Per task the workgroup synchronises four times.  NW waves per workgroup, each with CW = 64 / NW
 // columns of a block (row per lane).
@@ -302,7 +303,9 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
           const int i0n = i0 + SB;
           const double beta = make_reflector(col0, lane, L1, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
           b00 = beta;
-          if (lane < L1) st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), (lane == 0) ? beta : 0.0);
+          // (beta itself travels by mailbox when there is a follower to rewrite that entry: see phase (c))
+          if (lane < L1 && !(lane == 0 && k > 0 && has_follower))
+            st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), (lane == 0) ? beta : 0.0);
         }
         if (lane == 0 && k > 0 && has_follower)
           st_sc1(p.mail + ((size_t)(s & 3) * p.kmax + k) * MAILW + 64, b00);
@@ -325,14 +328,11 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         dd[j] -= v_r * w_c + w_r * vc[j];
         if (c == 0 && k > 0 && has_follower)               // column 0 of D_k: the follower's late numbers (entries >= L are 0)
           st_sc1(p.mail + ((size_t)(s & 3) * p.kmax + k) * MAILW + lane, dd[j]);
-        if (c <= lane && lane < L) {
-          if (c == SB - 1 && lead) {
-            // the corner: the previous sweep's task k+1 stores this entry too (as entry (0,0) of its diagonal
-            // block); ours must come second
-            if (!wait_word(&p.prog[s - 1], (unsigned)(k + 2))) give_up();
-          }
+        // (column 0 of a task k > 0 goes to the follower through the mailbox only: the follower rewrites exactly
+        // these 64 entries -- the corner of its D_{k-1} and the last column of its B_{k-1} -- and two stores of one
+        // entry from two sweeps would have to be ordered by a wait)
+        if (c <= lane && lane < L && !(c == 0 && k > 0 && has_follower))
           st_sc1(AB + (unsigned)((lane - c) + (i0 + c) * LDAB), dd[j]);
-        }
       }
       // ---- (d) B_k <- B_k H (rows I_{k+1}, columns I_k)
       double bp[CW];
@@ -349,7 +349,8 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 #pragma unroll
           for (int j = 0; j < CW; ++j) {
             const int c = c0w + j;
-            if (lane < L1 && c < L) st_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB), bp[j]);
+            if (lane < L1 && c < L && !(lane == 0 && c == 0 && k > 0 && has_follower))
+              st_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB), bp[j]);
           }
         }
       }
