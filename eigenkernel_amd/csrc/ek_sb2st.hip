@@ -321,9 +321,9 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 #pragma unroll
       for (int j = 0; j < CW; ++j) {
         const int c = c0w + j;
-        double pc = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) pc += s_p[w][c];
+        // (p of column c is p of row c, which lane c of this wave has just summed: a v_readlane instead of NW
+        // more LDS reads per column -- eight waves share one LDS pipe)
+        const double pc = lane_value(psum, c);
         const double w_c = tau * pc + alpha * vc[j];
         dd[j] -= v_r * w_c + w_r * vc[j];
         if (c == 0 && k > 0 && has_follower)               // column 0 of D_k: the follower's late numbers (entries >= L are 0)
