@@ -171,7 +171,6 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
   __shared__ double s_p[NW][SB], s_q[NW][SB];
   __shared__ double s_t[NW][CW * 65];
   __shared__ double s_D[SB * DLD];
-  __shared__ double s_z[SB];
   __shared__ double s_tau[2];
   __shared__ int s_sweep, s_ok;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       const double v_r = s_v[cur][lane];
       double vc[CW];
 #pragma unroll
-      for (int j = 0; j < CW; ++j) vc[j] = s_v[cur][c0w + j];
+      for (int j = 0; j < CW; ++j) vc[j] = lane_value(v_r, c0w + j);   // (a lane per row: v of column c is lane c's)
       // ---- the late numbers of the previous sweep's task k+1: our last column of B_k and the corner of D_k
       if (lead && wave == NW - 1) {
         unsigned spins = 0;
@@ -368,21 +367,20 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 #pragma unroll
         for (int j = 0; j < CW; ++j) st[j * 65 + lane] = vn_r * bp[j];
         wave_sync();
+        double tot_b;
         {
           const int j = lane / LPC, q = lane % LPC;
           const double *src = st + j * 65 + CW * q;
           double a0 = 0.0, a1 = 0.0;
 #pragma unroll
           for (int l = 0; l < CW; l += 2) { a0 += src[l]; a1 += src[l + 1]; }
-          const double tot = group_sum<LPC>(a0 + a1);
-          if (q == 0) s_z[c0w + j] = tot;
+          tot_b = group_sum<LPC>(a0 + a1);                 // lanes j LPC .. : v'^T (column j of this wave's part of B_k)
         }
-        wave_sync();
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
           const int c = c0w + j;
           if (c > 0) {           // column 0 is (beta, 0, ..., 0) and went to memory with the reflector
-            const double b = bp[j] - tau_n * vn_r * s_z[c];
+            const double b = bp[j] - tau_n * vn_r * lane_value(tot_b, j * LPC);
             if (lane < L1) st_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB), b);
           }
         }
