@@ -16,6 +16,8 @@
 #include "ek_common.h"
 #include "ek_block64.h"
 
+#include <cstdlib>
+
 namespace ek {
 namespace {
 
@@ -325,8 +327,9 @@ static void trsm_rlt_lower(hipStream_t s, int n, const double *L, int ldl, const
 
 // Below this order a block is reduced by two triangular solves (1.57 n^3 flops but the fewest
 // and largest GEMMs); above it the blocked recursion (n^3).  Measured on MI355X at N = 16384
-// (sygst stage): no recursion 0.133 s, threshold 2048 -> 0.115 s, 1024 -> 0.120 s, 512 -> 0.126 s.
-constexpr int kSygstDirect = 2048;
+// (sygst stage), round 1: no recursion 0.133 s, threshold 2048 -> 0.115 s, 1024 -> 0.120 s, 512 -> 0.126 s;
+// with the 16-byte-load GEMM of round 2: 1024 -> 0.110, 2048 -> 0.103, 4096 -> 0.099, 8192 -> 0.099, none 0.115.
+constexpr int kSygstDirect = 4096;
 
 // Recursive blocked DSYGST(itype = 1, 'L'):  with A = [A11 .; A21 A22], L = [L11 0; L21 L22]
 //   C11 = sygst(A11, L11)
