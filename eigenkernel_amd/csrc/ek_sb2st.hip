@@ -8,15 +8,16 @@
 // two-stage solvers use): sweep s annihilates column s below the sub-diagonal with a reflector on
 // rows s+1 .. s+64, whose two-sided application fills a 64x64 bulge one block further down; the
 // first column of the bulge is annihilated by the next reflector of the sweep, and so on to the end
-// of the band.  Task (s, k): reflector k of sweep s on I_k = [s+1+64k, s+64(k+1)], applied from the
-// left to B_{k-1} = A(I_k, I_{k-1}), from both sides to D_k = A(I_k, I_k), from the right to
-// B_k = A(I_{k+1}, I_k).  Task (s+1, j) may run once task (s, j+1) is done (see chase_kernel): the
-// sweeps form a pipeline.
+// of the band.  Task (s, k): reflector k of sweep s on I_k = [s+1+64k, s+64(k+1)], applied from both
+// sides to D_k = A(I_k, I_k) and from the right to B_k = A(I_{k+1}, I_k); then reflector k+1 is made from
+// column 0 of the new B_k and applied to B_k from the left, so that the task hands on a finished block.
+// Task (s+1, j) may start once task (s, j) is complete and receives 65 late numbers of task (s, j+1)
+// through a mailbox (see chase_kernel): the sweeps form a pipeline one task apart.
 //
 // MI355X shape: ONE persistent launch; a workgroup takes sweeps from a ticket counter (in order, so
-// a workgroup only ever waits for a sweep whose owner is already running) and walks down the band,
-// carrying B_{k-1} in registers from task to task (row per lane, 16 columns per wave).  Sweeps
-// synchronise through one progress word per sweep.  The band lives in L2 / Infinity Cache (16 MB at
+// a workgroup only ever waits for a sweep whose owner is already running) and walks down the band (row
+// per lane, 8 columns per wave).  Sweeps synchronise through one progress word per sweep.  The band
+// lives in L2 / Infinity Cache (16 MB at
 // n = 16384) and is only ever touched with agent-scope (sc1) loads and stores, so no cache
 // maintenance is needed: writer = sc1 stores, s_waitcnt vmcnt(0) in every wave, workgroup barrier,
 // sc1 store of the progress word; reader = sc1 poll by one lane, workgroup barrier, sc1 loads
