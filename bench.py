@@ -223,7 +223,7 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
     import threading
     from eigenkernel_amd import descriptor as dsc
     NB = 64
-    K, W = args.steps, max(1, args.warmup)
+    K, W = min(args.steps, 8), max(1, min(args.warmup, 2))      # a probe, not the headline: bounded whatever --steps says
     res = {"distribution": "1 x %d process grid, replicated inputs; PDPOTRF/PDSYGST (from 3 ranks on) and PDSYTRD "
                            "distributed over %s, eigenvector columns sharded"
                            % (world, "the HOST communicator (one-GPU rehearsal: timings mean nothing)"
