@@ -425,61 +425,78 @@ __device__ __forceinline__ double q2_v_entry(const Q2Geom &g, const double *__re
   return V2[(size_t)row + (size_t)s * ldv2];
 }
 
-// One wave per group: T (DLARFT, forward columnwise) from the reflectors and their tau, then the
-// record [V | -V T] the application streams.
-__global__ __launch_bounds__(64) void q2_tfactor_kernel(Q2Geom g, const double *__restrict__ V2, int ldv2,
-                                                        const double *__restrict__ tau2, int ldt,
-                                                        double *__restrict__ Rec) {
+// One workgroup (4 waves) per group: the record [V | -V T] the application streams.  The Gram matrix
+// G = V^T V and the product V T run on the matrix cores; between them one wave forms T by DLARFT's forward
+// columnwise recurrence T(0:i, i) = -tau_i T(0:i, 0:i) G(0:i, i) -- the only serial part (32 steps).
+// (The first version did all of it in one wave with per-lane dot products out of LDS: 8 ms per solve at
+// N = 16384; this one takes 3.)
+__global__ __launch_bounds__(256) void q2_tfactor_kernel(Q2Geom g, const double *__restrict__ V2, int ldv2,
+                                                         const double *__restrict__ tau2, int ldt,
+                                                         double *__restrict__ Rec) {
   __shared__ double sV[QR * QVLD];
+  __shared__ double sG[QG * QVLD];
   __shared__ double sT[QG * QVLD];
-  __shared__ double s_g[QG];
-  const int S = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
+  __shared__ double s_tau[QG];
+  const int S = blockIdx.y, k = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
   if (k >= q2_groups_of_block(g.n, S)) return;
   double *rec = Rec + ((size_t)S * g.kmax + k) * QREC;
-  for (int idx = lane; idx < QR * QG; idx += 64) {
+  for (int idx = t; idx < QR * QG; idx += 256) {
     const int rr = idx % QR, i = idx / QR;
     const double v = q2_v_entry(g, V2, ldv2, S, k, rr, i);
     sV[rr * QVLD + i] = v;
     rec[rr * QVLD + i] = v;
   }
-  for (int rr = lane; rr < QR; rr += 64) { rec[rr * QVLD + QG] = 0.0; rec[QR * QVLD + rr * QVLD + QG] = 0.0; }   // padding column
-  for (int idx = lane; idx < QG * QVLD; idx += 64) sT[idx] = 0.0;
-  wave_sync();
-  for (int i = 0; i < QG; ++i) {
-    const int s = q2_first_sweep(S) + i;
+  for (int rr = t; rr < QR; rr += 256) { rec[rr * QVLD + QG] = 0.0; rec[QR * QVLD + rr * QVLD + QG] = 0.0; }   // padding column
+  for (int idx = t; idx < QG * QVLD; idx += 256) sT[idx] = 0.0;
+  if (t < QG) {
+    const int s = q2_first_sweep(S) + t;
     const bool exists = s >= 0 && s < g.nsweeps && s + 1 + k * SB <= g.n - 2;
-    const double ti = exists ? tau2[(size_t)k + (size_t)s * ldt] : 0.0;
-    if (lane < i) {                              // g_a = v_a^T v_i over the common rows [i, a + SB)
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int rr = i;
-      for (; rr + 3 < lane + SB; rr += 4) {
-        a0 += sV[rr * QVLD + lane] * sV[rr * QVLD + i];
-        a1 += sV[(rr + 1) * QVLD + lane] * sV[(rr + 1) * QVLD + i];
-        a2 += sV[(rr + 2) * QVLD + lane] * sV[(rr + 2) * QVLD + i];
-        a3 += sV[(rr + 3) * QVLD + lane] * sV[(rr + 3) * QVLD + i];
-      }
-      for (; rr < lane + SB; ++rr) a0 += sV[rr * QVLD + lane] * sV[rr * QVLD + i];
-      s_g[lane] = (a0 + a1) + (a2 + a3);
-    }
-    wave_sync();
-    if (lane < i) {
-      double a = 0.0;
-      for (int l = lane; l < i; ++l) a += sT[lane * QVLD + l] * s_g[l];
-      sT[lane * QVLD + i] = -ti * a;
-    } else if (lane == i) sT[i * QVLD + i] = ti;
-    wave_sync();
+    s_tau[t] = exists ? tau2[(size_t)k + (size_t)s * ldt] : 0.0;
   }
-  // V T: row rr of the product by lane rr (and rr + 64)
-  for (int rr = lane; rr < QR; rr += 64) {
-    double vrow[QG];
-#pragma unroll
-    for (int l = 0; l < QG; ++l) vrow[l] = sV[rr * QVLD + l];
-    for (int j = 0; j < QG; ++j) {
-      double a = 0.0;
-#pragma unroll
-      for (int l = 0; l < QG; ++l) a += vrow[l] * sT[l * QVLD + j];     // T upper triangular: zeros below
-      rec[QR * QVLD + rr * QVLD + j] = -a;
+  __syncthreads();
+  // G = V^T V: 2 x 2 tiles of 16 x 16, one per wave, 24 k-steps over the 96 rows
+  {
+    const int ti = wave >> 1, tj = wave & 1;
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < QR; kk += 4) {
+      const double x = sV[(kk + l4) * QVLD + 16 * ti + l15];
+      const double y = sV[(kk + l4) * QVLD + 16 * tj + l15];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sG[(16 * ti + l4 + 4 * r) * QVLD + 16 * tj + l15] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int i = 0; i < QG; ++i) {
+      const double ti = s_tau[i];
+      if (lane < i) {
+        double a0 = 0.0, a1 = 0.0;
+        int l = lane;
+        for (; l + 1 < i; l += 2) {
+          a0 += sT[lane * QVLD + l] * sG[l * QVLD + i];
+          a1 += sT[lane * QVLD + l + 1] * sG[(l + 1) * QVLD + i];
+        }
+        if (l < i) a0 += sT[lane * QVLD + l] * sG[l * QVLD + i];
+        sT[lane * QVLD + i] = -ti * (a0 + a1);
+      } else if (lane == i) sT[i * QVLD + i] = ti;
+      wave_sync();
+    }
+  }
+  __syncthreads();
+  // -(V T): 6 x 2 tiles, three per wave, 8 k-steps over the 32 reflectors
+  for (int tile = wave; tile < 12; tile += 4) {
+    const int ti = tile >> 1, tj = tile & 1;
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < QG; kk += 4) {
+      const double x = sV[(16 * ti + l15) * QVLD + kk + l4];
+      const double y = sT[(kk + l4) * QVLD + 16 * tj + l15];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rec[QR * QVLD + (16 * ti + l4 + 4 * r) * QVLD + 16 * tj + l15] = -acc[r];
   }
 }
 
@@ -805,7 +822,7 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   double *Rec = (double *)(w + L.off_T);
   unsigned *ctl = (unsigned *)(w + L.off_ctl), *qprog = (unsigned *)(w + L.off_qprog);
   Q2Geom g{n, L.nsweeps, L.nS, L.kmax};
-  hipLaunchKernelGGL(q2_tfactor_kernel, dim3(L.kmax, L.nS), dim3(64), 0, s, g, V2, ldv2, tau2, L.ldt, Rec);
+  hipLaunchKernelGGL(q2_tfactor_kernel, dim3(L.kmax, L.nS), dim3(256), 0, s, g, V2, ldv2, tau2, L.ldt, Rec);
   constexpr size_t lds = (size_t)(QOPSZ + 4 * 16 * QSTLD) * sizeof(double);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)q2_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
