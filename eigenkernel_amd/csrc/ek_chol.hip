@@ -29,8 +29,8 @@ constexpr size_t kDiagLds = 4 * b64::IMG * sizeof(double);   // dynamic LDS of p
 // info (device): first non-positive pivot (1-based, global numbering) or 0.
 //
 // The block is handled as 2 x 2 blocks of 64 in terms of the UPPER factor R = L^T held in row-major
-// LDS images (ek_block64.h): the two 64-step factorisations and the two 64-step triangular inverses
-// run on all four waves with the matrix in registers (one barrier and 16 FMAs per thread and step),
+// LDS images (ek_block64.h): the two factorisations and the two triangular inverses go by row blocks of 16
+// (the serial steps of a block inside one wave, the rest of the image on the matrix cores),
 // everything between them is a 64x64 product on the matrix cores:
 //   R11 = chol(B11), X11 = R11^-1, R12 = X11^T B12, R22 = chol(B22 - R12^T R12), X22 = R22^-1,
 //   X12 = -X11 R12 X22;      L = R^T,  inv(L) = [X11 X12; 0 X22]^T.
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(int nb, double *B, int 
   using namespace b64;
   extern __shared__ double smem[];
   double *sA = smem, *sB = smem + IMG, *sC = smem + 2 * IMG, *sD = smem + 3 * IMG;
-  __shared__ double srow[kLine];
+  __shared__ double s_inv[kScratch];
   const int t = threadIdx.x;
   // element (gr, gc), gr <= gc, of the symmetric block from its lower triangle
   auto upper = [&](int gr, int gc) -> double {
@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(int nb, double *B, int 
     sC[r * LD + c] = upper(r, 64 + c);                     // B12
   }
   __syncthreads();
-  int fail = chol64_upper_wg(sA, srow);                    // sA = R11
+  int fail = chol64_upper_wg(sA, s_inv);                    // sA = R11
   if (fail >= 0) { fail_exit(fail); return; }
-  triinv64_upper_wg(sA, sB, srow);                         // sB = X11
+  triinv64_upper_wg(sA, sB, s_inv);                         // sB = X11
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     if (i >= j && i < nb) B[(size_t)i + (size_t)j * ldb] = sA[j * LD + i];                  // L11
@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(int nb, double *B, int 
     sA[r * LD + c] = (c >= r) ? upper(64 + r, 64 + c) - sC[r * LD + c] : 0.0;
   }
   __syncthreads();
-  fail = chol64_upper_wg(sA, srow);                        // sA = R22
+  fail = chol64_upper_wg(sA, s_inv);                        // sA = R22
   if (fail >= 0) { fail_exit(64 + fail); return; }
-  triinv64_upper_wg(sA, sC, srow);                         // sC = X22
+  triinv64_upper_wg(sA, sC, s_inv);                         // sC = X22
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     if (i >= j && 64 + i < nb) B[(size_t)(64 + i) + (size_t)(64 + j) * ldb] = sA[j * LD + i];   // L22

@@ -168,15 +168,16 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(int npart, const doub
 // first CholeskyQR pass: G (64x64, symmetric, stored j + 64 i) -> R1 (column-major) and R1^-1
 __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G, double *__restrict__ R,
                                                    double *__restrict__ Rinv, int *flag) {
-  __shared__ double sA[IMG], sB[IMG], srow[kLine];
+  __shared__ double sA[IMG], sB[IMG];
+  __shared__ double s_inv[kScratch];
   const int t = threadIdx.x;
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int j = idx & 63, i = idx >> 6;
     sA[i * LD + j] = G[idx];
   }
   __syncthreads();
-  if (chol64_upper_wg(sA, srow) >= 0 && t == 0) atomicExch(flag, 1);
-  triinv64_upper_wg(sA, sB, srow);
+  if (chol64_upper_wg(sA, s_inv) >= 0 && t == 0) atomicExch(flag, 1);
+  triinv64_upper_wg(sA, sB, s_inv);
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     R[idx] = sA[i * LD + j];
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   double *sA = smem, *sB = smem + IMG, *sC = smem + 2 * IMG, *sD = smem + 3 * IMG;
   __shared__ double s_sign[SB];
   __shared__ double s_red[4];
-  __shared__ double srow[kLine], scol[kLine];
+  __shared__ double s_inv[kScratch];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   long long tc[10]; int nt = 0;
   const bool prof = p.prof && t == 0;
@@ -224,28 +225,28 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
     if (!(dmax <= 0.25)) atomicExch(p.flag, 2);
   }
   if (prof) tc[nt++] = clock64();
-  if (chol64_upper_wg(sA, srow) >= 0 && t == 0) atomicExch(p.flag, 1);      // sA = R2
+  if (chol64_upper_wg(sA, s_inv) >= 0 && t == 0) atomicExch(p.flag, 1);      // sA = R2
   if (prof) tc[nt++] = clock64();
-  triinv64_upper_wg(sA, sB, srow);                                      // sB = R2^-1
+  triinv64_upper_wg(sA, sB, s_inv);                                      // sB = R2^-1
   if (prof) tc[nt++] = clock64();
   mm64(sC, false, sB, false, sD);                                       // sD = Q top = Qt_top R2^-1
   __syncthreads();
   if (prof) tc[nt++] = clock64();
-  lu64_signed_wg(sD, s_sign, srow, scol);                               // sD = L1 \ U of (Q_top - S)
+  lu64_signed_wg(sD, s_sign, s_inv);                               // sD = L1 \ U of (Q_top - S)
   if (prof) tc[nt++] = clock64();
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     p.L1[idx] = (i > j) ? sD[i * LD + j] : (i == j ? 1.0 : 0.0);
   }
   // T = -U S L1^-T (into sC transposed: sC(j, i) = T(i, j)); the top block of Qt is no longer needed
-  tsolve64_wg(sD, s_sign, sC, srow);
+  tsolve64_wg(sD, s_sign, sC, s_inv);
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     p.T[idx] = sC[j * LD + i];
     if (i == j) p.tau[i] = sC[i * LD + i];
   }
   __syncthreads();
-  triinv64_upper_wg(sD, sC, srow);                                      // sC = U^-1
+  triinv64_upper_wg(sD, sC, s_inv);                                      // sC = U^-1
   if (prof) tc[nt++] = clock64();
   for (int idx = t; idx < SB * SB; idx += 256) {                        // sD = R1
     const int i = idx & 63, j = idx >> 6;
@@ -656,7 +657,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   const bool prof = getenv("EK_SY2SB_PROF") != nullptr;
   if (prof) (void)hipMemsetAsync(sm + 10 * 4096, 0, 128, s);
   static int la_min = -1;
-  if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 1024; }
+  if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 5120; }
 
   // factorisation of the panel at column c0 into image `im`, T into `Tp`, issued on stream `st`
   auto panel_chain = [&](hipStream_t st, int c0, double *Vimg, double *Tp) {
