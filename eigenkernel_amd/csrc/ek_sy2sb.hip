@@ -32,7 +32,10 @@ namespace {
 
 using namespace b64;          // 64x64 LDS images and the workgroup-wide factorisations on them
 static_assert(SB == kBandW, "the panel width is the width of the 64x64 building blocks");
-constexpr int CH = 128;      // rows per workgroup of the tall-skinny kernels (two 64-row slabs)
+// rows per workgroup of the tall-skinny kernels (slabs of 64).  One slab: the chain of a panel is ~14 dependent
+// launches, and 64-row chunks put twice as many workgroups on each of them as 128-row chunks did
+// (stage 1 at N = 4096: 19.7 -> 17.7 ms, N = 16384: 215.7 -> 210.0 ms, N = 32768: 1.387 -> 1.382 s)
+constexpr int CH = 64;
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS operations have completed
@@ -151,18 +154,22 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p) {
   if (MODE != 2) store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
 }
 
-// sum of `npart` 64x64 partials in a fixed order: grid 16 x 256 threads
+// sum of `npart` 64x64 partials in a fixed order: grid 128 x 256 threads.  A workgroup owns 32 entries;
+// thread (q = t / 32, e) adds the partials q, q + 8, q + 16, .. (two accumulators), the eight sums of an
+// entry meet in LDS.  (One thread per entry over all partials was a chain of npart dependent-latency loads:
+// with 64-row chunks a panel of 16 000 rows has 250 partials.)
 __global__ __launch_bounds__(256) void reduce_parts_kernel(int npart, const double *__restrict__ part,
                                                            double *__restrict__ out) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int p = 0;
-  for (; p + 3 < npart; p += 4) {
-    a0 += part[(size_t)p * 4096 + e]; a1 += part[(size_t)(p + 1) * 4096 + e];
-    a2 += part[(size_t)(p + 2) * 4096 + e]; a3 += part[(size_t)(p + 3) * 4096 + e];
-  }
-  for (; p < npart; ++p) a0 += part[(size_t)p * 4096 + e];
-  out[e] = (a0 + a1) + (a2 + a3);
+  __shared__ double s_sum[8][32];
+  const int t = threadIdx.x, q = t >> 5, el = t & 31, e = blockIdx.x * 32 + el;
+  double a0 = 0.0, a1 = 0.0;
+  int p = q;
+  for (; p + 8 < npart; p += 16) { a0 += part[(size_t)p * 4096 + e]; a1 += part[(size_t)(p + 8) * 4096 + e]; }
+  if (p < npart) a0 += part[(size_t)p * 4096 + e];
+  s_sum[q][el] = a0 + a1;
+  __syncthreads();
+  if (t < 32)
+    out[e] = ((s_sum[0][t] + s_sum[1][t]) + (s_sum[2][t] + s_sum[3][t])) + ((s_sum[4][t] + s_sum[5][t]) + (s_sum[6][t] + s_sum[7][t]));
 }
 
 // first CholeskyQR pass: G (64x64, symmetric, stored j + 64 i) -> R1 (column-major) and R1^-1
@@ -673,11 +680,11 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     PanelArgs pa{};
     pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = Gpart2;
     hipLaunchKernelGGL(panel_kernel<0>, dim3(nch), dim3(256), 0, st, pa);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, st, nch, Gpart2, Gred2);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, Gpart2, Gred2);
     hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, Gred2, R1, R1inv, d_flag);
     pa.M = R1inv; pa.dst = Qt; pa.ldd = L.mpad;
     hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, st, pa);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, st, nch, Gpart2, Gred2);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, Gpart2, Gred2);
     HrArgs ha{Gred2, Qt, L.mpad, R1, M2, Tp, L1, Rband, tau1 + c0, d_flag, nullptr};
     if (prof) ha.prof = (long long *)(sm + 10 * 4096);
     hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), st, ha);
@@ -713,7 +720,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     if (timed) kprof_end(s, kProfSymm);
     YredArgs ya{m, nsplit, Ypart, L.mpad, (long long)L.mpad * SB, Y, V, ldi, Gpart};
     hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(16), dim3(256), 0, s, nch, Gpart, Gred);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s, nch, Gpart, Gred);
     hipLaunchKernelGGL(wmat_kernel, dim3(1), dim3(256), 0, s, Gred, Tm[cur], Mw);
     WArgs wa{m, Y, L.mpad, V, ldi, Mw, Vimg, ldi};
     hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
