@@ -273,64 +273,95 @@ struct SmallArgs {
   double *Apanel; int lda; double *Vall; int ldv; double *Vimg; int ldi;
   double *T, *tau;
 };
-constexpr int SMALL_MAX = 192;
+constexpr int SMALL_MAX = 127;              // panels of 128 rows and more go through the CholeskyQR2 chain
+constexpr int SMALL_ROWS = 128;             // rows of the LDS image (two slabs of 64)
 __global__ __launch_bounds__(256) void house_small_kernel(SmallArgs p) {
   extern __shared__ double smem[];
-  double *sP = smem;                       // m x 64 panel, row-major (LD)
-  double *sT = smem + SMALL_MAX * LD;      // T, row-major
-  __shared__ double s_tau[SB], s_g[SB], s_red[8];
+  double *sP = smem;                       // 128 x 64 panel, row-major (LD); rows >= m are zero
+  double *sT = smem + SMALL_ROWS * LD;     // T, row-major
+  double *sG = sT + IMG;                   // V^T V, row-major
+  __shared__ double s_tau[SB], s_w[4][SB], s_red[2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m = p.m;
-  for (int idx = t; idx < SMALL_MAX * SB; idx += 256) {
-    const int r = idx % SMALL_MAX, c = idx / SMALL_MAX;
+  for (int idx = t; idx < SMALL_ROWS * SB; idx += 256) {
+    const int r = idx % SMALL_ROWS, c = idx / SMALL_ROWS;
     sP[r * LD + c] = (r < m) ? p.Apanel[(size_t)r + (size_t)c * p.lda] : 0.0;
   }
   for (int idx = t; idx < IMG; idx += 256) sT[idx] = 0.0;
   __syncthreads();
   for (int j = 0; j < SB; ++j) {
     double tau = 0.0;
-    if (j < m - 1) {
-      // DLARFG on x = P(j:m, j)
-      double ssq = 0.0;
-      for (int r = j + 1 + t; r < m; r += 256) { const double x = sP[r * LD + j]; ssq += x * x; }
-      for (int o = 32; o > 0; o >>= 1) ssq += __shfl_down(ssq, o, 64);
-      if (lane == 0) s_red[wave] = ssq;
+    if (j < m - 1) {                       // uniform
+      // DLARFG on x = P(j:m, j): thread t < 128 holds row t
+      double x = (t > j && t < m) ? sP[t * LD + j] : 0.0;
+      double ssq = x * x;
+      if (wave < 2) {
+        for (int o = 32; o > 0; o >>= 1) ssq += __shfl_down(ssq, o, 64);
+        if (lane == 0) s_red[wave] = ssq;
+      }
       __syncthreads();
-      ssq = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+      ssq = s_red[0] + s_red[1];
       const double alpha = sP[j * LD + j];
-      __syncthreads();
-      if (ssq != 0.0) {
+      if (ssq != 0.0) {                    // uniform
         const double beta = -copysign(hypot(alpha, sqrt(ssq)), alpha);
         tau = (beta - alpha) / beta;
         const double scale = 1.0 / (alpha - beta);
-        for (int r = j + 1 + t; r < m; r += 256) sP[r * LD + j] *= scale;
-        if (t == 0) sP[j * LD + j] = beta;
-      }
-      __syncthreads();
-      // apply H_j to the columns c > j: one thread per column
-      if (tau != 0.0 && t > j && t < SB) {
-        double w = sP[j * LD + t];
-        for (int r = j + 1; r < m; ++r) w += sP[r * LD + j] * sP[r * LD + t];
-        w *= tau;
-        sP[j * LD + t] -= w;
-        for (int r = j + 1; r < m; ++r) sP[r * LD + t] -= w * sP[r * LD + j];
+        __syncthreads();                   // everybody has read alpha
+        if (t > j && t < m) sP[t * LD + j] = x * scale;
+        if (t == j) sP[j * LD + j] = beta;
+        __syncthreads();
+        // H_j on the columns c > j: wave q takes the rows r = j + q, j + q + 4, ..; v(j) = 1
+        const int c = lane;
+        double w = 0.0;
+        for (int r = j + wave; r < m; r += 4) {
+          const double v = (r == j) ? 1.0 : sP[r * LD + j];
+          w += v * sP[r * LD + c];
+        }
+        s_w[wave][c] = w;
+        __syncthreads();
+        w = tau * ((s_w[0][c] + s_w[1][c]) + (s_w[2][c] + s_w[3][c]));
+        if (c > j)
+          for (int r = j + wave; r < m; r += 4) {
+            const double v = (r == j) ? 1.0 : sP[r * LD + j];
+            sP[r * LD + c] -= w * v;
+          }
       }
     }
     if (t == 0) s_tau[j] = tau;
     __syncthreads();
   }
-  // T (DLARFT, forward columnwise): T(i,i) = tau_i, T(0:i, i) = -tau_i T(0:i,0:i) (V^T v_i)
+  // the triangle R goes out, V takes its place: unit diagonal, zeros above (no reflector for c >= m - 1)
+  for (int idx = t; idx < m * SB; idx += 256) {
+    const int r = idx % m, c = idx / m;
+    const double x = sP[r * LD + c];
+    p.Apanel[(size_t)r + (size_t)c * p.lda] = (r <= c || c >= m - 1) ? x : 0.0;
+  }
+  __syncthreads();
+  for (int idx = t; idx < SMALL_ROWS * SB; idx += 256) {
+    const int r = idx % SMALL_ROWS, c = idx / SMALL_ROWS;
+    if (c >= m - 1 || r < c) sP[r * LD + c] = 0.0;
+    else if (r == c) sP[r * LD + c] = 1.0;
+  }
+  __syncthreads();
+  {
+    double4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    slab_gram(sP, sP, acc);
+    slab_gram(sP + SB * LD, sP + SB * LD, acc);
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sG[(16 * wave + l4 + 4 * q) * LD + 16 * jt + l15] = acc[jt][q];
+  }
+  __syncthreads();
+  // T (DLARFT, forward columnwise): T(i,i) = tau_i, T(0:i, i) = -tau_i T(0:i,0:i) G(0:i, i)
   for (int i = 0; i < SB; ++i) {
     const double ti = s_tau[i];
     if (t < i) {
-      double g = (i < m) ? sP[i * LD + t] : 0.0;          // v_t(i) * v_i(i) with v_i(i) = 1 (row i < m)
-      for (int r = i + 1; r < m; ++r) g += sP[r * LD + t] * sP[r * LD + i];
-      s_g[t] = g;
-    }
-    __syncthreads();
-    if (t < i) {
       double a = 0.0;
-      for (int l = t; l < i; ++l) a += sT[t * LD + l] * s_g[l];
+      for (int l = t; l < i; ++l) a += sT[t * LD + l] * sG[l * LD + i];
       sT[t * LD + i] = -ti * a;
     } else if (t == i) sT[i * LD + i] = ti;
     __syncthreads();
@@ -342,12 +373,9 @@ __global__ __launch_bounds__(256) void house_small_kernel(SmallArgs p) {
   }
   for (int idx = t; idx < m * SB; idx += 256) {
     const int r = idx % m, c = idx / m;
-    const double x = sP[r * LD + c];
-    // reflector c exists for c < m - 1 (else v = 0: the column of V is empty, tau = 0)
-    const double v = (c < m - 1) ? ((r > c) ? x : (r == c ? 1.0 : 0.0)) : 0.0;
+    const double v = sP[r * LD + c];
     p.Vall[(size_t)r + (size_t)c * p.ldv] = v;
     p.Vimg[(size_t)r + (size_t)(SB + c) * p.ldi] = v;
-    p.Apanel[(size_t)r + (size_t)c * p.lda] = (r <= c || c >= m - 1) ? x : 0.0;
   }
 }
 
@@ -643,7 +671,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     (void)hipFuncSetAttribute((const void *)hr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               4 * IMG * (int)sizeof(double));
     (void)hipFuncSetAttribute((const void *)house_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (SMALL_MAX * LD + IMG) * (int)sizeof(double));
+                              (SMALL_ROWS * LD + 2 * IMG) * (int)sizeof(double));
     for (int q = 0; q < 2; ++q) {
       (void)hipEventCreateWithFlags(&evA[q], hipEventDisableTiming);
       (void)hipEventCreateWithFlags(&evB[q], hipEventDisableTiming);
@@ -674,7 +702,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     const int nch = ceil_div(m, CH);
     if (m <= SMALL_MAX) {
       SmallArgs sa{m, Ap, lda, Vp, ldv, Vimg, ldi, Tp, tau1 + c0};
-      hipLaunchKernelGGL(house_small_kernel, dim3(1), dim3(256), (SMALL_MAX * LD + IMG) * sizeof(double), st, sa);
+      hipLaunchKernelGGL(house_small_kernel, dim3(1), dim3(256), (SMALL_ROWS * LD + 2 * IMG) * sizeof(double), st, sa);
       return;
     }
     PanelArgs pa{};
