@@ -40,3 +40,8 @@ for s, e, nm, _ in win:
     acc[nm][0] += 1; acc[nm][1] += e - s
 for nm, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
     print(f"  {nm:60s} {c:6d} {t / 1e6:9.3f} ms  {t / c / 1e3:8.1f} us")
+# per-call durations of the kernels whose name contains argv[4] (every 6th call), in launch order
+if len(sys.argv) > 4:
+    for sub in sys.argv[4].split(","):
+        calls = [(s, e) for s, e, nm, _ in win if sub in nm]
+        print(sub, "per call (us):", " ".join("%.0f" % ((e - s) / 1e3) for s, e in calls[::6]))

@@ -7,4 +7,4 @@ grep -a -v "simple_timer\|output_stream" /tmp/gp.log | tail -20; wc -l /tmp/gp/t
 find /tmp/gp -name '*.csv'
 F=$(find /tmp/gp -name '*kernel_trace.csv' | head -1)
 head -2 $F
-python3 $R/tools/gap_report.py $F "" symm_lower
+python3 $R/tools/gap_report.py $F "" symm_lower ${CALLS:-symm_lower,gemm_kernel_w8,hr_kernel,yred}
