@@ -521,34 +521,53 @@ void potrf_lower_rl(hipStream_t s, hipStream_t s2, int n, double *B, int ldb, do
       copy_matrix(st, mrows, nbk, ppan, mrows, Bd + nbk, ldb);
     }
   };
+  // Two levels of blocking.  An OUTER panel of `ob` block columns (512 columns) is factored on stream s2 by the
+  // right-looking steps of width 128 restricted to the panel (diagonal kernel, block column through the inverse
+  // of the diagonal block, rank-128 update of the panel's remaining block columns); the matrix behind the panel
+  // then takes ONE rank-512 update on stream s -- the next panel's columns first, so that its factorisation
+  // runs beside the rest of the update.  With rank-128 updates of the whole trailing matrix (ob = 1, the earlier
+  // form) every 128 columns read and wrote the whole trailing triangle: 92 GB of C traffic at N = 16384.
+  static int ob = -1;
+  if (ob < 0) { const char *e = getenv("EK_POTRF_OB"); ob = e ? atoi(e) : 4; if (ob < 1) ob = 1; }
+  const int NOB = ceil_div(NRB, ob);
+  auto factor_outer = [&](hipStream_t st, int o) {
+    const int k0 = o * ob, k1 = (k0 + ob < NRB) ? k0 + ob : NRB;
+    for (int k = k0; k < k1; ++k) {
+      factor_panel(st, k);
+      const int cnt = k1 - 1 - k;                                 // block columns of the panel behind k
+      if (cnt > 0) {
+        const int nbk = (n - k * NB < NB) ? n - k * NB : NB;
+        GemmDesc g{};
+        g.N = NB; g.K = nbk; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
+        g.A = B; g.lda = ldb; g.B = B; g.ldb = ldb; g.C = B; g.ldc = ldb; g.lower_only = true;
+        g.even_offs = true;                                       // offsets are multiples of 128 rows and columns
+        g.M = n - (k + 1) * NB; g.batch = cnt;
+        g.d_offs = offs + (size_t)k * Ly.maxb * 3; g.d_dims = dims + (size_t)k * Ly.maxb * 3;
+        gemm(st, g);
+      }
+    }
+  };
   (void)hipEventRecord(evFork, s);
   (void)hipStreamWaitEvent(s2, evFork, 0);
-  factor_panel(s2, 0);
+  factor_outer(s2, 0);
   (void)hipEventRecord(evP[0], s2);
-  for (int k = 0; k + 1 < NRB; ++k) {
-    const int nbk = (n - k * NB < NB) ? n - k * NB : NB;
-    (void)hipStreamWaitEvent(s, evP[k & 1], 0);                 // block column k is factored
-    GemmDesc g{};
-    g.N = NB; g.K = nbk; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
-    g.A = B; g.lda = ldb; g.B = B; g.ldb = ldb; g.C = B; g.ldc = ldb; g.lower_only = true;
-    g.even_offs = true;                                        // offsets are multiples of 128 rows and columns
-    const long long *po = offs + (size_t)k * Ly.maxb * 3;
-    const int *pd = dims + (size_t)k * Ly.maxb * 3;
-    // block column k+1 first, so that its factorisation can start ...
-    g.M = n - (k + 1) * NB; g.batch = 1; g.d_offs = po; g.d_dims = pd;
-    gemm(s, g);
-    (void)hipEventRecord(evU[(k + 1) & 1], s);
-    (void)hipStreamWaitEvent(s2, evU[(k + 1) & 1], 0);
-    factor_panel(s2, k + 1);
-    (void)hipEventRecord(evP[(k + 1) & 1], s2);
-    // ... while block column k is applied to the block columns behind it
-    const int rest = NRB - (k + 2);
-    if (rest > 0) {
-      g.M = n - (k + 2) * NB; g.batch = rest; g.d_offs = po + 3; g.d_dims = pd + 3;
-      gemm(s, g);
-    }
+  for (int o = 0; o + 1 < NOB; ++o) {
+    const int c0 = o * ob * NB, c1 = (o + 1) * ob * NB, kw = c1 - c0;       // c1 < n here
+    const int m2 = n - c1;
+    const int wnext = (m2 < ob * NB) ? m2 : ob * NB;                        // width of the next outer panel
+    (void)hipStreamWaitEvent(s, evP[o & 1], 0);                             // panel o is factored
+    const double *P = B + (size_t)c1 + (size_t)c0 * ldb;                    // L(c1:, c0:c1)
+    double *C = B + (size_t)c1 + (size_t)c1 * ldb;
+    gemm(s, false, true, m2, wnext, kw, -1.0, P, ldb, P, ldb, 1.0, C, ldb, true);
+    (void)hipEventRecord(evU[(o + 1) & 1], s);
+    (void)hipStreamWaitEvent(s2, evU[(o + 1) & 1], 0);
+    factor_outer(s2, o + 1);
+    (void)hipEventRecord(evP[(o + 1) & 1], s2);
+    if (m2 > wnext)
+      gemm(s, false, true, m2 - wnext, m2 - wnext, kw, -1.0, P + wnext, ldb, P + wnext, ldb, 1.0,
+           C + (size_t)wnext + (size_t)wnext * ldb, ldb, true);
   }
-  (void)hipStreamWaitEvent(s, evP[(NRB - 1) & 1], 0);
+  (void)hipStreamWaitEvent(s, evP[(NOB - 1) & 1], 0);
   hipLaunchKernelGGL(info_to_double_kernel, dim3(ceil_div(NRB, 256)), dim3(256), 0, s, NRB, infos, infod);
   hipLaunchKernelGGL(first_info_kernel, dim3(1), dim3(64), 0, s, NRB, infod, d_info);
 }
