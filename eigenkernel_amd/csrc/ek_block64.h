@@ -16,13 +16,10 @@ constexpr int IMG = SB * LD; // doubles per image
 constexpr int kScratch = 16 * LD;   // doubles of LDS scratch the factorisations below ask for
 
 // C = op(A) op(B), all 64x64 LDS images, on the matrix cores, by the 4 waves of the workgroup:
-// wave w owns rows 16 w .. 16 w + 15 of C.  Callers synchronise before and after.
-// out_g != nullptr: C goes to global memory (column-major, ld 64), row i scaled by rs[i] if rs.
-__device__ __forceinline__ void mm64(const double *sA, bool ta, const double *sB, bool tb, double *sC,
-                                     double *out_g = nullptr, const double *rs = nullptr) {
+// wave w owns rows 16 w .. 16 w + 15 of C; acc[jt][r] is C(16 w + l4 + 4 r, 16 jt + l15).
+__device__ __forceinline__ void mm64_acc(const double *sA, bool ta, const double *sB, bool tb, double4_t (&acc)[4]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int i0 = 16 * wave;
-  double4_t acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   for (int kk = 0; kk < SB; kk += 4) {
@@ -33,13 +30,29 @@ __device__ __forceinline__ void mm64(const double *sA, bool ta, const double *sB
       acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[jt], 0, 0, 0);
     }
   }
+}
+__device__ __forceinline__ void mm64_store(const double4_t (&acc)[4], double *sC) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sC[(16 * wave + l4 + 4 * r) * LD + 16 * jt + l15] = acc[jt][r];
+}
+// Callers synchronise before and after.
+// out_g != nullptr: C goes to global memory (column-major, ld 64), row i scaled by rs[i] if rs.
+__device__ __forceinline__ void mm64(const double *sA, bool ta, const double *sB, bool tb, double *sC,
+                                     double *out_g = nullptr, const double *rs = nullptr) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int i0 = 16 * wave;
+  double4_t acc[4];
+  mm64_acc(sA, ta, sB, tb, acc);
+  if (!out_g) { mm64_store(acc, sC); return; }
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + l4 + 4 * r, j = 16 * jt + l15;
-      if (out_g) out_g[i + SB * j] = rs ? rs[i] * acc[jt][r] : acc[jt][r];
-      else sC[i * LD + j] = acc[jt][r];
+      out_g[i + SB * j] = rs ? rs[i] * acc[jt][r] : acc[jt][r];
     }
 }
 

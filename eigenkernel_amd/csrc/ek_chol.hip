@@ -22,7 +22,7 @@ namespace ek {
 namespace {
 
 constexpr int NB = kDiagNB;   // 128
-constexpr size_t kDiagLds = 4 * b64::IMG * sizeof(double);   // dynamic LDS of potrf_diag_kernel
+constexpr size_t kDiagLds = 2 * b64::IMG * sizeof(double);   // dynamic LDS of potrf_diag_kernel
 
 // One workgroup: B(0:nb,0:nb) = L L^T and inv(L), for a 128x128 diagonal block (nb <= 128; positions
 // outside nb behave as the identity so that short edge blocks need no special casing).
@@ -35,15 +35,21 @@ constexpr size_t kDiagLds = 4 * b64::IMG * sizeof(double);   // dynamic LDS of p
 //   R11 = chol(B11), X11 = R11^-1, R12 = X11^T B12, R22 = chol(B22 - R12^T R12), X22 = R22^-1,
 //   X12 = -X11 R12 X22;      L = R^T,  inv(L) = [X11 X12; 0 X22]^T.
 // This kernel is the serial chain of the factorisation (one launch per 128 columns, each waiting for
-// the previous trailing update), which is why it is built for latency.
+// the previous trailing update), which is why it is built for latency -- and for a small footprint: TWO LDS
+// images (76 KB with the scratch; X11 R12 waits in registers for X22).  With four images (144 KB) the
+// workgroup could only start on a CU that both resident workgroups of the trailing update's GEMM had left,
+// and the GEMM refilled every slot that came free first: the launch took 150 - 750 us instead of 60
+// (tools/potrf_trace.sh) for as long as an update was running beside it; it takes 110 - 250 now.  (Measured
+// without effect on that: s_setprio(3) in this kernel; the updates on a stream whose CU mask leaves 1, 2 or 4
+// CUs per XCD to the panel stream -- 36.6 -> 37.5 - 37.8 ms for the factorisation.)
 // inv (128x128, column-major): inv(L)(i,c) for i > c, 1/L(c,c) on the diagonal, zeros above.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(int nb, double *B, int ldb, double *inv, int *info,
                                                          int info_base) {
   using namespace b64;
   extern __shared__ double smem[];
-  double *sA = smem, *sB = smem + IMG, *sC = smem + 2 * IMG, *sD = smem + 3 * IMG;
-  __shared__ double s_inv[kScratch];
-  const int t = threadIdx.x;
+  double *sP = smem, *sQ = smem + IMG;
+  __shared__ double s_scr[kScratch];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
   // element (gr, gc), gr <= gc, of the symmetric block from its lower triangle
   auto upper = [&](int gr, int gc) -> double {
     if (gc < nb) return B[(size_t)gc + (size_t)gr * ldb];
@@ -56,48 +62,62 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(int nb, double *B, int 
   };
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int c = idx & 63, r = idx >> 6;
-    sA[r * LD + c] = (c >= r) ? upper(r, c) : 0.0;        // B11
-    sC[r * LD + c] = upper(r, 64 + c);                     // B12
+    sP[r * LD + c] = (c >= r) ? upper(r, c) : 0.0;        // B11
   }
   __syncthreads();
-  int fail = chol64_upper_wg(sA, s_inv);                    // sA = R11
+  int fail = chol64_upper_wg(sP, s_scr);                   // P = R11
   if (fail >= 0) { fail_exit(fail); return; }
-  triinv64_upper_wg(sA, sB, s_inv);                         // sB = X11
+  triinv64_upper_wg(sP, sQ, s_scr);                        // Q = X11
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
-    if (i >= j && i < nb) B[(size_t)i + (size_t)j * ldb] = sA[j * LD + i];                  // L11
-    inv[i + NB * j] = (i >= j) ? sB[j * LD + i] : 0.0;
+    if (i >= j && i < nb) B[(size_t)i + (size_t)j * ldb] = sP[j * LD + i];                  // L11
+    inv[i + NB * j] = (i >= j) ? sQ[j * LD + i] : 0.0;
     inv[i + NB * (64 + j)] = 0.0;
   }
-  mm64(sB, true, sC, false, sD);                           // sD = R12 = X11^T B12
-  __syncthreads();
-  for (int idx = t; idx < SB * SB; idx += 256) {
-    const int i = idx & 63, j = idx >> 6;
-    if (64 + i < nb) B[(size_t)(64 + i) + (size_t)j * ldb] = sD[j * LD + i];                // L21
-  }
-  mm64(sD, true, sD, false, sC);                           // sC = R12^T R12
   __syncthreads();
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int c = idx & 63, r = idx >> 6;
-    sA[r * LD + c] = (c >= r) ? upper(64 + r, 64 + c) - sC[r * LD + c] : 0.0;
+    sP[r * LD + c] = upper(r, 64 + c);                     // P = B12
   }
   __syncthreads();
-  fail = chol64_upper_wg(sA, s_inv);                        // sA = R22
-  if (fail >= 0) { fail_exit(64 + fail); return; }
-  triinv64_upper_wg(sA, sC, s_inv);                         // sC = X22
+  double4_t acc[4], Z[4];
+  mm64_acc(sQ, true, sP, false, acc);                      // R12 = X11^T B12
+  __syncthreads();
+  mm64_store(acc, sP);                                     // P = R12
+  __syncthreads();
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
-    if (i >= j && 64 + i < nb) B[(size_t)(64 + i) + (size_t)(64 + j) * ldb] = sA[j * LD + i];   // L22
-    inv[(64 + i) + NB * (64 + j)] = (i >= j) ? sC[j * LD + i] : 0.0;
+    if (64 + i < nb) B[(size_t)(64 + i) + (size_t)j * ldb] = sP[j * LD + i];                // L21
+  }
+  mm64_acc(sQ, false, sP, false, Z);                       // Z = X11 R12, kept in registers until X22 exists
+  mm64_acc(sP, true, sP, false, acc);                      // R12^T R12
+  __syncthreads();
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                          // Q = B22 - R12^T R12 (upper part)
+      const int i = 16 * wave + l4 + 4 * r, j = 16 * jt + l15;
+      sQ[i * LD + j] = (j >= i) ? upper(64 + i, 64 + j) - acc[jt][r] : 0.0;
+    }
+  __syncthreads();
+  fail = chol64_upper_wg(sQ, s_scr);                       // Q = R22
+  if (fail >= 0) { fail_exit(64 + fail); return; }
+  triinv64_upper_wg(sQ, sP, s_scr);                        // P = X22
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    if (i >= j && 64 + i < nb) B[(size_t)(64 + i) + (size_t)(64 + j) * ldb] = sQ[j * LD + i];   // L22
+    inv[(64 + i) + NB * (64 + j)] = (i >= j) ? sP[j * LD + i] : 0.0;
   }
   __syncthreads();
-  mm64(sB, false, sD, false, sA);                          // sA = X11 R12
+  mm64_store(Z, sQ);                                       // Q = X11 R12
   __syncthreads();
-  mm64(sA, false, sC, false, sD);                          // sD = X11 R12 X22 = -X12
+  mm64_acc(sQ, false, sP, false, acc);                     // X11 R12 X22 = -X12
+  __syncthreads();
+  mm64_store(acc, sQ);
   __syncthreads();
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, c = idx >> 6;
-    inv[(64 + i) + NB * c] = -sD[c * LD + i];
+    inv[(64 + i) + NB * c] = -sQ[c * LD + i];
   }
 }
 
