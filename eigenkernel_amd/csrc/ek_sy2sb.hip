@@ -178,10 +178,11 @@ __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G,
   __shared__ double sA[IMG], sB[IMG];
   __shared__ double s_inv[kScratch];
   const int t = threadIdx.x;
-  for (int idx = t; idx < SB * SB; idx += 256) {
-    const int j = idx & 63, i = idx >> 6;
-    sA[i * LD + j] = G[idx];
-  }
+  double gv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) gv[k] = G[t + 256 * k];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { const int idx = t + 256 * k; sA[(idx >> 6) * LD + (idx & 63)] = gv[k]; }
   __syncthreads();
   if (chol64_upper_wg(sA, s_inv) >= 0 && t == 0) atomicExch(flag, 1);
   triinv64_upper_wg(sA, sB, s_inv);
@@ -212,16 +213,21 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   if (prof) tc[nt++] = clock64();
   // G2 and its distance from the identity: the loss of orthogonality of the first pass
   double dev = 0.0;
-  for (int idx = t; idx < SB * SB; idx += 256) {
-    const int j = idx & 63, i = idx >> 6;
-    const double g = p.G2[idx];
-    sA[i * LD + j] = g;
-    const double e = fabs(g - (i == j ? 1.0 : 0.0));
-    dev = (e > dev || e != e) ? e : dev;
+  double gv[16], qv[16], r1v[16];               // all loads of the kernel in flight at once; R1 is used last
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int idx = t + 256 * k;
+    gv[k] = p.G2[idx];
+    qv[k] = p.Qt[(size_t)(idx & 63) + (size_t)(idx >> 6) * p.ldq];
+    r1v[k] = p.R1[idx];
   }
-  for (int idx = t; idx < SB * SB; idx += 256) {                        // sC = top block of Qt
-    const int i = idx & 63, j = idx >> 6;
-    sC[i * LD + j] = p.Qt[(size_t)i + (size_t)j * p.ldq];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int idx = t + 256 * k, lo = idx & 63, hi = idx >> 6;
+    sA[hi * LD + lo] = gv[k];                                             // G2(i = hi, j = lo)
+    const double e = fabs(gv[k] - (lo == hi ? 1.0 : 0.0));
+    dev = (e > dev || e != e) ? e : dev;
+    sC[lo * LD + hi] = qv[k];                                             // top block of Qt, (i = lo, j = hi)
   }
   for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(dev, o, 64); dev = (y > dev || y != y) ? y : dev; }
   if (lane == 0) s_red[wave] = dev;
@@ -255,9 +261,10 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   __syncthreads();
   triinv64_upper_wg(sD, sC, s_inv);                                      // sC = U^-1
   if (prof) tc[nt++] = clock64();
-  for (int idx = t; idx < SB * SB; idx += 256) {                        // sD = R1
-    const int i = idx & 63, j = idx >> 6;
-    sD[i * LD + j] = p.R1[idx];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {                                        // sD = R1
+    const int idx = t + 256 * k;
+    sD[(idx & 63) * LD + (idx >> 6)] = r1v[k];
   }
   if (prof) tc[nt++] = clock64();
   __syncthreads();
@@ -556,42 +563,42 @@ __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
   store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
 }
 
-// G = sum of the partials of V^T Y; Mw = [T ; -1/2 T^T G T] (128 x 64, column-major ld 128)
-__global__ __launch_bounds__(256) void wmat_kernel(const double *__restrict__ Gred,
-                                                   const double *__restrict__ T, double *__restrict__ Mw) {
-  __shared__ double sG[IMG], sT[IMG], sX[IMG];
-  const int t = threadIdx.x;
-  for (int idx = t; idx < SB * SB; idx += 256) {
-    const int j = idx & 63, i = idx >> 6;       // stored (j + 64 i) = G(i, j)
-    sG[i * LD + j] = Gred[idx];
-    const double tv = T[idx];                 // column-major: idx = i' + 64 j'
-    sT[(idx & 63) * LD + (idx >> 6)] = tv;
-    Mw[(idx & 63) + 128 * (idx >> 6)] = tv;
-  }
-  __syncthreads();
-  mm64(sG, false, sT, false, sX);             // X = G T
-  __syncthreads();
-  mm64(sT, true, sX, false, sG);              // S' = T^T X
-  __syncthreads();
-  for (int idx = t; idx < SB * SB; idx += 256) {
-    const int i = idx & 63, j = idx >> 6;
-    Mw[64 + i + 128 * j] = -0.5 * sG[i * LD + j];
-  }
-}
-
-// W = [Y | V] Mw, written to columns 0..63 and 128..191 of the image [W | V | W]
+// W = [Y | V] [T ; -1/2 T^T G T], G = V^T Y (the sum of yred_kernel's partials), written to columns 0..63 and
+// 128..191 of the image [W | V | W].  Every workgroup forms the 128 x 64 multiplier itself (two 64^3 products
+// on the matrix cores: less than the launch of a kernel that would do it once).
 struct WArgs {
   int m;
-  const double *Y; int ldy; const double *V; int ldv; const double *Mw;
+  const double *Y; int ldy; const double *V; int ldv;
+  const double *Gred;        // G, stored (j + 64 i) = G(i, j)
+  const double *T;           // column-major, ld 64
   double *Vimg; int ldi;
 };
 __global__ __launch_bounds__(256) void w_kernel(WArgs p) {
   __shared__ double sS[IMG], sM1[IMG], sM2[IMG];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4, r = t & 63, cg = t >> 6;
-  for (int idx = t; idx < SB * SB; idx += 256) {
-    const int k = idx & 63, j = idx >> 6;
-    sM1[j * LD + k] = p.Mw[k + 128 * j];
-    sM2[j * LD + k] = p.Mw[64 + k + 128 * j];
+  {
+    double gv[16], tv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { gv[k] = p.Gred[t + 256 * k]; tv[k] = p.T[t + 256 * k]; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int idx = t + 256 * k, lo = idx & 63, hi = idx >> 6;
+      sM2[hi * LD + lo] = gv[k];             // G(i = hi, j = lo)
+      sS[lo * LD + hi] = tv[k];              // T(i = lo, j = hi), natural
+      sM1[hi * LD + lo] = tv[k];             // image of T for the products below: sM1[j][k] = T(k, j)
+    }
+    __syncthreads();
+    double4_t acc[4];
+    mm64_acc(sM2, false, sS, false, acc);    // X = G T
+    __syncthreads();
+    mm64_store(acc, sM2);
+    __syncthreads();
+    mm64_acc(sS, true, sM2, false, acc);     // T^T X
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sM2[(16 * jt + l15) * LD + 16 * wave + l4 + 4 * q] = -0.5 * acc[jt][q];   // sM2[j][k] = -1/2 (T^T G T)(k, j)
   }
   for (int slab = 0; slab < CH / SB; ++slab) {
     const int row0 = blockIdx.x * CH + slab * SB;
@@ -685,7 +692,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   double *Ypart = (double *)(w + L.off_ypart), *Gpart = (double *)(w + L.off_gpart);
   double *sm = (double *)(w + L.off_small);
   double *Gred = sm, *R1 = sm + 4096, *R1inv = sm + 2 * 4096, *M2 = sm + 3 * 4096, *Tm[2] = {sm + 4 * 4096, sm + 9 * 4096},
-         *L1 = sm + 5 * 4096, *Rband = sm + 6 * 4096, *Mw = sm + 7 * 4096 /* 2 x 4096 */;
+         *L1 = sm + 5 * 4096, *Rband = sm + 6 * 4096;
   // panel-chain scratch of the look-ahead stream (its Gram partials must not meet those of yred)
   double *Gpart2 = (double *)(w + L.off_gpart2), *Gred2 = sm + 11 * 4096;
   const int ldi = L.mpad;
@@ -749,8 +756,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     YredArgs ya{m, nsplit, Ypart, L.mpad, (long long)L.mpad * SB, Y, V, ldi, Gpart};
     hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s, nch, Gpart, Gred);
-    hipLaunchKernelGGL(wmat_kernel, dim3(1), dim3(256), 0, s, Gred, Tm[cur], Mw);
-    WArgs wa{m, Y, L.mpad, V, ldi, Mw, Vimg, ldi};
+    WArgs wa{m, Y, L.mpad, V, ldi, Gred, Tm[cur], Vimg, ldi};
     hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
     // A22 -= W V^T + V W^T = [W | V] [V | W]^T, lower triangle.  With look-ahead the first block column is
     // updated first and the NEXT panel is factored on the second stream while the rest is updated.
