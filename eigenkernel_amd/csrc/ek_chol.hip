@@ -41,7 +41,9 @@ constexpr size_t kDiagLds = 2 * b64::IMG * sizeof(double);   // dynamic LDS of p
 // and the GEMM refilled every slot that came free first: the launch took 150 - 750 us instead of 60
 // (tools/potrf_trace.sh) for as long as an update was running beside it; it takes 110 - 250 now.  (Measured
 // without effect on that: s_setprio(3) in this kernel; the updates on a stream whose CU mask leaves 1, 2 or 4
-// CUs per XCD to the panel stream -- 36.6 -> 37.5 - 37.8 ms for the factorisation.)
+// CUs per XCD to the panel stream -- 36.6 -> 37.5 - 37.8 ms for the factorisation; the block column solved in
+// place by 128-row workgroups instead of gemm + copy -- 36.4 vs 36.6; the trailing update held to one workgroup
+// per CU by an LDS pad -- 41.4.)
 // inv (128x128, column-major): inv(L)(i,c) for i > c, 1/L(c,c) on the diagonal, zeros above.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(int nb, double *B, int ldb, double *inv, int *info,
                                                          int info_base) {
