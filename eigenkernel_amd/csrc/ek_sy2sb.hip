@@ -698,6 +698,11 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   const int ldi = L.mpad;
   const bool prof = getenv("EK_SY2SB_PROF") != nullptr;
   if (prof) (void)hipMemsetAsync(sm + 10 * 4096, 0, 128, s);
+  // rest of the trailing update: below 8192 rows the staged rank-k kernel (one workgroup per CU: the panel chain
+  // of the look-ahead finds room beside it), above the plain 8-wave GEMM (two per CU, 33 against 27 - 32 TFLOP/s
+  // alone; the chain is short against the update there).  N = 16384: 0.2025 -> 0.1949 s, N = 32768: 1.364 -> 1.278 s.
+  static int staged_max = -1;
+  if (staged_max < 0) { const char *e = getenv("EK_SY2SB_STAGED_MAX"); staged_max = e ? atoi(e) : 8192; }
   static int la_min = -1;
   if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 5120; }
 
@@ -769,7 +774,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
       panel_chain(s2, r0, img[cur ^ 1], Tm[cur ^ 1]);
       (void)hipEventRecord(evB[cur ^ 1], s2);
       gemm(s, false, true, m - SB, m - SB, 2 * SB, -1.0, P1 + SB, ldi, P2 + SB, ldi, 1.0,
-           A22 + (size_t)SB + (size_t)SB * lda, lda, true, /*staged_rank_k=*/true);
+           A22 + (size_t)SB + (size_t)SB * lda, lda, true, /*staged_rank_k=*/m < staged_max);
       waited = false;
     } else {
       gemm(s, false, true, m, m, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true);
