@@ -28,7 +28,7 @@ the ranks there are).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline"        : the dominant kernel, timed live with HIP events on its launch stream in the
-                      timed region: with the two-stage tridiagonalisation (orders >= 2048) the
+                      timed region: with the two-stage tridiagonalisation (orders >= 512) the
                       MFMA-bound application of the bulge-chasing reflectors (q2_apply_kernel),
                       else the HBM-bound symv of the one-stage reduction;
   "roofline_stages" : per stage of the path, algorithmic flops / device seconds

@@ -277,16 +277,17 @@ constexpr int kPotrfRlMin = 1024;
 // cores, band -> tridiagonal by bulge chasing; ek_sy2sb.hip, ek_sb2st.hip) instead of the one-stage
 // Householder reduction.  EK_HIP_TWO_STAGE_MIN overrides (0 = never); ek_hip_debug_set_two_stage too.
 // Measured with tools/crossover.py (standard problem, full spectrum, one-stage / two-stage seconds):
-// 512: 0.0099 / 0.0090, 1024: 0.0190 / 0.0174, 2048: 0.0388 / 0.0357, 4096: 0.0914 / 0.0799,
-// 8192: 0.3065 / 0.2193 -- the two-stage form is ahead at every order; below 2048 the difference is a
-// millisecond or two and the whole-path call keeps the one-stage form, whose by-products (PDSYTRD's
-// reflectors in A) are what a caller of the reference finds there.
+// 512: 0.0100 / 0.0074, 1024: 0.0190 / 0.0142, 2048: 0.0388 / 0.0290, 4096: 0.0914 / 0.066,
+// 8192: 0.3065 / 0.19 -- the two-stage form is ahead by a quarter and more from 512 on (at the start of
+// round 2 the difference below 2048 was a millisecond or two and the crossover stood at 2048).  Below 512 the
+// whole-path call keeps the one-stage form, whose by-products (PDSYTRD's reflectors in A) are what a caller
+// of the reference finds there; INTEGRATION.md says what A holds after a two-stage solve.
 int g_two_stage_min = -1;
 int two_stage_min() {
   if (g_two_stage_min >= 0) return g_two_stage_min;
   static int env = -2;
   if (env == -2) { const char *e = getenv("EK_HIP_TWO_STAGE_MIN"); env = e ? atoi(e) : -1; }
-  return env >= 0 ? env : 2048;
+  return env >= 0 ? env : 512;
 }
 
 // From how many ranks on the Cholesky factor and the reduction to standard form are distributed

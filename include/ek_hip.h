@@ -254,7 +254,7 @@ int ek_hip_check(int what, int problem, int n, int n_cols, int index1, int index
                  const double *w, const double *Z_loc, const int desc_Z[9], double *out);
 
 /* Which tridiagonalisation the whole-path calls use is an implementation detail behind the results
- * contract: orders >= 2048 (EK_HIP_TWO_STAGE_MIN overrides, 0 = never) go dense -> band -> tridiagonal
+ * contract: orders >= 512 (EK_HIP_TWO_STAGE_MIN overrides, 0 = never) go dense -> band -> tridiagonal
  * (two stages, all O(n^3) work on the matrix cores), smaller ones take the one-stage Householder
  * reduction that ek_hip_sytrd exposes with PDSYTRD's own output convention.  With two stages A_loc
  * returns the band and the first stage's R factors instead of PDSYTRD's reflectors (the reference
