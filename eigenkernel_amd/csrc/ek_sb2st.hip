@@ -73,10 +73,21 @@ __device__ __forceinline__ double lane_value(double v, int l) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
-// sum over the wave, result in every lane
+// sum over the wave, result in every lane.  The four row sums meet by two DPP row broadcasts (lane 15 of a row
+// into the next row, lane 31 into rows 2 and 3) and ONE v_readlane pair of lane 63 -- a pair costs about 40
+// cycles and four of them do not overlap (measured in ek_block64.h); the value is (r2 + r3) + (r0 + r1), the
+// same bits as (r0 + r1) + (r2 + r3).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov_rows(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
   v = group_sum<16>(v);
-  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+  v += dpp_mov_rows<0x142, 0xA>(v);        // row_bcast15: rows 1 and 3 += the sum of the row before
+  v += dpp_mov_rows<0x143, 0xC>(v);        // row_bcast31: rows 2 and 3 += r0 + r1
+  return lane_value(v, 63);
 }
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -168,7 +179,7 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
   constexpr int CW = SB / NW;            // columns of a block per wave
   constexpr int LPC = 64 / CW;           // lanes that share one column in the transposed reduction
-  __shared__ double s_v[2][SB];
+  __shared__ __attribute__((aligned(16))) double s_v[2][SB];
   __shared__ double s_p[NW][SB], s_q[NW][SB];
   __shared__ double s_t[NW][CW * 65];
   __shared__ double s_D[SB * DLD];
@@ -247,7 +258,8 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       const double v_r = s_v[cur][lane];
       double vc[CW];
 #pragma unroll
-      for (int j = 0; j < CW; ++j) vc[j] = lane_value(v_r, c0w + j);   // (a lane per row: v of column c is lane c's)
+      for (int j = 0; j < CW; ++j) vc[j] = s_v[cur][c0w + j];          // broadcast reads (16-byte pairs): 0.1286 -> 0.1272 s
+                                                                       // at N = 16384 against eight v_readlane pairs of v_r
       // ---- the late numbers of the previous sweep's task k+1: our last column of B_k and the corner of D_k
       if (lead && wave == NW - 1) {
         unsigned spins = 0;
