@@ -365,11 +365,24 @@ __global__ void dc_rotate_kernel(int mbeg, DcBufs b, double *__restrict__ W, int
 // ------------------------------------------------------------------ merge step 4: secular equation (DLAED4)
 // root i of 1 + rho * sum_j z_j^2 / (d_j - lambda) = 0 in shifted form lambda = d_K + tau,
 // K the nearer pole, so that d_j - lambda_i = (d_j - d_K) - tau keeps full relative accuracy.
-constexpr int SP = 4;   // lanes that share one root (they split the sum over the poles)
+#ifndef EK_DC_SP
+#define EK_DC_SP 64
+#endif
+// lanes that share one root / one weight (they split the sum or product over the poles): a whole wave.  A lane's
+// pass over its poles is a chain of dependent-latency loads of d and z (L2) with a division each; with 4 lanes
+// per root the top merge of N = 16384 took 6 ms in the secular kernel alone.  stedc at N = 16384, same box:
+// SP = 4: 0.0862 s (0.0911 with one lane per Loewner weight as well), 8: 0.0797, 16: 0.0769, 32: 0.0735, 64: 0.0728.
+constexpr int SP = EK_DC_SP;
 
+// butterfly: every lane of the group ends with the same bits
 __device__ __forceinline__ double group_sum(double v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
+#pragma unroll
+  for (int o = 1; o < SP; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double group_prod(double v) {
+#pragma unroll
+  for (int o = 1; o < SP; o <<= 1) v *= __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -472,18 +485,20 @@ __global__ void dc_secular_kernel(int mbeg, DcBufs b) {
 __global__ void dc_zhat_kernel(int mbeg, DcBufs b) {
   const int mi = mbeg + blockIdx.y;
   const Merge mg = b.merges[mi];
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = gid / SP, sub = gid % SP;          // SP lanes share one weight (they split the product)
   const int k = b.k[mi];
   if (j >= k) return;
   const double *dl = b.dl + mg.off, *tauv = b.tauv + mg.off;
   const int *korig = b.korig + mg.off;
   const double dj = dl[j];
   double p = 1.0;
-  for (int i = 0; i < k; ++i) {
+  for (int i = sub; i < k; i += SP) {
     const double del = (dj - dl[korig[i]]) - tauv[i];   // d_j - lambda_i
     p *= (i == j) ? del : del / (dj - dl[i]);
   }
-  b.zhat[mg.off + j] = copysign(sqrt(fabs(p)), b.zl[mg.off + j]);
+  p = group_prod(p);
+  if (sub == 0) b.zhat[mg.off + j] = copysign(sqrt(fabs(p)), b.zl[mg.off + j]);
 }
 
 // Column c < k of S: the normalised eigenvector of the rank-one update, entry of pole a stored
@@ -727,7 +742,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     hipLaunchKernelGGL(dc_permute_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, Q, ldq, W, ldz);
     hipLaunchKernelGGL(dc_rotate_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, W, ldz);
     hipLaunchKernelGGL(dc_secular_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
-    hipLaunchKernelGGL(dc_zhat_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b);
+    hipLaunchKernelGGL(dc_zhat_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
     if (selecting && lv + 1 == plan.levels.size()) {
       // Top merge (off = 0, order n): every eigenvalue is known now, so the final order can be
       // fixed before the eigenvector product and only the selected columns are multiplied,
