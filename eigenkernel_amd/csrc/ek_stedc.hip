@@ -9,7 +9,7 @@
 //   * leaves (order <= 32): implicit QL, one wavefront per leaf, Z block in LDS;
 //   * a merge is: rank-sort of the poles -> deflation scan (DLAED2, incl. the column types
 //     top-only / dense / bottom-only) -> column permutation + Givens rotations -> secular
-//     equation (4 lanes per root, origin shifted to the nearer pole) -> Loewner weights ->
+//     equation (a wave per root, origin shifted to the nearer pole) -> Loewner weights ->
 //     eigenvector matrix S of the rank-one update -> ONE batched MFMA launch per tree height
 //     holding two GEMMs per merge, Q(top) = W(top, [top|dense]) S and Q(bottom) =
 //     W(bottom, [dense|bottom]) S, whose sizes and offsets (functions of the deflation
@@ -147,19 +147,29 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const Leaf *__restrict__ le
 }
 
 // ------------------------------------------------------------------ merge step 1: z and rank sort
+constexpr int RP = 16;   // lanes that share one element of a rank sort (they split the comparisons)
+__device__ __forceinline__ int rank_sum(int v) {
+#pragma unroll
+  for (int o = 1; o < RP; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 __global__ void dc_sort_kernel(int mbeg, DcBufs b, const double *__restrict__ Q, int ldq) {
   const Merge mg = b.merges[mbeg + blockIdx.y];
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = gid / RP, sub = gid % RP;
   if (t >= mg.n) return;
   const double *d = b.d + mg.off;
   // NaN (numerical breakdown upstream) sorts as +inf so that ranks stay a permutation and
   // every later index stays in bounds; the breakdown is reported through info at the end
   const double dt = (d[t] == d[t]) ? d[t] : INFINITY;
   int rank = 0;
-  for (int i = 0; i < mg.n; ++i) {
+  for (int i = sub; i < mg.n; i += RP) {
     const double di = (d[i] == d[i]) ? d[i] : INFINITY;
     rank += (di < dt || (di == dt && i < t)) ? 1 : 0;
   }
+  rank = rank_sum(rank);
+  if (sub != 0) return;
   const double rho_in = b.e[mg.off + mg.n1 - 1];
   const double is2 = 0.70710678118654752440;
   double z;
@@ -543,15 +553,18 @@ __global__ void dc_copy_deflated_kernel(int mbeg, DcBufs b, const double *__rest
 // ------------------------------------------------------------------ final ordering
 __global__ void dc_final_rank_kernel(int n, DcBufs b, double *__restrict__ w, int *__restrict__ perm,
                                      int *info) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = gid / RP, sub = gid % RP;
   if (t >= n) return;
   const double raw = b.d[t];
   const double dt = (raw == raw) ? raw : INFINITY;
   int rank = 0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = sub; i < n; i += RP) {
     const double di = (b.d[i] == b.d[i]) ? b.d[i] : INFINITY;
     rank += (di < dt || (di == dt && i < t)) ? 1 : 0;
   }
+  rank = rank_sum(rank);
+  if (sub != 0) return;
   w[rank] = raw * b.orgnrm[0];
   perm[rank] = t;
   if (!(fabs(raw) <= 1.7e308)) atomicMax(info, n + 1);   // NaN / Inf eigenvalue: breakdown
@@ -736,7 +749,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     bool even = ((ldz | ldq | lds) & 1) == 0;      // every merge of this height starts on even rows and columns
     for (auto &m : plan.levels[lv]) { maxn = std::max(maxn, m.n); even = even && ((m.off | m.n1) & 1) == 0; }
     const int gx = ceil_div(maxn, 256);
-    hipLaunchKernelGGL(dc_sort_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, Q, ldq);
+    hipLaunchKernelGGL(dc_sort_kernel, dim3(ceil_div(maxn * RP, 256), cnt), dim3(256), 0, s, mbeg, b, Q, ldq);
     hipLaunchKernelGGL(dc_deflate_kernel, dim3(cnt), dim3(256), 0, s, mbeg, b);
     const int gy = std::min(maxn, std::max(1, 4096 / std::max(1, gx * cnt)));
     hipLaunchKernelGGL(dc_permute_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, Q, ldq, W, ldz);
@@ -748,7 +761,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
       // fixed before the eigenvector product and only the selected columns are multiplied,
       // straight into their final positions.
       int *selcol = b.rotp;               // the rotation list is spent once dc_rotate has run
-      hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, b, w, fperm, d_info);
+      hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n * RP, 256)), dim3(256), 0, s, n, b, w, fperm, d_info);
       sel_done = true;
       if (sel->nsel <= 0) break;
       hipLaunchKernelGGL(dc_select_kernel, dim3(ceil_div(sel->nsel, 256)), dim3(256), 0, s, *sel, fperm, selcol,
@@ -781,7 +794,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldz, Q, ldq);
   }
   if (sel_done) return;
-  hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, b, w, fperm, d_info);
+  hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n * RP, 256)), dim3(256), 0, s, n, b, w, fperm, d_info);
   if (selecting) {
     // no merge at all (a single leaf): pick the selected columns out of the leaf's eigenvectors
     if (sel->nsel <= 0) return;
