@@ -331,6 +331,27 @@ __global__ void full_from_lower_kernel(int n, const double *__restrict__ src, in
   for (int j = blockIdx.y; j < n; j += gridDim.y)
     dst[(size_t)i + (size_t)j * ldd] = (i >= j) ? src[(size_t)i + (size_t)j * lds] : src[(size_t)j + (size_t)i * lds];
 }
+// A(i, j) -= M(i, j) + M(j, i) for i >= j (n x n): the two halves of a SYR2K whose product M = X Y^T was formed
+// once, in full.  32 x 32 tiles, the mirrored tile through LDS.
+__global__ __launch_bounds__(256) void syr2k_fold_kernel(int n, const double *__restrict__ M, int ldm,
+                                                         double *__restrict__ A, int lda) {
+  __shared__ double sT[32][33];
+  const int bi = blockIdx.x, bj = blockIdx.y;
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                                    // mirrored tile: rows 32 bj.., columns 32 bi..
+    const int r = 32 * bj + tx, c = 32 * bi + ty + 8 * q;
+    sT[ty + 8 * q][tx] = (r < n && c < n) ? M[(size_t)r + (size_t)c * ldm] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = 32 * bi + tx, j = 32 * bj + ty + 8 * q;
+    if (i < n && j < n && i >= j)
+      A[(size_t)i + (size_t)j * lda] -= M[(size_t)i + (size_t)j * ldm] + sT[tx][ty + 8 * q];
+  }
+}
 static inline dim3 grid_mn(int m, int n) { return dim3(ceil_div(m, 256), n < 2048 ? (n > 0 ? n : 1) : 2048); }
 
 // X <- X L^-T where only the lower triangle of the (square, n x n) result is wanted: column
@@ -382,8 +403,19 @@ static void sygst_rec(hipStream_t s, int n, double *A, int lda, const double *L,
   hipLaunchKernelGGL(full_from_lower_kernel, grid_mn(n1, n1), dim3(256), 0, s, n1, A, lda, C11, n1);
   gemm(s, false, false, n2, n1, n1, 1.0, L21, ldl, C11, n1, 0.0, M, n2);
   hipLaunchKernelGGL(axpy_matrix_kernel, grid_mn(n2, n1), dim3(256), 0, s, n2, n1, -0.5, M, n2, A21, lda);
-  gemm(s, false, true, n2, n2, n1, -1.0, A21, lda, L21, ldl, 1.0, A22, lda, /*lower_only=*/true);
-  gemm(s, false, true, n2, n2, n1, -1.0, L21, ldl, A21, lda, 1.0, A22, lda, /*lower_only=*/true);
+  // A22 -= A21 L21^T + L21 A21^T.  As two lower-only products each loses a fifth to its tail (2080 tiles of 2 ms on
+  // 512 workgroup slots at n2 = 8192: 45 TFLOP/s); the same flops as ONE full product P = A21 L21^T (68 TFLOP/s, into
+  // the space of C11, which is spent) and a pass A22 -= P + P^T over the lower triangle.
+  static int fold = -1;
+  if (fold < 0) { const char *e = getenv("EK_SYGST_FOLD"); fold = e ? atoi(e) : 1; }
+  if (fold && n2 <= n1) {
+    double *P = C11;
+    gemm(s, false, true, n2, n2, n1, 1.0, A21, lda, L21, ldl, 0.0, P, n2);
+    hipLaunchKernelGGL(syr2k_fold_kernel, dim3(ceil_div(n2, 32), ceil_div(n2, 32)), dim3(256), 0, s, n2, P, n2, A22, lda);
+  } else {
+    gemm(s, false, true, n2, n2, n1, -1.0, A21, lda, L21, ldl, 1.0, A22, lda, /*lower_only=*/true);
+    gemm(s, false, true, n2, n2, n1, -1.0, L21, ldl, A21, lda, 1.0, A22, lda, /*lower_only=*/true);
+  }
   hipLaunchKernelGGL(axpy_matrix_kernel, grid_mn(n2, n1), dim3(256), 0, s, n2, n1, -0.5, M, n2, A21, lda);
   trsm_lln(s, n2, n1, L22, ldl, inv2, A21, lda, work);
   sygst_rec(s, n2, A22, lda, L22, ldl, inv2, work, scratch);
