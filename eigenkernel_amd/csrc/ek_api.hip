@@ -1579,7 +1579,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   const bool dist = cell && g_comm.on && g_comm.nranks == cell->nprow * cell->npcol;
   if (dist && g_comm.rank != cell->myrow * cell->npcol + cell->mycol) return -994;
   const size_t wb_sytrd = dist ? sytrd_dist_work_bytes(n, g_comm.nranks) : sytrd_work_bytes(n),
-               wb_stedc = stedc_work_bytes(n), wb_ormtr = ormtr_work_bytes(n, nc_loc);
+               wb_stedc = stedc_work_bytes(n), wb_ormtr = ormtr_work_bytes(n, nc_loc, n_vec);
   const size_t mat = al((size_t)ld * ld * 8);
   size_t scratch = wb_sytrd;
   if (wb_stedc > scratch) scratch = wb_stedc;
@@ -1746,9 +1746,9 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     // bulge chasing was measured: the skinny GEMMs take CUs and issue slots from the latency-bound pipeline,
     // which loses 11 ms to gain 6)
     ormtr_prepare(s, n, wV, ld, dt1, q1prep);
-    ormtr_apply(s, n, nc_loc, wV, ld, q1prep, zc, ld, work);
+    ormtr_apply(s, n, nc_loc, wV, ld, q1prep, zc, ld, work, n_vec);
   } else {
-    ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work);
+    ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work, n_vec);
   }
   mark();                                                              // 6
   if (problem == 1) trsm_llt(s, n, nc_loc, wB, ld, dInv, zc, ld, twork);

@@ -244,16 +244,16 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
            int ldz, void *work, int *d_info, const StedcSelect *sel = nullptr);
 
 // ---------------------------------------------------------------- back-transformation (ek_ormtr.hip)
-size_t ormtr_work_bytes(int n, int ncols);
+size_t ormtr_work_bytes(int n, int ncols, int ncols_global = -1);   // ncols_global: columns of the whole Z (a grid cell holds ncols of them)
 // Z(:, 0:ncols) <- Q Z with Q = H(0)...H(n-2) given by explicit V (see sytrd_lower) and tau.
 void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, const double *tau,
-                 double *Z, int ldz, void *work);
+                 double *Z, int ldz, void *work, int ncols_global = -1);
 // the same in two parts: the T factors of the block reflectors (independent of Z; prep >= ormtr_prep_bytes(n)),
 // then their application (work >= ormtr_work_bytes(n, ncols) - ormtr_prep_bytes(n))
 size_t ormtr_prep_bytes(int n);
 void ormtr_prepare(hipStream_t s, int n, const double *V, int ldv, const double *tau, void *prep);
 void ormtr_apply(hipStream_t s, int n, int ncols, const double *V, int ldv, const void *prep, double *Z, int ldz,
-                 void *work);
+                 void *work, int ncols_global = -1);
 // explicit V from the PDSYTRD storage (reflectors below the sub-diagonal of A)
 void build_explicit_v(hipStream_t s, int n, const double *A, int lda, double *V, int ldv);
 // synthetic SPD generator of SURVEY.md 8(d) on the device

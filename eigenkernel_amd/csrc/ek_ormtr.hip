@@ -77,10 +77,33 @@ void build_explicit_v(hipStream_t s, int n, const double *A, int lda, double *V,
                      n, A, lda, V, ldv);
 }
 
-size_t ormtr_work_bytes(int n, int ncols) {
+// W1 = V_b^T Z has KB x ncols outputs and an inner dimension of up to n: with few columns (a selected part of
+// the spectrum) that is a few dozen tiles with a very long K.  Then K is cut into kSplitMax slices at most, one
+// batch entry per slice into its own partial, and the partials are summed in a fixed order.  The slicing is a
+// function of the GLOBAL number of vectors, not of the columns this call holds: a grid cell's piece of the
+// eigenvectors stays bit-identical to the 1 x 1 result.
+constexpr int kSplitMax = 16;
+static int ormtr_split(int ncols_global) {
+  const int tiles = (KB / 128) * ceil_div(ncols_global > 0 ? ncols_global : 1, 128);
+  int S = 512 / tiles;
+  if (S > kSplitMax) S = kSplitMax;
+  return S >= 2 ? S : 1;
+}
+
+size_t ormtr_work_bytes(int n, int ncols, int ncols_global) {
   const int nblk = ceil_div(n > 1 ? n - 1 : 1, KB);
+  const int S = ormtr_split(ncols_global > 0 ? ncols_global : ncols);
   return 2 * al256((size_t)nblk * KB * KB * 8) + al256((size_t)nblk * (KB / 2) * (KB / 2) * 8) +
-         2 * al256((size_t)KB * (ncols > 0 ? ncols : 1) * 8);
+         2 * al256((size_t)KB * (ncols > 0 ? ncols : 1) * 8) +
+         (S > 1 ? al256((size_t)S * KB * (ncols > 0 ? ncols : 1) * 8) : 0);
+}
+
+__global__ void sum_partials_kernel(size_t count, int S, const double *__restrict__ P, double *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double a = P[i];
+  for (int c = 1; c < S; ++c) a += P[(size_t)c * count + i];
+  out[i] = a;
 }
 
 // The block reflectors' T factors do not depend on the vectors they are applied to: ormtr_prepare forms them
@@ -151,14 +174,16 @@ void ormtr_prepare(hipStream_t s, int n, const double *V, int ldv, const double 
 
 // prep: what ormtr_prepare left (its T factors come first); work: >= 2 * KB * ncols doubles
 void ormtr_apply(hipStream_t s, int n, int ncols, const double *V, int ldv, const void *prep, double *Z, int ldz,
-                 void *work) {
+                 void *work, int ncols_global) {
   const int nrefl = n - 1;
   if (nrefl <= 0 || ncols <= 0) return;
   const int nblk = ceil_div(nrefl, KB);
   const double *T = (const double *)prep;
   char *w = (char *)work;
   double *W1 = (double *)w; w += al256((size_t)KB * ncols * 8);
-  double *W2 = (double *)w;
+  double *W2 = (double *)w; w += al256((size_t)KB * ncols * 8);
+  double *Wp = (double *)w;                        // partials of the split form
+  const int Smax = ormtr_split(ncols_global > 0 ? ncols_global : ncols);
   for (int b = nblk - 1; b >= 0; --b) {
     const int c0 = b * KB;
     const int kb = (nrefl - c0 < KB) ? nrefl - c0 : KB;
@@ -167,6 +192,20 @@ void ormtr_apply(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
     const int row0 = c0, m = n - row0;
     const double *Vb = V + (size_t)row0 + (size_t)c0 * ldv;
     double *Zb = Z + row0;
+    const int kc = round_up(ceil_div(m, Smax), 64);      // slices start on even rows (16-byte operand loads)
+    const int S = (Smax > 1 && m >= 4096) ? ceil_div(m, kc) : 1;
+    if (S > 1) {
+      const size_t cnt = (size_t)KB * ncols;
+      GemmDesc g{};
+      g.M = kb; g.N = ncols; g.K = kc; g.transA = true; g.transB = false; g.alpha = 1.0; g.beta = 0.0;
+      g.A = Vb; g.lda = ldv; g.strideA = kc; g.B = Zb; g.ldb = ldz; g.strideB = kc;
+      g.C = Wp; g.ldc = KB; g.strideC = (long long)cnt; g.batch = S - 1;
+      gemm(s, g);
+      const int klast = m - (S - 1) * kc;
+      gemm(s, true, false, kb, ncols, klast, 1.0, Vb + (size_t)(S - 1) * kc, ldv, Zb + (size_t)(S - 1) * kc, ldz, 0.0,
+           Wp + (size_t)(S - 1) * cnt, KB);
+      hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, cnt, S, Wp, W1);
+    } else
     gemm(s, true, false, kb, ncols, m, 1.0, Vb, ldv, Zb, ldz, 0.0, W1, KB);
     gemm(s, false, false, kb, ncols, kb, 1.0, T + (size_t)b * KB * KB, KB, W1, KB, 0.0, W2, KB);
     gemm(s, false, false, m, ncols, kb, -1.0, Vb, ldv, W2, KB, 1.0, Zb, ldz);
@@ -174,11 +213,11 @@ void ormtr_apply(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
 }
 
 void ormtr_lower(hipStream_t s, int n, int ncols, const double *V, int ldv, const double *tau,
-                 double *Z, int ldz, void *work) {
+                 double *Z, int ldz, void *work, int ncols_global) {
   if (n - 1 <= 0 || ncols <= 0) return;
   char *prep = (char *)work;
   ormtr_prepare(s, n, V, ldv, tau, prep);
-  ormtr_apply(s, n, ncols, V, ldv, prep, Z, ldz, prep + ormtr_prep_bytes(n));
+  ormtr_apply(s, n, ncols, V, ldv, prep, Z, ldz, prep + ormtr_prep_bytes(n), ncols_global);
 }
 
 }  // namespace ek
