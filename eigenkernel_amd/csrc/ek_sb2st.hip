@@ -841,7 +841,11 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   const int nslab = ceil_div(ncols, QNC), npair = ceil_div(L.nS, 2), npass = npair * nslab;
   (void)hipMemsetAsync(qprog, 0, (size_t)npass * 4, s);
   (void)hipMemsetAsync(ctl + 2, 0, 4, s);
-  Q2ApplyArgs a{g, Rec, Z, ldz, ncols, nslab, npass, npair, qprog, ctl, 2};
+  // extra: how many further steps a pass stays behind its predecessor in the slab (fetch distance).  With few slabs
+  // the passes of a slab are one dependent chain and every step of distance is paid npair times: 0 / 1 / 2 / 3 give
+  // 21.0 / 22.2 / 24.2 / 26.2 ms for 1024 columns at N = 16384, 5.1 / 5.4 / 5.6 / 6.0 ms at N = 4096, and the same
+  // 227 ms for all 16384 columns.
+  Q2ApplyArgs a{g, Rec, Z, ldz, ncols, nslab, npass, npair, qprog, ctl, 0};
   if (const char *ev = getenv("EK_Q2_EXTRA")) a.extra = atoi(ev);
   int nwg = 512;
   if (const char *ev = getenv("EK_Q2_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
