@@ -1638,10 +1638,10 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, 4 * sizeof(int), s));
   mark();                                                              // 0
   // stage-in: padded, zero-filled work copies
-  EK_HIP_CHECK(hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s));
+  if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s));   // (the copy covers all of an unpadded array)
   copy_matrix(s, n, n, dA, lda, wA, ld);
   if (problem == 1) {
-    EK_HIP_CHECK(hipMemsetAsync(wB, 0, (size_t)ld * ld * 8, s));
+    if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wB, 0, (size_t)ld * ld * 8, s));
     copy_matrix(s, n, n, dB, ldb, wB, ld);
   }
   EK_HIP_CHECK(hipMemsetAsync(wV, 0, (size_t)ld * ld * 8, s));
