@@ -116,32 +116,94 @@ struct ChaseArgs {
   double *V2; int ldv2;
   double *tau2; int ldt;
   unsigned *prog;        // [nsweeps] tasks completed per sweep
-  unsigned *ctl;         // [0] ticket, [1] abort
+  unsigned *ctl;         // [0] ticket, [1] abort, [3] "the position-owned kernel gave up" (this kernel then runs), [4] census
   double *mail; int kmax;   // mailbox lines [4][kmax][MAILW]
   long long *prof;       // optional: [0..5] shader cycles per phase of a task summed over workgroup 0's tasks, [6] tasks
+  int only_if_abandoned; // run only if ctl[3] is set (the fall-back behind chase_pos_kernel)
 };
 
 constexpr unsigned kSpinLimit = 1u << 22;
 
-struct ChaseArgs;
-// One wave: DLARFG on x (lane = row, x = 0 beyond the block) -> v into LDS and into the reflector store of
-// the sweep, tau; returns beta in every lane.
-template <typename Args>
-__device__ __forceinline__ double make_reflector(double x, int lane, int L, int i0, int s, int k, const Args &p,
-                                                 double *sv, double *stau) {
+// ------------------------------------------------------------------------ the arithmetic of a task
+// Shared by the two kernels below, which differ only in WHERE the blocks live and how the sweeps hand them
+// on; with contraction off and every fused operation written out, both produce the same bits.
+// Layout of a task's blocks: lane = row of the block, wave w holds columns 8 w .. 8 w + 7 (CW per wave).
+struct Reflector { double v, tau, beta; };
+
+// One wave: DLARFG on x (lane = row, x = 0 beyond the block): v (v_0 = 1), tau, beta in every lane.
+__device__ __forceinline__ Reflector reflector_of(double x, int lane) {
+#pragma clang fp contract(off)
   const double ssq = wave_sum((lane >= 1) ? x * x : 0.0);
   const double alpha0 = lane_value(x, 0);
-  double beta = alpha0, tau = 0.0, scale = 0.0;
+  Reflector r;
+  r.beta = alpha0; r.tau = 0.0;
+  double scale = 0.0;
   if (ssq != 0.0) {
-    beta = -copysign(sqrt(alpha0 * alpha0 + ssq), alpha0);   // the path keeps |A| within 1e+-90
-    tau = (beta - alpha0) / beta;
-    scale = 1.0 / (alpha0 - beta);
+    r.beta = -copysign(sqrt(__builtin_fma(alpha0, alpha0, ssq)), alpha0);   // the path keeps |A| within 1e+-90
+    r.tau = (r.beta - alpha0) / r.beta;
+    scale = 1.0 / (alpha0 - r.beta);
   }
-  const double v = (lane == 0) ? 1.0 : x * scale;    // rows >= L carry x = 0
-  sv[lane] = v;
-  if (lane == 0) { *stau = tau; p.tau2[(size_t)k + (size_t)s * p.ldt] = tau; }
-  if (lane < L) p.V2[(size_t)(i0 + lane) + (size_t)s * p.ldv2] = v;
-  return beta;
+  r.v = (lane == 0) ? 1.0 : x * scale;    // rows beyond the block carry x = 0
+  return r;
+}
+// partial sums of p = D v and q = B v over this wave's columns
+template <int CW>
+__device__ __forceinline__ void task_partials(const double (&dd)[CW], const double (&bk)[CW], const double (&vc)[CW],
+                                              double &pp, double &qq) {
+#pragma clang fp contract(off)
+  pp = 0.0; qq = 0.0;
+#pragma unroll
+  for (int j = 0; j < CW; ++j) { pp = __builtin_fma(dd[j], vc[j], pp); qq = __builtin_fma(bk[j], vc[j], qq); }
+}
+// column 0 of B H (rows = lanes), from q = B v summed over the waves
+__device__ __forceinline__ double task_col0(double bk0, double tau, double qs, double vc0) {
+#pragma clang fp contract(off)
+  const double t = tau * qs;
+  return __builtin_fma(-t, vc0, bk0);
+}
+// w = tau p + alpha v with alpha = -tau/2 (p^T v) tau ... the vector of the symmetric rank-2 update D - v w^T - w v^T
+__device__ __forceinline__ double task_w(double tau, double psum, double v_r) {
+#pragma clang fp contract(off)
+  const double p_r = tau * psum;
+  const double dot = wave_sum(p_r * v_r);
+  const double alpha = (-0.5 * tau) * dot;
+  return __builtin_fma(alpha, v_r, p_r);
+}
+// D(r, c) -= v_r w_c + w_r v_c, written so that entries (r, c) and (c, r) get the same bits: a block that stays in
+// registers as a full image stays exactly symmetric, and a block whose lower triangle travels through memory and
+// is mirrored gets the same numbers.
+__device__ __forceinline__ double task_rank2(double d, double v_r, double w_c, double w_r, double v_c) {
+#pragma clang fp contract(off)
+  const double t1 = v_r * w_c, t2 = w_r * v_c;
+  return d - (t1 + t2);
+}
+__device__ __forceinline__ double task_right(double b, double q_r, double v_c) {
+#pragma clang fp contract(off)
+  return __builtin_fma(-q_r, v_c, b);
+}
+// B <- H' B with the new reflector (vn, tau_n), rows = lanes: v'^T B by a transposing reduction through the wave's
+// LDS buffer st (CW x 65 doubles); column 0 of the block (c == 0) is left alone: it is (beta, 0, ..., 0).
+template <int CW>
+__device__ __forceinline__ void task_left(double (&bp)[CW], double vn_r, double tau_n, double *st, int lane, bool skip0) {
+#pragma clang fp contract(off)
+  constexpr int LPC = 64 / CW;
+#pragma unroll
+  for (int j = 0; j < CW; ++j) st[j * 65 + lane] = vn_r * bp[j];
+  wave_sync();
+  double tot_b;
+  {
+    const int j = lane / LPC, q = lane % LPC;
+    const double *src = st + j * 65 + CW * q;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int l = 0; l < CW; l += 2) { a0 += src[l]; a1 += src[l + 1]; }
+    tot_b = group_sum<LPC>(a0 + a1);                 // lanes j LPC .. : v'^T (column j of this wave's part of B)
+  }
+  const double u = tau_n * vn_r;
+#pragma unroll
+  for (int j = 0; j < CW; ++j)
+    if (!(skip0 && j == 0)) bp[j] = __builtin_fma(-u, lane_value(tot_b, j * LPC), bp[j]);
+  wave_sync();
 }
 
 // Dependencies between sweeps.  Task (s, k) works on rows and columns s+1+64k .. s+64(k+2) of the lower
@@ -154,8 +216,25 @@ __device__ __forceinline__ double make_reflector(double x, int lane, int L, int 
 //  * everything else is final when task (s-1, k) ends, PROVIDED a task finishes the block it hands on:
 //    so a task applies the NEXT reflector from the left to the new B_k at its own end (it holds both),
 //    instead of the next task doing that first.
-// Hence: task (s, k) starts when task (s-1, k) is complete (one progress word per sweep); the 65 late
-// numbers of task (s-1, k+1) come through a MAILBOX line its last wave polls directly (an "empty" bit
+//
+// TWO kernels are built on that.
+//
+// chase_pos_kernel (the default; orders up to 64 x the number of workgroups the chip holds at once):
+// a workgroup owns a POSITION k of the band and keeps D_k and B_k in its REGISTERS for the whole stage
+// (lane = row, 8 columns per wave); sweep after sweep passes through it.  From one sweep to the next the blocks
+// move one row and one column down the band: the images shift by one (DPP wave shift for the rows, a register
+// rename and one LDS exchange for the columns), the new last row of D_k is the old first row of B_k, and the
+// new last column of B_k and the corner of D_k are the 65 late numbers of position k+1.  Nothing but the
+// reflectors (for Q2), d and e ever goes to memory; between positions travel two self-flagging mailbox lines per
+// sweep: the reflector (64 + tau) forward to k+1, the late numbers (64 + beta) back to k-1.  The stage is
+// the cycle "reflector of (s, k+1) -> late numbers of (s, k+1) -> reflector of (s+1, k+1)": two hops across
+// the chip and the two short chains between them per sweep (tools/chain_hop.hip: 2.5 us for the bare cycle),
+// instead of a whole task plus fetch, drain and progress word (7.9 us).
+//
+// chase_kernel (the older form; any order, no co-residency needed; also the fall-back if the positions could
+// not all become resident): a workgroup takes SWEEPS from a ticket counter and walks down the band, blocks
+// travel through memory.  Task (s, k) starts when task (s-1, k) is complete (one progress word per sweep); the 65
+// late numbers of task (s-1, k+1) come through a MAILBOX line its last wave polls directly (an "empty" bit
 // pattern marks a slot; the reader empties it again; four lines per task index in rotation) -- data that
 // is its own flag costs no drain, no barrier and no second round trip.  Sweeps follow each other ONE task
 // apart (plus the hand-off), not three; the pipeline is latency-bound and its length is the number of
@@ -164,7 +243,7 @@ __device__ __forceinline__ double make_reflector(double x, int lane, int L, int 
 // sweep ever has to wait for a store of another.
 //
 // Per task the workgroup synchronises four times.  NW waves per workgroup, each with CW = 64 / NW
-// columns of a block (row per lane).
+// columns of a block (row per lane).  Both kernels run the arithmetic above: same bits.
 constexpr int MAILW = 72;                              // doubles per mailbox line: 64 (column 0 of D_k) + beta + padding
 constexpr unsigned long long kMailEmpty = 0x7ff8dead0000beefull;   // a NaN no computation produces
 
@@ -178,7 +257,6 @@ __global__ void mail_init_kernel(double *mail, int count) {
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
   constexpr int CW = SB / NW;            // columns of a block per wave
-  constexpr int LPC = 64 / CW;           // lanes that share one column in the transposed reduction
   __shared__ __attribute__((aligned(16))) double s_v[2][SB];
   __shared__ double s_p[NW][SB], s_q[NW][SB];
   __shared__ double s_t[NW][CW * 65];
@@ -189,6 +267,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
   const int n = p.n;
   const int c0w = CW * wave;                               // this wave's columns of a block
   double *AB = p.AB;
+  if (p.only_if_abandoned && !__hip_atomic_load(&p.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
   if (t == 0) s_ok = 1;
   auto give_up = [&]() { __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   // bounded wait until *w >= need
@@ -201,6 +280,11 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         return false;
     }
     return true;
+  };
+  auto put_reflector = [&](const Reflector &r, int L, int i0, int s, int k, double *sv, double *stau) {
+    sv[lane] = r.v;
+    if (lane == 0) { *stau = r.tau; p.tau2[(size_t)k + (size_t)s * p.ldt] = r.tau; }
+    if (lane < L) p.V2[(size_t)(i0 + lane) + (size_t)s * p.ldv2] = r.v;
   };
   while (true) {
     __syncthreads();
@@ -248,8 +332,9 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       if (k == 0) {
         if (wave == 0) {
           const double x = (lane < L) ? ld_sc1(AB + (size_t)(1 + lane) + (size_t)s * LDAB) : 0.0;
-          const double beta = make_reflector(x, lane, L, i0, s, k, p, s_v[cur], &s_tau[cur]);
-          if (lane < L) st_sc1(AB + (size_t)(1 + lane) + (size_t)s * LDAB, (lane == 0) ? beta : 0.0);
+          const Reflector r = reflector_of(x, lane);
+          put_reflector(r, L, i0, s, k, s_v[cur], &s_tau[cur]);
+          if (lane < L) st_sc1(AB + (size_t)(1 + lane) + (size_t)s * LDAB, (lane == 0) ? r.beta : 0.0);
         }
         __syncthreads();                                                     // #1 (first task only)
       }
@@ -295,9 +380,10 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       // ---- partial sums of p = D v and q = B_k v
       double dd[CW];
       {
-        double pp = 0.0, qq = 0.0;
+        double pp, qq;
 #pragma unroll
-        for (int j = 0; j < CW; ++j) { dd[j] = s_D[lane * DLD + c0w + j]; pp += dd[j] * vc[j]; qq += bk[j] * vc[j]; }
+        for (int j = 0; j < CW; ++j) dd[j] = s_D[lane * DLD + c0w + j];
+        task_partials<CW>(dd, bk, vc, pp, qq);
         s_p[wave][lane] = pp; s_q[wave][lane] = qq;
       }
       __syncthreads();                                                       // #3
@@ -309,15 +395,16 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         double qs = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) qs += s_q[w][lane];
-        const double col0 = (L1 > 0) ? bk[0] - tau * qs * vc[0] : 0.0;
+        const double col0 = (L1 > 0) ? task_col0(bk[0], tau, qs, vc[0]) : 0.0;
         double b00 = col0;                                 // lane 0: entry (0,0) of the new B_k
         if (k + 1 < K) {
           const int i0n = i0 + SB;
-          const double beta = make_reflector(col0, lane, L1, i0n, s, k + 1, p, s_v[cur ^ 1], &s_tau[cur ^ 1]);
-          b00 = beta;
+          const Reflector r = reflector_of(col0, lane);
+          put_reflector(r, L1, i0n, s, k + 1, s_v[cur ^ 1], &s_tau[cur ^ 1]);
+          b00 = r.beta;
           // (beta itself travels by mailbox when there is a follower to rewrite that entry: see phase (c))
           if (lane < L1 && !(lane == 0 && k > 0 && has_follower))
-            st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), (lane == 0) ? beta : 0.0);
+            st_sc1(AB + (unsigned)((SB + lane) + i0 * LDAB), (lane == 0) ? r.beta : 0.0);
         }
         if (lane == 0 && k > 0 && has_follower)
           st_sc1(p.mail + ((size_t)(s & 3) * p.kmax + k) * MAILW + 64, b00);
@@ -326,18 +413,13 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       double psum = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) psum += s_p[w][lane];
-      const double p_r = tau * psum;
-      const double dot = wave_sum(p_r * v_r);
-      const double alpha = -0.5 * tau * dot;
-      const double w_r = p_r + alpha * v_r;
+      const double w_r = task_w(tau, psum, v_r);
 #pragma unroll
       for (int j = 0; j < CW; ++j) {
         const int c = c0w + j;
-        // (p of column c is p of row c, which lane c of this wave has just summed: a v_readlane instead of NW
-        // more LDS reads per column -- eight waves share one LDS pipe)
-        const double pc = lane_value(psum, c);
-        const double w_c = tau * pc + alpha * vc[j];
-        dd[j] -= v_r * w_c + w_r * vc[j];
+        // (w of column c is w of row c, which lane c of this wave has: a v_readlane instead of more LDS reads per
+        // column -- eight waves share one LDS pipe)
+        dd[j] = task_rank2(dd[j], v_r, lane_value(w_r, c), w_r, vc[j]);
         if (c == 0 && k > 0 && has_follower)               // column 0 of D_k: the follower's late numbers (entries >= L are 0)
           st_sc1(p.mail + ((size_t)(s & 3) * p.kmax + k) * MAILW + lane, dd[j]);
         // (column 0 of a task k > 0 goes to the follower through the mailbox only: the follower rewrites exactly
@@ -356,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
         for (int w = 0; w < NW; ++w) qsum += s_q[w][lane];
         const double q_r = tau * qsum;
 #pragma unroll
-        for (int j = 0; j < CW; ++j) bp[j] = bk[j] - q_r * vc[j];
+        for (int j = 0; j < CW; ++j) bp[j] = task_right(bk[j], q_r, vc[j]);
         if (k == K - 1) {                                  // no further task in this sweep: the block is final
 #pragma unroll
           for (int j = 0; j < CW; ++j) {
@@ -374,28 +456,12 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
       if (k + 1 < K) {
         __syncthreads();                                                     // #4: the new reflector is in LDS
         // ---- (b) B_k <- H' B_k with the NEW reflector (rows I_{k+1}): the block is final for this sweep
-        const double tau_n = s_tau[cur ^ 1];
-        const double vn_r = s_v[cur ^ 1][lane];
-        double *st = s_t[wave];
-#pragma unroll
-        for (int j = 0; j < CW; ++j) st[j * 65 + lane] = vn_r * bp[j];
-        wave_sync();
-        double tot_b;
-        {
-          const int j = lane / LPC, q = lane % LPC;
-          const double *src = st + j * 65 + CW * q;
-          double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-          for (int l = 0; l < CW; l += 2) { a0 += src[l]; a1 += src[l + 1]; }
-          tot_b = group_sum<LPC>(a0 + a1);                 // lanes j LPC .. : v'^T (column j of this wave's part of B_k)
-        }
+        task_left<CW>(bp, s_v[cur ^ 1][lane], s_tau[cur ^ 1], s_t[wave], lane, wave == 0);
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
           const int c = c0w + j;
-          if (c > 0) {           // column 0 is (beta, 0, ..., 0) and went to memory with the reflector
-            const double b = bp[j] - tau_n * vn_r * lane_value(tot_b, j * LPC);
-            if (lane < L1) st_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB), b);
-          }
+          if (c > 0 && lane < L1)           // column 0 is (beta, 0, ..., 0) and went to memory with the reflector
+            st_sc1(AB + (unsigned)((SB + lane - c) + (i0 + c) * LDAB), bp[j]);
         }
         // the task is complete once its stores are (the last task is told below)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -407,6 +473,250 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) __hip_atomic_store(&p.prog[s], (unsigned)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ------------------------------------------------------------------------ positions: blocks in registers
+struct PosArgs {
+  int n, K0;             // K0 = number of positions = tasks of sweep 0
+  double *AB;
+  double *V2; int ldv2;
+  double *tau2; int ldt;
+  double *fwd, *bwd;     // [K0 + 1][4][MAILW]: line (k, s & 3) is written by position k-1 (fwd) / k+1 (bwd) for position k
+  unsigned *retired;     // [K0 + 1]: position k has finished its last task and left A(n-1, n-1) in the band array
+  unsigned *ctl;         // [3] abandoned, [4] census of the workgroups
+  int per;               // workgroup b holds position (b & 7) * per + (b >> 3): neighbours mostly share an XCD (speed only)
+  unsigned census_spins;
+};
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift(double v) {   // 0x130: lane i <- lane i + 1 (lane 63 keeps its own value)
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
+  constexpr int NW = 8, CW = SB / NW;
+  __shared__ __attribute__((aligned(16))) double s_v[2][SB];   // [0] the reflector of this task, [1] the one it makes
+  __shared__ double s_p[NW][SB], s_q[NW][SB];
+  __shared__ double s_t[NW][CW * 65];
+  __shared__ double s_x[NW][SB], s_y[NW][SB], s_row[SB];
+  __shared__ double s_tau[2];
+  __shared__ int s_ok;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int k = (int)(blockIdx.x & 7) * p.per + (int)(blockIdx.x >> 3);
+  if (k >= p.K0) return;
+  const int n = p.n;
+  const int c0w = CW * wave;
+  double *AB = p.AB;
+  unsigned *abandoned = &p.ctl[3];
+  auto give_up = [&]() { __hip_atomic_store(abandoned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // ---- census: every position must be resident before any of them waits for a neighbour
+  if (t == 0) {
+    int ok = 1;
+    atomicAdd(&p.ctl[4], 1u);
+    unsigned spins = 0;
+    while (__hip_atomic_load(&p.ctl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.K0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > p.census_spins || __hip_atomic_load(abandoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+    }
+    if (!ok) give_up();
+    s_ok = ok;
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  // one mailbox line: lane l takes entry l, lane 0 entry 64 as well; bounded; the reader empties the line again
+  auto take_line = [&](double *line, double &a, double &b) -> bool {
+    a = ld_sc1(line + lane); b = (lane == 0) ? ld_sc1(line + 64) : 0.0;
+    unsigned spins = 0;
+    while (__any(mail_empty(a) || (lane == 0 && mail_empty(b)))) {
+      if ((++spins & 63u) == 0u &&
+          (spins > kSpinLimit || __hip_atomic_load(abandoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        return false;
+      __builtin_amdgcn_s_sleep(1);
+      if (mail_empty(a)) a = ld_sc1(line + lane);
+      if (lane == 0 && mail_empty(b)) b = ld_sc1(line + 64);
+    }
+    const double e = __longlong_as_double((long long)kMailEmpty);
+    st_sc1(line + lane, e);
+    if (lane == 0) st_sc1(line + 64, e);
+    return true;
+  };
+  // ---- the blocks of sweep 0 from the packed band (written by an earlier kernel): D_k as a full image
+  const int s_last = n - 3 - SB * k;                     // the last sweep that has a task at this position (L = 2 then)
+  double dd[CW], bk[CW];
+  {
+    const int i0 = 1 + SB * k;
+    const int L = (n - i0 < SB) ? n - i0 : SB;
+    int L1 = n - i0 - SB; if (L1 > SB) L1 = SB; if (L1 < 0) L1 = 0;
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+      const int c = c0w + j;
+      const int hi = (lane > c) ? lane : c, lo = (lane > c) ? c : lane;
+      dd[j] = (lane < L && c < L) ? AB[(size_t)(hi - lo) + (size_t)(i0 + lo) * LDAB] : 0.0;
+      bk[j] = (lane < L1 && c < L) ? AB[(size_t)(SB + lane - c) + (size_t)(i0 + c) * LDAB] : 0.0;
+    }
+  }
+  double xnext = 0.0;                                      // position 0, wave 0: column s+1 below the diagonal
+  for (int s = 0; s <= s_last; ++s) {
+    const int i0 = s + 1 + k * SB;
+    const int L = (n - i0 < SB) ? n - i0 : SB;
+    int L1 = n - i0 - SB; if (L1 > SB) L1 = SB; if (L1 < 0) L1 = 0;
+    const int K = (n - 3 - s) / SB + 1;
+    const int Kprev = (s > 0) ? (n - 2 - s) / SB + 1 : 0;
+    const bool lead = s > 0 && k + 1 < Kprev;              // position k+1 had a task in sweep s-1: its late numbers come by mail
+    // every store of the previous task (mail, emptied lines) has completed before this task sends anything
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- the reflector of this task: position 0 makes it from its own column, the others receive it
+    if (wave == 0) {
+      if (k == 0) {
+        const double x = (s == 0) ? ((lane < L) ? AB[(size_t)(1 + lane)] : 0.0) : xnext;
+        const Reflector r = reflector_of(x, lane);
+        s_v[0][lane] = r.v;
+        if (lane == 0) { s_tau[0] = r.tau; p.tau2[(size_t)s * p.ldt] = r.tau; st_sc1(AB + (size_t)1 + (size_t)s * LDAB, r.beta); }
+        if (lane < L) p.V2[(size_t)(i0 + lane) + (size_t)s * p.ldv2] = r.v;
+      } else {
+        double a, b;
+        if (!take_line(p.fwd + ((size_t)k * 4 + (s & 3)) * MAILW, a, b)) { if (lane == 0) { give_up(); s_ok = 0; } }
+        s_v[0][lane] = a;
+        if (lane == 0) s_tau[0] = b;
+      }
+    }
+    // ---- the entering column: the late numbers of position k+1's task of the previous sweep
+    if (wave == NW - 1 && s > 0) {
+      if (lead) {
+        double a, b;
+        if (!take_line(p.bwd + ((size_t)k * 4 + ((s - 1) & 3)) * MAILW, a, b)) { if (lane == 0) { give_up(); s_ok = 0; } }
+        // a: entry l = D_{k+1}(l, 0) of the previous sweep; b (lane 0): beta.  Row r of our new last column is entry r + 1
+        const double up = dpp_shift<0x130>(a);
+        const double beta = lane_value(b, 0), corner = lane_value(a, 0);
+        const double col = (lane < 63) ? up : beta;
+        bk[CW - 1] = (lane < L1 && SB - 1 < L) ? col : 0.0;
+        if (lane == 63 && SB - 1 < L) dd[CW - 1] = corner;
+      } else if (L == SB) {
+        // the one sweep after position k+1 has retired (or never existed): the corner is A(n-1, n-1) in the band array
+        int ok = 1;
+        if (lane == 0) {
+          unsigned spins = 0;
+          while (!__hip_atomic_load(&p.retired[k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0u &&
+                (spins > kSpinLimit || __hip_atomic_load(abandoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = 0; break; }
+          }
+          if (!ok) { give_up(); s_ok = 0; }
+        }
+        wave_sync();
+        const double corner = ld_sc1(AB + (size_t)(i0 + SB - 1) * LDAB);
+        if (lane == 63) dd[CW - 1] = corner;
+      }
+    }
+    __syncthreads();                                                         // #1
+    if (!s_ok) return;
+    const double tau = s_tau[0];
+    const double v_r = s_v[0][lane];
+    double vc[CW];
+#pragma unroll
+    for (int j = 0; j < CW; ++j) vc[j] = s_v[0][c0w + j];
+    {
+      double pp, qq;
+      task_partials<CW>(dd, bk, vc, pp, qq);
+      s_p[wave][lane] = pp; s_q[wave][lane] = qq;
+    }
+    __syncthreads();                                                         // #2
+    // ---- the reflector of position k+1 first: position k+1 is waiting for it
+    double b00 = 0.0;
+    if (wave == 0) {
+      double qs = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) qs += s_q[w][lane];
+      const double col0 = (L1 > 0) ? task_col0(bk[0], tau, qs, vc[0]) : 0.0;
+      b00 = col0;
+      if (k + 1 < K) {
+        const Reflector r = reflector_of(col0, lane);
+        double *line = p.fwd + ((size_t)(k + 1) * 4 + (s & 3)) * MAILW;
+        st_sc1(line + lane, r.v);
+        if (lane == 0) st_sc1(line + 64, r.tau);
+        s_v[1][lane] = r.v;
+        if (lane == 0) { s_tau[1] = r.tau; p.tau2[(size_t)(k + 1) + (size_t)s * p.ldt] = r.tau; }
+        if (lane < L1) p.V2[(size_t)(i0 + SB + lane) + (size_t)s * p.ldv2] = r.v;
+        b00 = r.beta;
+      }
+      b00 = lane_value(b00, 0);                            // entry (0, 0) of the new B_k
+      if (k > 0 && lane == 0) st_sc1(p.bwd + ((size_t)(k - 1) * 4 + (s & 3)) * MAILW + 64, b00);
+    }
+    // ---- D_k <- H D_k H
+    double psum = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) psum += s_p[w][lane];
+    const double w_r = task_w(tau, psum, v_r);
+#pragma unroll
+    for (int j = 0; j < CW; ++j) dd[j] = task_rank2(dd[j], v_r, lane_value(w_r, c0w + j), w_r, vc[j]);
+    if (wave == 0) {
+      // column 0 of D_k leaves the position: the late numbers of position k-1, or (position 0) d and the next column
+      if (k > 0) st_sc1(p.bwd + ((size_t)(k - 1) * 4 + (s & 3)) * MAILW + lane, dd[0]);
+      else if (lane == 0) st_sc1(AB + (size_t)(s + 1) * LDAB, dd[0]);
+    }
+    // ---- B_k <- B_k H
+    double bp[CW];
+    {
+      double qsum = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) qsum += s_q[w][lane];
+      const double q_r = tau * qsum;
+#pragma unroll
+      for (int j = 0; j < CW; ++j) bp[j] = (L1 > 0) ? task_right(bk[j], q_r, vc[j]) : 0.0;
+    }
+    if (k + 1 < K) {
+      __syncthreads();                                                       // #3: the new reflector is in LDS
+      task_left<CW>(bp, s_v[1][lane], s_tau[1], s_t[wave], lane, wave == 0);
+    }
+    if (s == s_last) break;
+    // ---- the blocks of the next sweep: one row and one column further down the band
+    if (k == 0 && wave == 0) {
+      const double up = dpp_shift<0x130>(dd[0]);
+      xnext = (lane < 63) ? up : b00;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < CW; ++j) s_row[c0w + j] = bp[j];                   // row 0 of B_k: the new last row and column of D_k
+    }
+    s_x[wave][lane] = dd[0]; s_y[wave][lane] = bp[0];
+    __syncthreads();                                                         // #4
+#pragma unroll
+    for (int j = 0; j + 1 < CW; ++j) { dd[j] = dd[j + 1]; bk[j] = bp[j + 1]; }
+    dd[CW - 1] = (wave + 1 < NW) ? s_x[(wave + 1) & (NW - 1)][lane] : 0.0;
+    bk[CW - 1] = (wave + 1 < NW) ? s_y[(wave + 1) & (NW - 1)][lane] : 0.0;
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+      const double brow0 = lane_value(bk[j], 0);             // B_k(0, c + 1)
+      const double du = dpp_shift<0x130>(dd[j]), bu = dpp_shift<0x130>(bk[j]);
+      dd[j] = (lane == 63) ? brow0 : du;
+      bk[j] = (lane == 63) ? 0.0 : bu;
+    }
+    if (wave == NW - 1) dd[CW - 1] = (lane < 63) ? s_row[lane + 1] : 0.0;    // the corner and B's last column: next sweep's mail
+  }
+  // ---- retirement: the last task had L = 2; what is left of D_k is A(n-1, n-1) (position 0: also e(n-2))
+  if (wave == 0) {
+    if (lane == 1) {
+      st_sc1(AB + (size_t)(n - 1) * LDAB, dd[1]);
+      if (k == 0) st_sc1(AB + (size_t)1 + (size_t)(n - 2) * LDAB, dd[0]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&p.retired[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ void set_word_kernel(unsigned *p, unsigned v) { *p = v; }
+
+// the band again if the position-owned kernel gave up half way, and the state chase_kernel starts from
+__global__ void repack_band_kernel(int n, const double *__restrict__ A, int lda, double *__restrict__ AB, const unsigned *ctl) {
+  if (!ctl[3]) return;
+  const int c = blockIdx.x;
+  for (int d = threadIdx.x; d < LDAB; d += blockDim.x) {
+    double v = 0.0;
+    if (d <= SB && c + d < n) v = A[(size_t)(c + d) + (size_t)c * lda];
+    AB[(size_t)d + (size_t)c * LDAB] = v;
   }
 }
 
@@ -757,7 +1067,7 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Layout {
   int nsweeps, nS, kmax, ldt;
-  size_t off_ab, off_tau, off_prog, off_mail, off_ctl, off_T, off_qprog, total;
+  size_t off_ab, off_tau, off_prog, off_mail, off_pmail, off_retired, off_ctl, off_T, off_qprog, total;
   explicit Layout(int n) {
     nsweeps = n > 2 ? n - 2 : 0;
     nS = ceil_div((nsweeps > 0 ? nsweeps : 1) + 1, QG);   // block S = sweeps 32 S - 1 .. 32 S + 30
@@ -768,12 +1078,31 @@ struct Layout {
     off_tau = o; o += al256((size_t)ldt * (nsweeps + 1) * 8);
     off_prog = o; o += al256((size_t)(nsweeps + 1) * 4);
     off_mail = o; o += al256((size_t)4 * (kmax + 1) * MAILW * 8);
+    off_pmail = o; o += al256((size_t)2 * 4 * (kmax + 2) * MAILW * 8);   // chase_pos_kernel: forward and backward lines
+    off_retired = o; o += al256((size_t)(kmax + 2) * 4);
     off_ctl = o; o += 256;
     off_T = o; o += al256((size_t)nS * kmax * QREC * 8);
     off_qprog = o; o += al256((size_t)nS * ceil_div(n, QNC) * 4);
     total = o;
   }
 };
+
+// how many 512-thread workgroups of chase_pos_kernel the device holds at once (they must all be resident)
+int pos_capacity() {
+  static int cap = -1;
+  if (cap < 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chase_pos_kernel, 512, 0) != hipSuccess)
+      cap = 0;
+    else {
+      if (per_cu > 2) per_cu = 2;                          // two per CU is what has been measured
+      cap = per_cu * pr.multiProcessorCount;
+    }
+  }
+  return cap;
+}
 
 }  // namespace
 
@@ -789,22 +1118,40 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
   char *w = (char *)work;
   double *AB = (double *)(w + L.off_ab), *tau2 = (double *)(w + L.off_tau);
   unsigned *prog = (unsigned *)(w + L.off_prog), *ctl = (unsigned *)(w + L.off_ctl);
-  double *mail = (double *)(w + L.off_mail);
-  const int nmail = 4 * (L.kmax + 1) * MAILW;
+  double *mail = (double *)(w + L.off_mail), *pmail = (double *)(w + L.off_pmail);
+  unsigned *retired = (unsigned *)(w + L.off_retired);
+  const int nmail = 4 * (L.kmax + 1) * MAILW, npmail = 2 * 4 * (L.kmax + 2) * MAILW;
   hipLaunchKernelGGL(pack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB);
   (void)hipMemsetAsync(tau2, 0, (size_t)L.ldt * (L.nsweeps + 1) * 8, s);
   (void)hipMemsetAsync(prog, 0, (size_t)(L.nsweeps + 1) * 4 + 0, s);
-  hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(nmail, 256)), dim3(256), 0, s, mail, nmail);
   (void)hipMemsetAsync(ctl, 0, 256, s);
   if (L.nsweeps > 0) {
-    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, mail, L.kmax + 1, nullptr};
+    // which kernel: 1 = sweeps through memory (chase_kernel), 2 = positions in registers (chase_pos_kernel, with
+    // chase_kernel behind it in case its workgroups cannot all become resident); default 2 where the chip holds K0
+    int mode = 2;
+    if (const char *ev = getenv("EK_SB2ST_CHASE")) mode = atoi(ev);
+    const int K0 = (n - 3) / SB + 1;
+    const bool pos = mode == 2 && K0 <= pos_capacity() && !getenv("EK_SB2ST_WGS") && !getenv("EK_SB2ST_PROF");
+    kprof_begin(s, kProfChase);
+    if (pos) {
+      hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(npmail, 256)), dim3(256), 0, s, pmail, npmail);
+      (void)hipMemsetAsync(retired, 0, (size_t)(L.kmax + 2) * 4, s);
+      hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, s, retired + K0, 1u);   // there is no position K0
+      const int per = ceil_div(K0, 8);
+      unsigned census = 1u << 16;                            // x ~0.3 us: what a workgroup waits for the others to arrive
+      if (const char *ev = getenv("EK_SB2ST_CENSUS_SPINS")) census = (unsigned)atoi(ev);
+      PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * MAILW, retired, ctl, per, census};
+      hipLaunchKernelGGL(chase_pos_kernel, dim3(per * 8), dim3(512), 0, s, a);
+      hipLaunchKernelGGL(repack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB, ctl);
+    }
+    hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(nmail, 256)), dim3(256), 0, s, mail, nmail);
+    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, mail, L.kmax + 1, nullptr, pos ? 1 : 0};
     if (getenv("EK_SB2ST_PROF")) { c.prof = (long long *)(ctl + 16); }
     // enough workgroups for the pipeline (a sweep starts one task behind its predecessor)
     int nwg = n / SB + 8;
     if (nwg > 256) nwg = 256;
     if (nwg > L.nsweeps) nwg = L.nsweeps;
     if (const char *ev = getenv("EK_SB2ST_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
-    kprof_begin(s, kProfChase);
     static int nw = -1;
     if (nw < 0) { const char *ev = getenv("EK_SB2ST_WAVES"); nw = ev ? atoi(ev) : 8; }
     if (nw == 16) hipLaunchKernelGGL(chase_kernel<16>, dim3(nwg), dim3(1024), 0, s, c);
@@ -820,6 +1167,12 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
     fprintf(stderr, "[sb2st prof] tasks %lld; cycles per task: gate+loads %.0f, reflector %.0f, left-apply+fill %.0f, "
             "partials %.0f, updates %.0f\n", h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6],
             (double)h[3] / h[6], (double)h[4] / h[6]);
+  }
+  if (getenv("EK_SB2ST_VERBOSE")) {
+    unsigned h[8];
+    (void)hipMemcpyAsync(h, ctl, sizeof(h), hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    fprintf(stderr, "[sb2st] n %d: abort %u, positions abandoned %u, census %u\n", n, h[1], h[3], h[4]);
   }
   hipLaunchKernelGGL(forward_abort_kernel, dim3(1), dim3(1), 0, s, ctl, d_flag);   // abort word -> caller's flag
 }

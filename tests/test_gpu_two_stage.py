@@ -133,6 +133,45 @@ def test_bulge_chasing_does_not_depend_on_the_width_of_the_pipeline(hip, n):
         os.environ.pop("EK_SB2ST_WGS", None)
 
 
+@pytest.mark.parametrize("n", [3, 4, 66, 130, 193, 777, 1500, 4200])
+def test_both_bulge_chasing_kernels_give_the_same_bits(hip, n):
+    """ek_sb2st.hip has two kernels for the chase: positions of the band held in registers, sweeps passing
+    through them by mail (the default), and sweeps walking through memory (EK_SB2ST_CHASE=1; the fall-back).
+    They share the arithmetic of a task, so d, e, the reflectors (seen through the applied Q2) must agree bit
+    for bit -- which also shows that no hand-off of either protocol delivered a stale or a misplaced number."""
+    Bd = _random_band(n, 3 * n + 1)
+    Z0 = np.eye(n)[:, ::max(n // 16, 1)][:, :16].copy()
+    try:
+        os.environ["EK_SB2ST_CHASE"] = "1"
+        d1, e1, Z1, f1 = hip.sb2st(Bd, Z0)
+        os.environ["EK_SB2ST_CHASE"] = "2"
+        d2, e2, Z2, f2 = hip.sb2st(Bd, Z0)
+        d3, e3, Z3, f3 = hip.sb2st(Bd, Z0)
+    finally:
+        os.environ.pop("EK_SB2ST_CHASE", None)
+    assert f1 == 0 and f2 == 0 and f3 == 0
+    assert np.array_equal(d1, d2) and np.array_equal(e1, e2) and np.array_equal(Z1, Z2)
+    assert np.array_equal(d3, d2) and np.array_equal(e3, e2) and np.array_equal(Z3, Z2)
+    T = np.diag(d2) + np.diag(e2, 1) + np.diag(e2, -1)
+    assert np.abs(np.linalg.eigvalsh(Bd) - np.linalg.eigvalsh(T)).max() <= 8 * n * EPS * np.abs(d2).max()
+
+
+def test_position_kernel_falls_back_when_its_workgroups_cannot_all_be_resident(hip):
+    """The position-owned kernel needs every workgroup on the chip at once; its census gives up after a bounded
+    wait and the sweep kernel behind it redoes the stage from the repacked band (same bits).  A census of zero
+    polls makes that happen whenever a workgroup is not the last to arrive."""
+    n = 1500
+    Bd = _random_band(n, 11)
+    d0, e0, _, f0 = hip.sb2st(Bd)
+    try:
+        os.environ["EK_SB2ST_CENSUS_SPINS"] = "0"
+        d1, e1, _, f1 = hip.sb2st(Bd)
+    finally:
+        os.environ.pop("EK_SB2ST_CENSUS_SPINS", None)
+    assert f0 == 0 and f1 == 0
+    assert np.array_equal(d0, d1) and np.array_equal(e0, e1)
+
+
 @pytest.fixture()
 def forced_two_stage(hip):
     hip.set_two_stage(100)
