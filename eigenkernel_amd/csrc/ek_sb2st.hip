@@ -477,6 +477,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
 }
 
 // ------------------------------------------------------------------------ positions: blocks in registers
+constexpr int PMAILW = 80;     // doubles per line of the position kernel: 64 numbers = four whole 128-byte lines, the 65th in a fifth
 struct PosArgs {
   int n, K0;             // K0 = number of positions = tasks of sweep 0
   double *AB;
@@ -485,7 +486,7 @@ struct PosArgs {
   double *fwd, *bwd;     // [K0 + 1][4][MAILW]: line (k, s & 3) is written by position k-1 (fwd) / k+1 (bwd) for position k
   unsigned *retired;     // [K0 + 1]: position k has finished its last task and left A(n-1, n-1) in the band array
   unsigned *ctl;         // [3] abandoned, [4] census of the workgroups
-  int per;               // workgroup b holds position (b & 7) * per + (b >> 3): neighbours mostly share an XCD (speed only)
+  int per;               // 0: workgroup b holds position b; > 0: position (b & 7) * per + (b >> 3), neighbours mostly on one XCD
   unsigned census_spins;
 };
 
@@ -501,11 +502,12 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
   __shared__ __attribute__((aligned(16))) double s_v[2][SB];   // [0] the reflector of this task, [1] the one it makes
   __shared__ double s_p[NW][SB], s_q[NW][SB];
   __shared__ double s_t[NW][CW * 65];
-  __shared__ double s_x[NW][SB], s_y[NW][SB], s_row[SB];
-  __shared__ double s_tau[2];
+  __shared__ double s_x[NW][SB], s_y[NW][SB], s_row[SB], s_b0[SB];
+  __shared__ double s_tau[2], s_b00;
   __shared__ int s_ok;
+  constexpr int RW = 1;                                    // the wave that makes the reflectors
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int k = (int)(blockIdx.x & 7) * p.per + (int)(blockIdx.x >> 3);
+  const int k = p.per > 0 ? (int)(blockIdx.x & 7) * p.per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (k >= p.K0) return;
   const int n = p.n;
   const int c0w = CW * wave;
@@ -527,20 +529,24 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
   __syncthreads();
   if (!s_ok) return;
   // one mailbox line: lane l takes entry l, lane 0 entry 64 as well; bounded; the reader empties the line again
-  auto take_line = [&](double *line, double &a, double &b) -> bool {
-    a = ld_sc1(line + lane); b = (lane == 0) ? ld_sc1(line + 64) : 0.0;
+  // (two polls in flight half a round trip apart: a message is seen about a quarter of a round trip after it lands
+  // instead of half of one)
+  auto take_line = [&](double *line, bool with65, double &a, double &b) -> bool {
+    const bool l65 = with65 && lane == 0;
+    a = ld_sc1(line + lane); b = l65 ? ld_sc1(line + 64) : 0.0;
+    __builtin_amdgcn_s_sleep(2);
+    double a2 = ld_sc1(line + lane), b2 = l65 ? ld_sc1(line + 64) : 0.0;
     unsigned spins = 0;
-    while (__any(mail_empty(a) || (lane == 0 && mail_empty(b)))) {
+    while (__any(mail_empty(a) || (l65 && mail_empty(b)))) {
       if ((++spins & 63u) == 0u &&
           (spins > kSpinLimit || __hip_atomic_load(abandoned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
         return false;
-      __builtin_amdgcn_s_sleep(1);
-      if (mail_empty(a)) a = ld_sc1(line + lane);
-      if (lane == 0 && mail_empty(b)) b = ld_sc1(line + 64);
+      a = a2; b = b2;
+      a2 = ld_sc1(line + lane); b2 = l65 ? ld_sc1(line + 64) : 0.0;
     }
     const double e = __longlong_as_double((long long)kMailEmpty);
     st_sc1(line + lane, e);
-    if (lane == 0) st_sc1(line + 64, e);
+    if (l65) st_sc1(line + 64, e);
     return true;
   };
   // ---- the blocks of sweep 0 from the packed band (written by an earlier kernel): D_k as a full image
@@ -578,16 +584,17 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
         if (lane < L) p.V2[(size_t)(i0 + lane) + (size_t)s * p.ldv2] = r.v;
       } else {
         double a, b;
-        if (!take_line(p.fwd + ((size_t)k * 4 + (s & 3)) * MAILW, a, b)) { if (lane == 0) { give_up(); s_ok = 0; } }
-        s_v[0][lane] = a;
-        if (lane == 0) s_tau[0] = b;
+        // (v_0 = 1 always: tau travels in its place, the message is four whole 128-byte lines)
+        if (!take_line(p.fwd + ((size_t)k * 4 + (s & 3)) * PMAILW, false, a, b)) { if (lane == 0) { give_up(); s_ok = 0; } }
+        s_v[0][lane] = (lane == 0) ? 1.0 : a;
+        if (lane == 0) s_tau[0] = a;
       }
     }
     // ---- the entering column: the late numbers of position k+1's task of the previous sweep
     if (wave == NW - 1 && s > 0) {
       if (lead) {
         double a, b;
-        if (!take_line(p.bwd + ((size_t)k * 4 + ((s - 1) & 3)) * MAILW, a, b)) { if (lane == 0) { give_up(); s_ok = 0; } }
+        if (!take_line(p.bwd + ((size_t)k * 4 + ((s - 1) & 3)) * PMAILW, true, a, b)) { if (lane == 0) { give_up(); s_ok = 0; } }
         // a: entry l = D_{k+1}(l, 0) of the previous sweep; b (lane 0): beta.  Row r of our new last column is entry r + 1
         const double up = dpp_shift<0x130>(a);
         const double beta = lane_value(b, 0), corner = lane_value(a, 0);
@@ -622,41 +629,45 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
       double pp, qq;
       task_partials<CW>(dd, bk, vc, pp, qq);
       s_p[wave][lane] = pp; s_q[wave][lane] = qq;
+      if (wave == 0) s_b0[lane] = bk[0];
     }
     __syncthreads();                                                         // #2
-    // ---- the reflector of position k+1 first: position k+1 is waiting for it
-    double b00 = 0.0;
-    if (wave == 0) {
+    // ---- the reflector of position k+1: position k+1 is waiting for it.  Made by wave RW from column 0 of B_k (which
+    // wave 0 has put into LDS) while wave 0 updates column 0 of D_k, the late numbers position k-1 is waiting for.
+    if (wave == RW) {
       double qs = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) qs += s_q[w][lane];
-      const double col0 = (L1 > 0) ? task_col0(bk[0], tau, qs, vc[0]) : 0.0;
-      b00 = col0;
+      const double col0 = (L1 > 0) ? task_col0(s_b0[lane], tau, qs, s_v[0][0]) : 0.0;
+      double b00 = col0;
       if (k + 1 < K) {
         const Reflector r = reflector_of(col0, lane);
-        double *line = p.fwd + ((size_t)(k + 1) * 4 + (s & 3)) * MAILW;
-        st_sc1(line + lane, r.v);
-        if (lane == 0) st_sc1(line + 64, r.tau);
+        double *line = p.fwd + ((size_t)(k + 1) * 4 + (s & 3)) * PMAILW;
+        st_sc1(line + lane, (lane == 0) ? r.tau : r.v);
         s_v[1][lane] = r.v;
         if (lane == 0) { s_tau[1] = r.tau; p.tau2[(size_t)(k + 1) + (size_t)s * p.ldt] = r.tau; }
         if (lane < L1) p.V2[(size_t)(i0 + SB + lane) + (size_t)s * p.ldv2] = r.v;
         b00 = r.beta;
       }
-      b00 = lane_value(b00, 0);                            // entry (0, 0) of the new B_k
-      if (k > 0 && lane == 0) st_sc1(p.bwd + ((size_t)(k - 1) * 4 + (s & 3)) * MAILW + 64, b00);
+      if (lane == 0) {                                     // entry (0, 0) of the new B_k
+        if (k > 0) st_sc1(p.bwd + ((size_t)(k - 1) * 4 + (s & 3)) * PMAILW + 64, b00);
+        else s_b00 = b00;
+      }
     }
     // ---- D_k <- H D_k H
     double psum = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) psum += s_p[w][lane];
     const double w_r = task_w(tau, psum, v_r);
-#pragma unroll
-    for (int j = 0; j < CW; ++j) dd[j] = task_rank2(dd[j], v_r, lane_value(w_r, c0w + j), w_r, vc[j]);
     if (wave == 0) {
       // column 0 of D_k leaves the position: the late numbers of position k-1, or (position 0) d and the next column
-      if (k > 0) st_sc1(p.bwd + ((size_t)(k - 1) * 4 + (s & 3)) * MAILW + lane, dd[0]);
+      dd[0] = task_rank2(dd[0], v_r, lane_value(w_r, 0), w_r, vc[0]);
+      if (k > 0) st_sc1(p.bwd + ((size_t)(k - 1) * 4 + (s & 3)) * PMAILW + lane, dd[0]);
       else if (lane == 0) st_sc1(AB + (size_t)(s + 1) * LDAB, dd[0]);
     }
+#pragma unroll
+    for (int j = 0; j < CW; ++j)
+      if (!(wave == 0 && j == 0)) dd[j] = task_rank2(dd[j], v_r, lane_value(w_r, c0w + j), w_r, vc[j]);
     // ---- B_k <- B_k H
     double bp[CW];
     {
@@ -673,16 +684,16 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
     }
     if (s == s_last) break;
     // ---- the blocks of the next sweep: one row and one column further down the band
-    if (k == 0 && wave == 0) {
-      const double up = dpp_shift<0x130>(dd[0]);
-      xnext = (lane < 63) ? up : b00;
-    }
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < CW; ++j) s_row[c0w + j] = bp[j];                   // row 0 of B_k: the new last row and column of D_k
     }
     s_x[wave][lane] = dd[0]; s_y[wave][lane] = bp[0];
     __syncthreads();                                                         // #4
+    if (k == 0 && wave == 0) {
+      const double up = dpp_shift<0x130>(dd[0]);
+      xnext = (lane < 63) ? up : s_b00;
+    }
 #pragma unroll
     for (int j = 0; j + 1 < CW; ++j) { dd[j] = dd[j + 1]; bk[j] = bp[j + 1]; }
     dd[CW - 1] = (wave + 1 < NW) ? s_x[(wave + 1) & (NW - 1)][lane] : 0.0;
@@ -1078,7 +1089,7 @@ struct Layout {
     off_tau = o; o += al256((size_t)ldt * (nsweeps + 1) * 8);
     off_prog = o; o += al256((size_t)(nsweeps + 1) * 4);
     off_mail = o; o += al256((size_t)4 * (kmax + 1) * MAILW * 8);
-    off_pmail = o; o += al256((size_t)2 * 4 * (kmax + 2) * MAILW * 8);   // chase_pos_kernel: forward and backward lines
+    off_pmail = o; o += al256((size_t)2 * 4 * (kmax + 2) * PMAILW * 8);   // chase_pos_kernel: forward and backward lines
     off_retired = o; o += al256((size_t)(kmax + 2) * 4);
     off_ctl = o; o += 256;
     off_T = o; o += al256((size_t)nS * kmax * QREC * 8);
@@ -1120,7 +1131,7 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
   unsigned *prog = (unsigned *)(w + L.off_prog), *ctl = (unsigned *)(w + L.off_ctl);
   double *mail = (double *)(w + L.off_mail), *pmail = (double *)(w + L.off_pmail);
   unsigned *retired = (unsigned *)(w + L.off_retired);
-  const int nmail = 4 * (L.kmax + 1) * MAILW, npmail = 2 * 4 * (L.kmax + 2) * MAILW;
+  const int nmail = 4 * (L.kmax + 1) * MAILW, npmail = 2 * 4 * (L.kmax + 2) * PMAILW;
   hipLaunchKernelGGL(pack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB);
   (void)hipMemsetAsync(tau2, 0, (size_t)L.ldt * (L.nsweeps + 1) * 8, s);
   (void)hipMemsetAsync(prog, 0, (size_t)(L.nsweeps + 1) * 4 + 0, s);
@@ -1137,11 +1148,14 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
       hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(npmail, 256)), dim3(256), 0, s, pmail, npmail);
       (void)hipMemsetAsync(retired, 0, (size_t)(L.kmax + 2) * 4, s);
       hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, s, retired + K0, 1u);   // there is no position K0
-      const int per = ceil_div(K0, 8);
+      // neighbours on one XCD (EK_SB2ST_XCDMAP=1) buy nothing at one workgroup per CU (N = 16384: 52.0 vs 51.6 ms) and
+      // cost at two (N = 32768: 143 vs 125 ms: the two workgroups of a CU are then close in the pipeline and busy together)
+      int per = 0;
+      if (const char *ev = getenv("EK_SB2ST_XCDMAP")) { if (atoi(ev) != 0) per = ceil_div(K0, 8); }
       unsigned census = 1u << 16;                            // x ~0.3 us: what a workgroup waits for the others to arrive
       if (const char *ev = getenv("EK_SB2ST_CENSUS_SPINS")) census = (unsigned)atoi(ev);
-      PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * MAILW, retired, ctl, per, census};
-      hipLaunchKernelGGL(chase_pos_kernel, dim3(per * 8), dim3(512), 0, s, a);
+      PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * PMAILW, retired, ctl, per, census};
+      hipLaunchKernelGGL(chase_pos_kernel, dim3(per > 0 ? per * 8 : K0), dim3(512), 0, s, a);
       hipLaunchKernelGGL(repack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB, ctl);
     }
     hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(nmail, 256)), dim3(256), 0, s, mail, nmail);
