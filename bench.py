@@ -138,15 +138,17 @@ def gpu_step_at(lib, torch, dev, problem, n, steps=3):
     dw = torch.empty((n,), dtype=torch.float64, device=dev)
     tot = 0.0
     for it in range(steps + 1):
-        assert lib.ek_hip_synth_matrix_device(n, 1, dA.data_ptr(), n) == 0
-        if problem == 1:
-            assert lib.ek_hip_synth_matrix_device(n, 2, dB.data_ptr(), n) == 0
+        if lib.ek_hip_synth_matrix_device(n, 1, dA.data_ptr(), n) != 0:
+            raise RuntimeError("synth")
+        if problem == 1 and lib.ek_hip_synth_matrix_device(n, 2, dB.data_ptr(), n) != 0:
+            raise RuntimeError("synth")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         info = lib.ek_hip_solve_device(problem, n, n, dA.data_ptr(), n, dB.data_ptr() if problem == 1 else None, n,
                                        dw.data_ptr(), dZ.data_ptr(), n, None, 0)
         torch.cuda.synchronize()
-        assert info == 0, info
+        if info != 0:
+            raise RuntimeError("ek_hip_solve_device info=%d" % info)
         if it > 0:
             tot += time.perf_counter() - t0
     sec = tot / steps
@@ -159,16 +161,17 @@ def host_path_step(lib, solver, problem, n, n_vec):
     staging included.  Inputs are generated on the device and copied out first."""
     import numpy as np
     from eigenkernel_amd import descriptor as dsc
+    tmp = ctypes.c_void_p()
     try:
         A = np.zeros((n, n), order="F"); B = np.zeros((n, n), order="F") if problem == 1 else None
         Z = np.zeros((n, n), order="F"); w = np.zeros(n)
-        tmp = ctypes.c_void_p()
-        assert lib.ek_hip_malloc(ctypes.byref(tmp), n * n * 8) == 0
+        if lib.ek_hip_malloc(ctypes.byref(tmp), n * n * 8) != 0:
+            return {"error": "ek_hip_malloc"}
         for seed, M in ((1, A), (2, B)):
             if M is not None:
-                assert lib.ek_hip_synth_matrix_device(n, seed, tmp, n) == 0
-                assert lib.ek_hip_memcpy_d2h(M.ctypes.data, tmp, n * n * 8) == 0
-        lib.ek_hip_free(tmp)
+                if lib.ek_hip_synth_matrix_device(n, seed, tmp, n) != 0 or lib.ek_hip_memcpy_d2h(M.ctypes.data, tmp, n * n * 8) != 0:
+                    return {"error": "input generation"}
+        lib.ek_hip_free(tmp); tmp = ctypes.c_void_p()
         desc = dsc.descinit(n, n, 64, 64, 0, 0, 0, n)
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
         st = (ctypes.c_double * 8)()
@@ -181,8 +184,99 @@ def host_path_step(lib, solver, problem, n, n_vec):
             return {"error": "ek_hip_solve info=%d" % info}
         return {"value": n_vec / sec, "unit": "eigenpairs/s", "seconds": sec, "host_device_copies_seconds": st[7],
                 "note": "one ek_hip_solve call on pageable host arrays (A, B in; Z, A, B, w out)"}
-    except MemoryError as exc:
+    except Exception as exc:      # an optional extra never takes the line down
         return {"error": repr(exc)}
+    finally:
+        if tmp:
+            lib.ek_hip_free(tmp)
+
+
+def run_other_config(lib, torch, dev, name, steps, warmup):
+    """One more BASELINE configuration on this GPU after the headline region: `steps` timed solves (each between
+    synchronisations, inputs regenerated outside the timed part), parity of the last output through the reference's
+    acceptance quantities, and the fraction of the fp64 matrix peak its largest kernel (q2_apply_kernel) reached."""
+    n, prob, nv = CONFIGS[name]
+    problem = 1 if prob == "gep" else 0
+    n_vec = nv if 0 < nv < n else n
+    dA = torch.empty((n, n), dtype=torch.float64, device=dev)
+    dB = torch.empty((n, n), dtype=torch.float64, device=dev) if problem == 1 else None
+    dZ = torch.empty((n, n), dtype=torch.float64, device=dev)
+    dw = torch.empty((n,), dtype=torch.float64, device=dev)
+    stage = (ctypes.c_double * 8)()
+    ssum = [0.0] * 8
+
+    def regen():
+        if lib.ek_hip_synth_matrix_device(n, 1, dA.data_ptr(), n) != 0:
+            raise RuntimeError("synth")
+        if problem == 1 and lib.ek_hip_synth_matrix_device(n, 2, dB.data_ptr(), n) != 0:
+            raise RuntimeError("synth")
+
+    tot = 0.0
+    kp_s, kp_l = (ctypes.c_double * 4)(), (ctypes.c_longlong * 4)()
+    for it in range(warmup + steps):
+        regen()
+        if it == warmup:
+            lib.ek_hip_profile_kernels(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = lib.ek_hip_solve_device(problem, n, n_vec, dA.data_ptr(), n, dB.data_ptr() if problem == 1 else None, n,
+                                       dw.data_ptr(), dZ.data_ptr(), n, stage, 8)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if info != 0:
+            lib.ek_hip_profile_kernels(0)
+            raise RuntimeError("ek_hip_solve_device info=%d" % info)
+        if it >= warmup:
+            tot += dt
+            for q in range(8):
+                ssum[q] += stage[q]
+    lib.ek_hip_profile_kernels_get(kp_s, kp_l)
+    lib.ek_hip_profile_kernels(0)
+    sec = tot / steps
+    res = {"config": {"workload": "synthetic (SURVEY 8(d)) N=%d %s, %s" % (
+               n, "generalized EVP" if problem == 1 else "standard EVP",
+               "full spectrum" if n_vec == n else "lowest %d eigenpairs" % n_vec), "n": n, "problem": prob, "n_vec": n_vec},
+           "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * sec, "value": n_vec / sec, "unit": "eigenpairs/s",
+           "tflops_equiv": flops(problem, n, n_vec) / sec / 1e12,
+           "stage_seconds_per_step": {lib.ek_hip_stage_name(q).decode(): ssum[q] / steps for q in range(8)}}
+    if kp_l[0] > 0 and kp_s[0] > 0:
+        dur = kp_s[0] / kp_l[0]
+        fl = 2.0 * n * n * n_vec
+        res["dominant_kernel"] = {"kernel": "q2_apply_kernel", "avg_launch_us": 1e6 * dur, "achieved": fl / dur / 1e12,
+                                  "unit": "TFLOP/s", "frac": fl / dur / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                  "chase_avg_launch_us": 1e6 * kp_s[1] / max(kp_l[1], 1)}
+    w = dw.cpu().numpy()
+    ok = bool((w[1:n_vec] >= w[:n_vec - 1]).all())
+    regen()
+    an, ave, mx, orth = (ctypes.c_double(0) for _ in range(4))
+    rc1 = lib.ek_hip_residual_device(problem, n, n_vec, dA.data_ptr(), n, dB.data_ptr() if problem == 1 else None, n,
+                                     dw.data_ptr(), dZ.data_ptr(), n, ctypes.byref(an), ctypes.byref(ave), ctypes.byref(mx))
+    rc2 = lib.ek_hip_orthogonality_device(problem, n, 1, n_vec, dB.data_ptr() if problem == 1 else None, n,
+                                          dZ.data_ptr(), n, ctypes.byref(orth))
+    bound = 1e-14 * max(1.0, (n / 1024.0) ** 0.5)
+    res["parity"] = {"residual_norm_max": mx.value, "orthogonality": orth.value,
+                     "bounds": {"residual_norm_max": bound, "orthogonality": 1e-11},
+                     "ok": bool(ok and rc1 == 0 and rc2 == 0 and mx.value <= bound and orth.value <= 1e-11)}
+    return res
+
+
+def q2_traffic_record(n, ncols):
+    """HBM bytes per q2_apply_kernel launch from the committed PMC measurement -- only while the kernel's source is
+    the file the measurement was taken from (the record carries its sha256); a stale record is not reported."""
+    import hashlib
+    tpath = os.path.join(ROOT, "profiles", "r03_q2_apply_traffic.json")
+    src = os.path.join(ROOT, "eigenkernel_amd", "csrc", "ek_sb2st.hip")
+    try:
+        tj = json.load(open(tpath))
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+        if tj.get("n") != n or tj.get("ncols") != int(ncols):
+            return None, "profiles/r03_q2_apply_traffic.json is for another shape"
+        if tj.get("source_sha256") != sha:
+            return None, "profiles/r03_q2_apply_traffic.json is stale: ek_sb2st.hip has changed since it was measured"
+        return tj.get("hbm_bytes_per_launch"), ("profiles/r03_q2_apply_traffic.json (rocprofv3 --pmc at git %s, not live)"
+                                                % tj.get("git", "?"))
+    except Exception as exc:
+        return None, "no PMC record (%r)" % (exc,)
 
 
 _emitted = False
@@ -398,7 +492,7 @@ def main():
                     help="lowest n_vec eigenpairs only (the *_select arms, BASELINE.json configs[4]); 0 = all")
     ap.add_argument("--cpu-sample-n", type=int, default=1536,
                     help="order of the CPU-oracle sample (scalar C port, 1 core)")
-    ap.add_argument("--scalapack-sample-n", type=int, default=4096,
+    ap.add_argument("--scalapack-sample-n", type=int, default=6144,
                     help="order of the ScaLAPACK-path sample (all physical cores)")
     ap.add_argument("--distribution", choices=["auto", "replicas", "columns", "grid"], default="auto",
                     help="N>1 GPUs: 'auto' (default) = measure replicas first (one independent problem per rank: "
@@ -418,6 +512,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the ScaLAPACK baseline (mandatory under a profiler: 64 MPI ranks are not to be profiled)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive step (value_incl_copies)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other BASELINE configurations (c2, c5, c4 at full size, a few steps each) that the "
+                         "default single-GPU run appends as \"other_configs\"")
     ap.add_argument("--no-symv-events", action="store_true")
     ap.add_argument("--symv-events-stride", type=int, default=8,
                     help="time the symv launch of every k-th column with HIP events (1 = all launches; "
@@ -609,15 +706,7 @@ def main():
             fl = 2.0 * n * n * k
             dur = kp_s[0] / kp_l[0]
             ach = fl / dur / 1e12
-            traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_q2_apply_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("n") == n and tj.get("ncols") == int(k):
-                        traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/r02_q2_apply_traffic.json (rocprofv3 --pmc, not live)"
-                except Exception:
-                    pass
+            traffic, tsrc = q2_traffic_record(n, k)
             out["roofline"] = {
                 "kernel": "q2_apply_kernel (Z <- Q2 Z: reflectors of the band->tridiagonal stage, compact-WY blocks of 32 "
                           "sweeps applied two blocks per pass, window of Z resident in MFMA accumulator registers)",
@@ -626,7 +715,7 @@ def main():
                 "launches": int(kp_l[0]), "avg_launch_us": 1e6 * dur, "algorithmic_flops_per_launch": fl,
                 "measured_mfma_ceiling_tflops": 69.0,   # largest GEMM shapes of this library (profiles/r02_gemm_shapes_n16384_v6.txt); register-only loop: 49.6
                 "other_kernels": {
-                    "chase_kernel (band -> tridiagonal, latency-bound pipeline of sweeps)":
+                    "chase_pos_kernel (band -> tridiagonal: positions of the band in registers, sweeps pass through by mail)":
                         {"launches": int(kp_l[1]), "avg_launch_us": 1e6 * kp_s[1] / max(kp_l[1], 1)},
                     "symm_lower_kernel (Y = A22 V of every 8th panel)":
                         {"launches": int(kp_l[2]), "avg_launch_us": 1e6 * kp_s[2] / max(kp_l[2], 1)}},
@@ -652,27 +741,71 @@ def main():
             }
         else:
             out["roofline"] = None
-        # per stage: algorithmic flops of SURVEY.md 8(d) (K1 n^3/3, K2 n^3, K3 4n^3/3, K5 ~4n^3/3, K6 2 n^2 k,
-        # K7 n^2 k) over the stage's device seconds, against the fp64 matrix peak
-        st_fl = {"reduce_generalized:pdpotrf": n3 / 3 if problem == 1 else 0.0,
-                 "reduce_generalized:pdsygst": n3 if problem == 1 else 0.0,
-                 "eigen_solver_scalapack_all:pdsytrd": 4 * n3 / 3,
-                 "eigen_solver_scalapack_all:pdstedc": 4 * n3 / 3 if k == n else 2 * n3 / 3 + 2 * n * n * k / 3,
-                 "eigen_solver_scalapack_all:pdormtr": 2.0 * n * n * k,
-                 "recovery_generalized": n * n * k if problem == 1 else 0.0}
+        # per stage: algorithmic flops of SURVEY.md 8(d) (K1 n^3/3, K2 n^3, K3 4n^3/3, K5 4n^3/3 NOMINAL, K6 2 n^2 k,
+        # K7 n^2 k) over the stage's device seconds, against the fp64 matrix peak -- and, where the path executes a
+        # different count, that count beside it: the divide & conquer runs what deflation leaves (counted on the
+        # device from the merge products' dimensions; the nominal figure is an upper bound, so ITS fraction is the
+        # executed one), the two-stage back-transformation applies two sets of reflectors (Q2 and Q1: 4 n^2 k).
+        stats = (ctypes.c_double * 8)()
+        lib.ek_hip_debug_last_solve_stats(stats, 8)
+        dc_exec, two_stage = float(stats[0]), stats[1] > 0.5
+        st_fl = {"reduce_generalized:pdpotrf": (n3 / 3 if problem == 1 else 0.0, None),
+                 "reduce_generalized:pdsygst": (n3 if problem == 1 else 0.0, None),
+                 "eigen_solver_scalapack_all:pdsytrd": (4 * n3 / 3, None),
+                 "eigen_solver_scalapack_all:pdstedc": (4 * n3 / 3 if k == n else 2 * n3 / 3 + 2 * n * n * k / 3,
+                                                        dc_exec if dc_exec > 0 else None),
+                 "eigen_solver_scalapack_all:pdormtr": (2.0 * n * n * k, 4.0 * n * n * k if two_stage else None),
+                 "recovery_generalized": (n * n * k if problem == 1 else 0.0, None)}
         out["roofline_stages"] = {}
-        for name, fl in st_fl.items():
+        fl_exec_total = 0.0
+        for name, (fl, fx) in st_fl.items():
             sec = out["stage_seconds_per_step"].get(name, 0.0)
+            fl_exec_total += fx if fx is not None else fl
             if fl > 0 and sec > 0:
-                out["roofline_stages"][name] = {"algorithmic_flops": fl, "seconds": sec, "tflops": fl / sec / 1e12,
-                                                "frac_of_fp64_mfma_peak": fl / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+                e = {"algorithmic_flops": fl, "seconds": sec, "tflops": fl / sec / 1e12}
+                if fx is not None:
+                    e["executed_flops"] = fx
+                    e["tflops_executed"] = fx / sec / 1e12
+                if name.endswith("pdstedc") and fx is not None:
+                    e["algorithmic_flops_note"] = "LAPACK's nominal count without deflation: an upper bound, not priced"
+                    e["frac_of_fp64_mfma_peak"] = fx / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS
+                else:
+                    e["frac_of_fp64_mfma_peak"] = fl / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS
+                out["roofline_stages"][name] = e
+        out["tflops_executed"] = (1 if columns else world) * fl_exec_total * K / total / 1e12
+        out["tflops_equiv_note"] = ("tflops_equiv prices the solve with SURVEY.md 8(d)'s nominal F(N) (BASELINE.json's metric); "
+                                    "tflops_executed with what the path ran: D&C after deflation, both back-transformations of "
+                                    "the two-stage form")
+        _pending = out      # the headline exists from here on: none of the extras below can take it down
         if world == 1 and not columns and not args.no_host_path:
-            out["value_incl_copies"] = host_path_step(lib, solver, problem, n, n_vec)
+            try:
+                out["value_incl_copies"] = host_path_step(lib, solver, problem, n, n_vec)
+            except Exception as exc:
+                out["value_incl_copies"] = {"error": repr(exc)}
+        if world == 1 and not columns and not args.no_other_configs and (n, args.problem, n_vec) == (16384, "gep", 16384):
+            # every other BASELINE configuration at full size on this GPU, driver-timed in the same run
+            del dAs[:]
+            if dBs is not None:
+                del dBs[:]
+            torch.cuda.empty_cache()
+            out["other_configs"] = {}
+            for name, st, wu in (("c2", 10, 2), ("c5", 5, 1), ("c4", 2, 1)):
+                try:
+                    out["other_configs"][name] = run_other_config(lib, torch, dev, name, st, wu)
+                except Exception as exc:
+                    out["other_configs"][name] = {"error": repr(exc)}
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
-            base = cpu_baseline_scalapack(problem, args.scalapack_sample_n)
-            out["cpu_baseline"] = base if base is not None else cpu_baseline(problem, args.cpu_sample_n)
-            sn = args.scalapack_sample_n if base is not None else args.cpu_sample_n
-            out["cpu_baseline"]["gpu_same_order"] = gpu_step_at(lib, torch, dev, problem, sn)
+            try:
+                base = cpu_baseline_scalapack(problem, args.scalapack_sample_n)
+                out["cpu_baseline"] = base if base is not None else cpu_baseline(problem, args.cpu_sample_n)
+                sn = args.scalapack_sample_n if base is not None else args.cpu_sample_n
+                try:
+                    out["cpu_baseline"]["gpu_same_order"] = gpu_step_at(lib, torch, dev, problem, sn)
+                except Exception as exc:
+                    out["cpu_baseline"]["gpu_same_order"] = {"error": repr(exc)}
+            except Exception as exc:
+                out["cpu_baseline"] = {"error": repr(exc)}
         _pending = out
     if ((world > 1 or args.force_grid_probe) and dist is not None and args.distribution in ("auto", "replicas")
             and not args.no_grid_probe):

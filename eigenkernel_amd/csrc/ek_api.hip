@@ -31,6 +31,8 @@ struct Context {
   size_t ws_bytes = 0;
   int *d_info = nullptr;
   double *d_status = nullptr;   // one word for the team's status agreements (comm_agree)
+  double *d_stats = nullptr;    // [8] counters of the last whole-path solve ([0] flops the D&C merge products executed)
+  double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 Context g_ctx;
 std::mutex g_mu;
@@ -54,6 +56,8 @@ int ensure_init() {
   }
   EK_HIP_CHECK(hipMalloc((void **)&g_ctx.d_info, 64 * sizeof(int)));
   EK_HIP_CHECK(hipMalloc((void **)&g_ctx.d_status, 64));
+  EK_HIP_CHECK(hipMalloc((void **)&g_ctx.d_stats, 64));
+  EK_HIP_CHECK(hipMemset(g_ctx.d_stats, 0, 64));
   g_ctx.ready = true;
   return 0;
 }
@@ -401,6 +405,21 @@ SytrdExchange team_exchange(int nteam, int n = 0) {
 // over the attached communicator and all of them leave together -- the failing rank with its own code,
 // the others with -993.  Returns 0 when every rank is fine.  (The word lives in memory allocated at
 // initialisation, so the agreement itself needs nothing that could fail locally.)
+// 1 if `local` is non-zero on ANY rank of the team (the same answer on all of them), else 0; < 0: the exchange failed
+int comm_any(int local) {
+  if (!g_comm.on || g_comm.nranks <= 1) return local ? 1 : 0;
+  const SytrdExchange x = team_exchange(0);
+  double st = local ? 1.0 : 0.0;
+  bool ok = hipMemcpy(g_ctx.d_status, &st, sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  double *bufs[1] = {g_ctx.d_status};
+  g_comm.err = 0;
+  x.allreduce(g_ctx.stream, 1, bufs, 1, x.user);
+  ok = ok && hipStreamSynchronize(g_ctx.stream) == hipSuccess && !g_comm.err;
+  ok = ok && hipMemcpy(&st, g_ctx.d_status, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  if (!ok) return -996;
+  return st != 0.0 ? 1 : 0;
+}
+
 int comm_agree(int local_rc) {
   if (!g_comm.on || g_comm.nranks <= 1) return local_rc;
   const SytrdExchange x = team_exchange(0);
@@ -1280,6 +1299,14 @@ int ek_hip_profile_kernels_get(double *seconds, long long *launches) {
   return 0;
 }
 
+// counters of the last whole-path solve of this process: out[0] = flops executed by the merge products of the
+// divide & conquer (after deflation and column selection), out[1] = 1 if the tridiagonalisation ran in two stages
+int ek_hip_debug_last_solve_stats(double *out, int count) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < count && i < 8; ++i) out[i] = g_ctx.stats[i];
+  return 0;
+}
+
 // Timing of the two-stage pieces on a device-generated synthetic matrix of order n:
 // seconds[0] dense -> band, [1] band -> tridiagonal, [2] Q2 applied to ncols columns, [3] Q1 applied.
 int ek_hip_debug_two_stage_timing(int n, int ncols, int reps, double *seconds, int *flag) {
@@ -1719,9 +1746,13 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     EK_HIP_CHECK(hipMemsetAsync(dt1, 0, (size_t)ld * 8, s));
     sy2sb_lower(s, g_ctx.stream2, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
     sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st);
+    // (the bulge chasing does nothing when the first stage has raised its flag: the band is not valid then)
     int flag = 0;
     EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
     EK_HIP_CHECK(hipStreamSynchronize(s));
+    // a team decides together: a flag that only one rank has raised (an abandoned wait depends on timing, not on the
+    // data) must not leave the ranks with eigenvectors of two different decompositions
+    if (dist) { flag = comm_any(flag); if (flag < 0) return flag; }
     if (flag == 0) two_stage_done = true;
     else {
       EK_HIP_CHECK(hipMemcpyAsync(wA, wA0, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
@@ -1737,7 +1768,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // forms only those (columns 0..nc_loc-1 of wZ) and the two remaining stages treat the
   // columns of Z independently
   const StedcSelect pick{nc_loc, cell ? cell->nb : (n > 0 ? n : 1), cell ? cell->npcol : 1, cell ? cell->mycol : 0};
-  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick);
+  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats);
   mark();                                                              // 5
   double *zc = wZ;
   if (two_stage_done) {
@@ -1765,7 +1796,9 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   EK_HIP_CHECK(hipGetLastError());
   int info[4] = {0, 0, 0, 0};
   EK_HIP_CHECK(hipMemcpyAsync(info, g_ctx.d_info, sizeof(info), hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipMemcpyAsync(g_ctx.stats, g_ctx.d_stats, sizeof(g_ctx.stats), hipMemcpyDeviceToHost, s));
   EK_HIP_CHECK(hipStreamSynchronize(s));
+  g_ctx.stats[1] = two_stage_done ? 1.0 : 0.0;
   if (timing) {
     float ms[8];
     for (int i = 0; i < 8; ++i) (void)hipEventElapsedTime(&ms[i], tm.ev[i], tm.ev[i + 1]);
@@ -1782,7 +1815,11 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", comm_error_string());
     return -996;
   }
-  if (two_stage_done && info[2] != 0) return -992;   // the pipelined back-transformation was abandoned (a bounded wait ran out)
+  if (two_stage_done) {   // the pipelined back-transformation was abandoned (a bounded wait ran out): on a team, for all ranks
+    int bad = info[2] != 0;
+    if (dist) bad = comm_any(bad);
+    if (bad) return bad < 0 ? bad : -992;
+  }
   if (info[0] != 0) return info[0];          // Cholesky: leading minor not positive definite
   if (info[1] != 0) return 100000 + info[1];  // tridiagonal eigensolver did not converge
   return 0;

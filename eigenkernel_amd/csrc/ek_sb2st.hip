@@ -120,6 +120,7 @@ struct ChaseArgs {
   double *mail; int kmax;   // mailbox lines [4][kmax][MAILW]
   long long *prof;       // optional: [0..5] shader cycles per phase of a task summed over workgroup 0's tasks, [6] tasks
   int only_if_abandoned; // run only if ctl[3] is set (the fall-back behind chase_pos_kernel)
+  const int *skip;       // device: non-zero = the band is not valid (the first stage raised its flag): do nothing
 };
 
 constexpr unsigned kSpinLimit = 1u << 22;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
   const int c0w = CW * wave;                               // this wave's columns of a block
   double *AB = p.AB;
   if (p.only_if_abandoned && !__hip_atomic_load(&p.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  if (p.skip && *p.skip) return;
   if (t == 0) s_ok = 1;
   auto give_up = [&]() { __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   // bounded wait until *w >= need
@@ -488,6 +490,7 @@ struct PosArgs {
   unsigned *ctl;         // [3] abandoned, [4] census of the workgroups
   int per;               // 0: workgroup b holds position b; > 0: position (b & 7) * per + (b >> 3), neighbours mostly on one XCD
   unsigned census_spins;
+  const int *skip;       // device: non-zero = the band is not valid (the first stage raised its flag): do nothing
 };
 
 template <int CTRL>
@@ -509,6 +512,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int k = p.per > 0 ? (int)(blockIdx.x & 7) * p.per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (k >= p.K0) return;
+  if (p.skip && *p.skip) return;
   const int n = p.n;
   const int c0w = CW * wave;
   double *AB = p.AB;
@@ -740,7 +744,9 @@ constexpr int QVLD = QG + 1;           // LDS leading dimension of the V image (
 constexpr int QREC = 2 * QR * QVLD;    // doubles per group record: the LDS images of V and of -(V T) (96 x 33, row-major)
 
 struct Q2Geom {
-  int n, nsweeps, nS, kmax;            // kmax: groups per block of sweeps (uniform index S * kmax + k)
+  int n, nsweeps, nS, kmax;            // kmax: groups of block 0 (the most any block has)
+  const unsigned *offS;                // [nS + 1] device: first record of block S (block S has q2_groups_of_block(n, S) of them:
+                                       // the store is a triangle, not nS x kmax)
 };
 __host__ __device__ inline int q2_first_sweep(int S) { return S * QG - 1; }
 __host__ __device__ inline int q2_groups_of_block(int n, int S) {   // number of k for which any reflector exists
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(256) void q2_tfactor_kernel(Q2Geom g, const double 
   const int S = blockIdx.y, k = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   if (k >= q2_groups_of_block(g.n, S)) return;
-  double *rec = Rec + ((size_t)S * g.kmax + k) * QREC;
+  double *rec = Rec + ((size_t)g.offS[S] + k) * QREC;
   for (int idx = t; idx < QR * QG; idx += 256) {
     const int rr = idx % QR, i = idx / QR;
     const double v = q2_v_entry(g, V2, ldv2, S, k, rr, i);
@@ -918,7 +924,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
     double zreg[16];
     d2_t oreg[NOP];
     auto fetch_ops = [&](int Sb, int k) {                // the record is the LDS image itself: a linear copy
-      const d2_t *rec = reinterpret_cast<const d2_t *>(p.Rec + ((size_t)Sb * p.g.kmax + k) * QREC);
+      const d2_t *rec = reinterpret_cast<const d2_t *>(p.Rec + ((size_t)p.g.offS[Sb] + k) * QREC);
 #pragma unroll
       for (int q = 0; q < NOP; ++q) oreg[q] = (q < NOP - 1 || t + 256 * q < NPAIR) ? rec[t + 256 * q] : (d2_t){0.0, 0.0};
     };
@@ -1073,12 +1079,20 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
 }
 
 __global__ void forward_abort_kernel(const unsigned *ctl, int *flag) { if (ctl[1]) atomicOr(flag, 4); }
+__global__ void q2_offsets_kernel(int n, int nS, unsigned *offS) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    unsigned o = 0;
+    for (int S = 0; S < nS; ++S) { offS[S] = o; o += (unsigned)q2_groups_of_block(n, S); }
+    offS[nS] = o;
+  }
+}
 
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Layout {
   int nsweeps, nS, kmax, ldt;
-  size_t off_ab, off_tau, off_prog, off_mail, off_pmail, off_retired, off_ctl, off_T, off_qprog, total;
+  size_t off_ab, off_tau, off_prog, off_mail, off_pmail, off_retired, off_ctl, off_T, off_qprog, off_offs, total;
+  size_t nrec;
   explicit Layout(int n) {
     nsweeps = n > 2 ? n - 2 : 0;
     nS = ceil_div((nsweeps > 0 ? nsweeps : 1) + 1, QG);   // block S = sweeps 32 S - 1 .. 32 S + 30
@@ -1092,8 +1106,11 @@ struct Layout {
     off_pmail = o; o += al256((size_t)2 * 4 * (kmax + 2) * PMAILW * 8);   // chase_pos_kernel: forward and backward lines
     off_retired = o; o += al256((size_t)(kmax + 2) * 4);
     off_ctl = o; o += 256;
-    off_T = o; o += al256((size_t)nS * kmax * QREC * 8);
+    nrec = 0;
+    for (int S = 0; S < nS; ++S) nrec += (size_t)q2_groups_of_block(n, S);
+    off_T = o; o += al256((nrec + 1) * QREC * 8);
     off_qprog = o; o += al256((size_t)nS * ceil_div(n, QNC) * 4);
+    off_offs = o; o += al256((size_t)(nS + 1) * 4);
     total = o;
   }
 };
@@ -1154,12 +1171,12 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
       if (const char *ev = getenv("EK_SB2ST_XCDMAP")) { if (atoi(ev) != 0) per = ceil_div(K0, 8); }
       unsigned census = 1u << 16;                            // x ~0.3 us: what a workgroup waits for the others to arrive
       if (const char *ev = getenv("EK_SB2ST_CENSUS_SPINS")) census = (unsigned)atoi(ev);
-      PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * PMAILW, retired, ctl, per, census};
+      PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * PMAILW, retired, ctl, per, census, d_flag};
       hipLaunchKernelGGL(chase_pos_kernel, dim3(per > 0 ? per * 8 : K0), dim3(512), 0, s, a);
       hipLaunchKernelGGL(repack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB, ctl);
     }
     hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(nmail, 256)), dim3(256), 0, s, mail, nmail);
-    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, mail, L.kmax + 1, nullptr, pos ? 1 : 0};
+    ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, mail, L.kmax + 1, nullptr, pos ? 1 : 0, d_flag};
     if (getenv("EK_SB2ST_PROF")) { c.prof = (long long *)(ctl + 16); }
     // enough workgroups for the pipeline (a sweep starts one task behind its predecessor)
     int nwg = n / SB + 8;
@@ -1200,7 +1217,9 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   const double *tau2 = (const double *)(w + L.off_tau);
   double *Rec = (double *)(w + L.off_T);
   unsigned *ctl = (unsigned *)(w + L.off_ctl), *qprog = (unsigned *)(w + L.off_qprog);
-  Q2Geom g{n, L.nsweeps, L.nS, L.kmax};
+  unsigned *offS = (unsigned *)(w + L.off_offs);
+  hipLaunchKernelGGL(q2_offsets_kernel, dim3(1), dim3(64), 0, s, n, L.nS, offS);
+  Q2Geom g{n, L.nsweeps, L.nS, L.kmax, offS};
   hipLaunchKernelGGL(q2_tfactor_kernel, dim3(L.kmax, L.nS), dim3(256), 0, s, g, V2, ldv2, tau2, L.ldt, Rec);
   constexpr size_t lds = (size_t)(QOPSZ + 4 * 16 * QSTLD) * sizeof(double);
   static bool attr = false;

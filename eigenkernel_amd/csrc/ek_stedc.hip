@@ -666,8 +666,23 @@ struct WorkLayout {
 
 size_t stedc_work_bytes(int n) { return WorkLayout(n > 0 ? n : 1).total; }
 
+namespace {
+// flops of the eigenvector products this solve really ran: 2 M N K over the two GEMMs of every merge, with the
+// dimensions the deflation (and the column selection of the top merge) left on the device
+__global__ void dc_flops_kernel(int nmerge, const int *__restrict__ gdims, double *out) {
+  __shared__ double s_sum[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < 2 * nmerge; i += 256)
+    a += 2.0 * (double)gdims[3 * i] * (double)gdims[3 * i + 1] * (double)gdims[3 * i + 2];
+  s_sum[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s_sum[threadIdx.x] += s_sum[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = s_sum[0];
+}
+}  // namespace
+
 void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z, int ldz,
-           void *work, int *d_info, const StedcSelect *sel) {
+           void *work, int *d_info, const StedcSelect *sel, double *d_flops) {
   if (n <= 0) return;
   const WorkLayout L(n);
   char *base = (char *)work;
@@ -740,6 +755,9 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
   hipLaunchKernelGGL(dc_leaf_kernel, dim3((int)plan.leaves.size()), dim3(64), 0, s, d_leaves, b, Q, ldq,
                      d_info);
 
+  auto count_flops = [&]() {
+    if (d_flops) hipLaunchKernelGGL(dc_flops_kernel, dim3(1), dim3(256), 0, s, (int)all.size(), b.gdims, d_flops);
+  };
   double *W = Z;   // the output array doubles as the permuted-basis scratch until the end
   const bool selecting = sel && sel->nsel < n;
   bool sel_done = false;
@@ -793,6 +811,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     gemm(s, g);
     hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldz, Q, ldq);
   }
+  count_flops();
   if (sel_done) return;
   hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n * RP, 256)), dim3(256), 0, s, n, b, w, fperm, d_info);
   if (selecting) {

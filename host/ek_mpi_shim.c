@@ -33,7 +33,10 @@ int ekm_allgatherv(const double *send, long long count, double *recv, const long
   const long long slab = 1ll << 27;   /* doubles per rank and round */
   long long maxc = 0;
   for (int r = 0; r < np; ++r) if (counts[r] > maxc) maxc = counts[r];
-  if (counts[me] != count) return -1;
+  /* a rank whose own count disagrees with the table must not leave the collective alone: agree first */
+  int bad = (counts[me] != count) ? 1 : 0, anybad = 0;
+  MPI_Allreduce(&bad, &anybad, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+  if (anybad) return -1;
   int *cnt = (int *)malloc(sizeof(int) * (size_t)np), *dsp = (int *)malloc(sizeof(int) * (size_t)np);
   if (!cnt || !dsp) { free(cnt); free(dsp); return -2; }
   int rc = 0;

@@ -22,6 +22,17 @@
  *     <= -1000 = HIP runtime error (-1000 - hipError_t);
  *     ek_hip_solve*: -4 also when A contains NaN/Inf; 100000 + k = the tridiagonal eigensolver
  *     failed (k <= n: QL iteration of the leaf containing row k; k = n+1: non-finite eigenvalue);
+ *     the values -990 .. -999 are NOT argument indices (no entry has that many arguments) but
+ *     states of the device pipeline and of the team, decided jointly by all ranks of a grid:
+ *       -992  a bounded wait inside a persistent kernel of the two-stage path ran out (the
+ *             application of the bulge-chasing reflectors was abandoned; outputs undefined),
+ *       -993  another rank of the team failed (workspace, staging, peer windows): this rank's
+ *             own step was fine, the call ended on all ranks together,
+ *       -994  rank / grid-cell mismatch with the attached communicator,
+ *       -995  no communicator attached,  -996  exchange (RCCL / host hook) failed,
+ *       -997  RCCL not loadable,  -998  no all-gather hook registered,  -999  the hook failed;
+ *     a host of the reference's shape must test these before reading info < 0 as "argument -info
+ *     illegal" (XERBLA's meaning); INTEGRATION.md section 4 has the table;
  *   - SPMD: called once, collectively, by the single main thread of every rank
  *     (main.f90:100-104), one rank per GPU.  Grids larger than 1x1 need a way to exchange data:
  *     the RCCL communicator (ek_hip_comm_init), the host communicator (ek_hip_comm_attach_host)

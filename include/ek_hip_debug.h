@@ -52,6 +52,12 @@ int ek_hip_debug_sb2st(int n, const double *A, int lda, double *d, double *e, do
 int ek_hip_debug_two_stage_timing(int n, int ncols, int reps, double *seconds, int *flag);
 int ek_hip_debug_set_two_stage(int min_order);
 
+/* Counters of this process's last whole-path solve: out[0] = flops the merge products of the divide & conquer
+ * executed (2 M N K over both GEMMs of every merge, with the dimensions deflation and the column selection left
+ * on the device: what bench.py prices that stage with, the nominal 4 n^3 / 3 being an upper bound), out[1] = 1
+ * if the tridiagonalisation ran in two stages. */
+int ek_hip_debug_last_solve_stats(double *out, int count);
+
 #ifdef __cplusplus
 }
 #endif

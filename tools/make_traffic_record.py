@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""profiles/r03_q2_apply_traffic.json from the PMC summaries tools/r03_profile.sh left under gpurun_out/r03prof_<tag>/:
+HBM bytes per q2_apply_kernel launch = FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64 bytes,
+MI355X_MICROARCH.md) + WRITE_SIZE (16-byte stores: exact), both in KiB in the counter files; with the sha256 of the
+kernel's source file and the git commit, so that bench.py can tell a stale record.  usage: make_traffic_record.py <tag> [n]"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counter(path, kernel, name):
+    for line in open(path):
+        f = line.split()
+        if len(f) >= 5 and f[0].startswith(kernel) and f[1] == name:
+            return float(f[2]), float(f[3])
+    raise SystemExit("no %s for %s in %s" % (name, kernel, path))
+
+
+def main():
+    tag = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+    d = os.path.join(ROOT, "gpurun_out", "r03prof_" + tag)
+    nf, fetch = counter(os.path.join(d, "pmc_fetch_c3.txt"), "q2_apply_kernel", "FETCH_SIZE")
+    nw, write = counter(os.path.join(d, "pmc_write_c3.txt"), "q2_apply_kernel", "WRITE_SIZE")
+    sha_box = open(os.path.join(d, "source_sha256.txt")).read().split()[0]
+    src = os.path.join(ROOT, "eigenkernel_amd", "csrc", "ek_sb2st.hip")
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    if sha != sha_box:
+        raise SystemExit("ek_sb2st.hip has changed since the measurement (%s vs %s)" % (sha[:12], sha_box[:12]))
+    git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    rec = {"n": n, "ncols": n, "kernel": "q2_apply_kernel", "git": git, "source_sha256": sha,
+           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex) on "
+                     "`python3 bench.py --steps 1 --warmup 0 ...` (tools/r03_profile.sh); counters are KiB; FETCH_SIZE doubled as "
+                     "MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE taken as is (16-byte stores)",
+           "fetch_size_kib": fetch / nf, "write_size_kib": write / nw,
+           "hbm_bytes_per_launch": (2.0 * fetch / nf + write / nw) * 1024.0,
+           "algorithmic_bytes_per_launch": 2.0 * 8.0 * n ** 3 / 64.0}
+    out = os.path.join(ROOT, "profiles", "r03_q2_apply_traffic.json")
+    json.dump(rec, open(out, "w"), indent=1)
+    print(out, rec["hbm_bytes_per_launch"] / 1e12, "TB per launch")
+
+
+if __name__ == "__main__":
+    main()
