@@ -12,3 +12,5 @@ done
 # reference's 2x4 grid for 8 ranks (processes.f90:56-65); 3 s and 5 min on 8 cores
 /opt/conda/bin/mpiexec -np 8 oracle/scalapack_path 4096 0 tests/golden/scalapack_synth_sep_n4096_np8.txt > /dev/null
 /opt/conda/bin/mpiexec -np 8 oracle/scalapack_path 16384 1 tests/golden/scalapack_synth_gep_n16384_np8.txt > /dev/null
+# C4: N=32768 generalized on the same 2x4 grid: 38 min on 8 cores (2268 s of ScaLAPACK: pdsytrd 1235 s), ~45 GiB
+/opt/conda/bin/mpiexec -np 8 oracle/scalapack_path 32768 1 tests/golden/scalapack_synth_gep_n32768_np8.txt > /dev/null

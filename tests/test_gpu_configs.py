@@ -148,11 +148,15 @@ def test_c5_n16384_generalized_lowest_1024(hip, golden_dir):
         _grid_piece_is_bit_identical(lib, dev, r, True, n, n_vec, (2, 4), (0, 2))
 
 
-def test_c4_n32768_generalized_full_spectrum(hip):
+def test_c4_n32768_generalized_full_spectrum(hip, golden_dir):
+    """BASELINE.json configs[3] at full size on one GPU, eigenvalues held to the reference's library path (the same
+    six ScaLAPACK calls on the 2 x 4 grid, tests/golden/make_scalapack_goldens.sh) within N eps max|lambda|."""
     lib = hip.load_library()
     n = 32768
+    w_ref = np.loadtxt(os.path.join(golden_dir, "scalapack_synth_gep_n32768_np8.txt"))
     with _Dev(lib) as dev:
         r = _solve_1x1(lib, dev, True, n, n)
+        assert np.abs(r["w"] - w_ref).max() <= n * EPS * np.abs(w_ref).max()
         _acceptance(lib, True, n, n, r["dA0"], r["dB0"], r["dw"], r["dZ"])
         w = r["w"]
         # the generator's spectrum (SURVEY.md 8(d)): GEP eigenvalues inside [0.38, 2.63]

@@ -198,6 +198,9 @@ def test_full_size_scalapack_fixtures_against_an_independent_lapack(oracle, gold
     w3 = np.loadtxt(os.path.join(golden_dir, "scalapack_synth_gep_n16384_np8.txt"))
     assert w3.shape == (16384,) and np.all(np.diff(w3) > 0)
     assert 0.38 < w3[0] < 0.39 and 2.61 < w3[-1] < 2.63     # GEP spectrum [0.38, 2.63]
+    w4 = np.loadtxt(os.path.join(golden_dir, "scalapack_synth_gep_n32768_np8.txt"))      # C4
+    assert w4.shape == (32768,) and np.all(np.diff(w4) > 0)
+    assert 0.38 < w4[0] < 0.39 and 2.61 < w4[-1] < 2.63
 
 
 def test_verifier_mirror_is_pinned_to_the_reference_verifier_probe(oracle, golden_dir):
