@@ -1239,6 +1239,101 @@ int ek_hip_debug_sy2sb(int n, double *A, int lda, double *V, int ldv, double *ta
 }
 
 // Stage 2: the lower band (half bandwidth 64) of A -> d, e; Z (n x ncols, may be null) <- Q2 Z.
+// all-gather of the packed band of a team whose members hold the columns of their own strips (strip S on rank S mod P):
+// one exchange per round of P strips
+void gather_band_strips(hipStream_t s, int n, int nmem, int rank0, double *const *ABs, const SytrdExchange &x) {
+  const int NRB = ceil_div(n, 128), P = x.nranks;
+  if (P <= 1) return;
+  for (int q = 0; q * P < NRB; ++q) {
+    size_t offs[kMaxTeam], counts[kMaxTeam];
+    for (int r = 0; r < P; ++r) {
+      const int S = q * P + r;
+      const int cols = (S < NRB) ? ((n - S * 128 < 128) ? n - S * 128 : 128) : 0;
+      offs[r] = (S < NRB) ? (size_t)S * 128 * kBandLd : 0; counts[r] = (size_t)cols * kBandLd;
+    }
+    x.allgatherv(s, nmem, rank0, ABs, offs, counts, P, x.user);
+  }
+}
+
+__global__ void band_to_matrix_kernel(int n, const double *__restrict__ AB, double *__restrict__ A, int lda) {
+  const int c = blockIdx.x;
+  for (int d = threadIdx.x; d <= kBandW; d += blockDim.x)
+    if (c + d < n) A[(size_t)(c + d) + (size_t)c * lda] = AB[(size_t)d + (size_t)c * kBandLd];
+}
+
+// Dense -> band over a team (stage level, for tests): nteam >= 1 rehearses a whole team inside this process (every
+// member with its own copy of A -- NaN outside its own strips if EK_HIP_TEAM_POISON=1 --, exchanges by device kernels),
+// nteam == 0 makes this process one rank of the attached communicator.  Out: the gathered band in the lower band of A
+// (zero elsewhere), the reflectors V and tau of member 0; *mismatch = entries in which the members' bands, V or tau differ.
+int ek_hip_debug_sy2sb_team(int n, double *A, int lda, double *V, int ldv, double *tau, int nteam, int *flag,
+                            long long *mismatch) {
+  if (n < 1 || !A || !V || !tau || lda < n || ldv < n) return -1;
+  if (nteam < 0 || nteam > kMaxTeam) return -7;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nteam == 0 && !g_comm.on) return -7;
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const int nmem = nteam > 0 ? nteam : 1, P = nteam > 0 ? nteam : g_comm.nranks;
+  const size_t wb = sy2sb_dist_work_bytes(n, P), bandb = (size_t)kBandLd * (round_up(n + 1, 128)) * 8;
+  const size_t per = 2 * al((size_t)ld * ld * 8) + al(wb) + al(bandb) + al((size_t)ld * 8) + 256;
+  void *ws;
+  rc = workspace(per * nmem + 512, &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  unsigned long long *d_cnt = a.get<unsigned long long>(1);
+  int *d_flags = a.get<int>(kMaxTeam);
+  EK_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 8, s));
+  EK_HIP_CHECK(hipMemsetAsync(d_flags, 0, kMaxTeam * sizeof(int), s));
+  Sy2sbMember mem[kMaxTeam];
+  double *ABs[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    double *dA = a.get<double>((size_t)ld * ld), *dV = a.get<double>((size_t)ld * ld);
+    char *work = a.get<char>(wb);
+    ABs[m] = (double *)a.get<char>(bandb);
+    double *dt = a.get<double>(ld);
+    EK_HIP_CHECK(hipMemsetAsync(dA, 0, (size_t)ld * ld * 8, s));
+    EK_HIP_CHECK(hipMemsetAsync(dV, 0, (size_t)ld * ld * 8, s));
+    EK_HIP_CHECK(hipMemsetAsync(dt, 0, (size_t)ld * 8, s));
+    rc = h2d_matrix(n, n, A, lda, dA, ld, s); if (rc) return rc;
+    mem[m] = Sy2sbMember{dA, ld, dV, ld, dt, d_flags + m, work, nteam > 0 ? m : g_comm.rank};
+    const char *poison = getenv("EK_HIP_TEAM_POISON");
+    if (poison && poison[0] == '1' && P > 1)
+      hipLaunchKernelGGL(poison_foreign_strips_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s,
+                         n, dA, ld, P, mem[m].rank);
+  }
+  const SytrdExchange x = team_exchange(nteam, 0);
+  g_comm.err = 0;
+  sy2sb_lower_dist(s, n, nmem, mem, x);
+  for (int m = 0; m < nmem; ++m) pack_band(s, n, mem[m].A, ld, ABs[m]);
+  gather_band_strips(s, n, nmem, mem[0].rank, ABs, x);
+  EK_HIP_CHECK(hipGetLastError());
+  for (int m = 1; m < nmem; ++m) {
+    const unsigned nb = (unsigned)(((size_t)n * n + 255) / 256);
+    hipLaunchKernelGGL(count_mismatch_kernel, dim3(nb), dim3(256), 0, s, n, n, mem[0].Vall, ld, mem[m].Vall, ld, 0, d_cnt);
+    hipLaunchKernelGGL(count_mismatch_kernel, dim3((unsigned)(((size_t)kBandLd * n + 255) / 256)), dim3(256), 0, s, kBandLd, n,
+                       ABs[0], kBandLd, ABs[m], kBandLd, 0, d_cnt);
+    hipLaunchKernelGGL(count_mismatch_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, 1, mem[0].tau1, n, mem[m].tau1, n, 0, d_cnt);
+  }
+  // the band into member 0's matrix (zero elsewhere) and out
+  EK_HIP_CHECK(hipMemsetAsync(mem[0].A, 0, (size_t)ld * ld * 8, s));
+  hipLaunchKernelGGL(band_to_matrix_kernel, dim3(n), dim3(128), 0, s, n, ABs[0], mem[0].A, ld);
+  rc = d2h_matrix(n, n, mem[0].A, ld, A, lda, s); if (rc) return rc;
+  rc = d2h_matrix(n, n, mem[0].Vall, ld, V, ldv, s); if (rc) return rc;
+  EK_HIP_CHECK(hipMemcpyAsync(tau, mem[0].tau1, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  unsigned long long cnt = 0;
+  int hf[kMaxTeam];
+  EK_HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipMemcpyAsync(hf, d_flags, sizeof(hf), hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  if (mismatch) *mismatch = (long long)cnt;
+  int f = 0;
+  for (int m = 0; m < nmem; ++m) f |= hf[m];
+  if (flag) *flag = f;
+  if (g_comm.err) { fprintf(stderr, "[ek_hip] exchange failed: %s\n", comm_error_string()); return -996; }
+  return 0;
+}
+
 int ek_hip_debug_sb2st(int n, const double *A, int lda, double *d, double *e, double *Z, int ldz, int ncols,
                        int *flag) {
   if (n < 1) return -1;
@@ -1628,7 +1723,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // the reduced matrix for the (rare) fall-back to the one-stage path, and the stages' own scratch
   const int ts_min = two_stage_min();
   const bool two_stage = ts_min > 0 && n >= ts_min && n >= 3;
-  const size_t wb_sy2sb = two_stage ? al(sy2sb_work_bytes(n)) : 0, wb_sb2st = two_stage ? al(sb2st_work_bytes(n)) : 0;
+  const size_t wb_sy2sb = two_stage ? al(dist ? sy2sb_dist_work_bytes(n, g_comm.nranks) : sy2sb_work_bytes(n)) : 0,
+               wb_sb2st = two_stage ? al(sb2st_work_bytes(n)) : 0;
   const size_t wb_q1prep = two_stage ? al(ormtr_prep_bytes(n)) : 0;
   const size_t ws_need = 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
                          4 * al((size_t)ld * 8) + sygst_scr + potrf_wb +
@@ -1720,32 +1816,28 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
     sytrd_lower_dist(s, n, 1, &me, team_exchange(0, n));
   } else if (two_stage) {
-    if (dist && problem == 1 && g_comm.nranks >= dist_min_ranks()) {
-      // the distributed reduction left the reduced matrix on every rank only in the 128-wide column
-      // strips it owns (strip S on rank S mod P): one all-gather per round of P strips completes it.
-      // From here on a team needs no further exchange: both stages of the tridiagonalisation run
-      // replicated (bit-identical on all ranks), the back-transformations on the cell's own columns.
-      const SytrdExchange x = team_exchange(0);
-      const int NRB = ceil_div(n, 128), P = x.nranks;
-      double *bufs[1] = {wA};
-      for (int q = 0; q * P < NRB; ++q) {
-        size_t offs[kMaxTeam], counts[kMaxTeam];
-        for (int r = 0; r < P; ++r) {
-          const int S = q * P + r;
-          const int cols = (S < NRB) ? ((n - S * 128 < 128) ? n - S * 128 : 128) : 0;
-          offs[r] = (S < NRB) ? (size_t)S * 128 * ld : 0; counts[r] = (size_t)cols * ld;
-        }
-        x.allgatherv(s, 1, g_comm.rank, bufs, offs, counts, P, x.user);
-      }
-    }
     // dense -> band -> tridiagonal.  The panel factorisation of the first stage is CholeskyQR2 with a
     // device-side check; a matrix it cannot handle (rank-deficient or very ill-conditioned panels,
     // e.g. an input that is already banded) takes the one-stage path from a copy instead.
     EK_HIP_CHECK(hipMemcpyAsync(wA0, wA, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
     EK_HIP_CHECK(hipMemsetAsync(wV2, 0, (size_t)ld * ld * 8, s));
     EK_HIP_CHECK(hipMemsetAsync(dt1, 0, (size_t)ld * 8, s));
-    sy2sb_lower(s, g_ctx.stream2, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
-    sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st);
+    if (dist) {
+      // On a team the first stage is distributed over the 128-wide column strips (strip S on rank S mod P: where
+      // the distributed reduction to standard form left the matrix, so nothing is gathered in front of it): per panel
+      // one broadcast of [V | T | tau] and one all-reduce of Y (ek_sy2sb.hip).  Then ONE all-gather of the band
+      // (65 n doubles); the bulge chasing and the D&C below its top merge run replicated, bit-identical on all ranks.
+      const SytrdExchange x = team_exchange(0);
+      const Sy2sbMember me{wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb, g_comm.rank};
+      sy2sb_lower_dist(s, n, 1, &me, x);
+      double *ABs[1] = {sb2st_band(work_sb2st, n)};
+      pack_band(s, n, wA, ld, ABs[0]);
+      gather_band_strips(s, n, 1, g_comm.rank, ABs, x);
+      sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st, /*band_packed=*/true);
+    } else {
+      sy2sb_lower(s, g_ctx.stream2, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
+      sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st);
+    }
     // (the bulge chasing does nothing when the first stage has raised its flag: the band is not valid then)
     int flag = 0;
     EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1758,7 +1850,12 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
       EK_HIP_CHECK(hipMemcpyAsync(wA, wA0, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
       EK_HIP_CHECK(hipMemsetAsync(wV, 0, (size_t)ld * ld * 8, s));
       EK_HIP_CHECK(hipMemsetAsync(dd, 0, 3 * al((size_t)ld * 8), s));
-      sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
+      if (dist) {     // (the copy holds the matrix in this rank's strips only: the one-stage form over the team)
+        const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
+        sytrd_lower_dist(s, n, 1, &me, team_exchange(0, n));
+      } else {
+        sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
+      }
     }
   } else {
     sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);

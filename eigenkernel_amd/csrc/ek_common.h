@@ -222,12 +222,24 @@ size_t sy2sb_work_bytes(int n);
 void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
                  int *d_flag, void *work);
 
+// Team form (1 x P, 128-wide column strips, strip S on rank S mod P): a member passes its copy of the matrix, of which
+// only the columns of its own strips need to be valid (and only they are kept current); V, tau1 come out complete and
+// identical on every member, the band stays in the members' own strips (see ek_sy2sb.hip).
+struct Sy2sbMember { double *A; int lda; double *Vall; int ldv; double *tau1; int *d_flag; void *work; int rank; };
+size_t sy2sb_dist_work_bytes(int n, int nranks);
+void sy2sb_lower_dist(hipStream_t s, int n, int nmem, const Sy2sbMember *mem, const SytrdExchange &x);
+
 size_t sb2st_work_bytes(int n);
 // Band (lower band of A, half bandwidth kBandW) -> d(n), e(n-1) by bulge chasing.  V2 (n x n, ldv2,
 // zero on entry) receives the reflectors (column s = those of sweep s, stacked); *d_flag |= 4 if the
 // persistent kernel had to be abandoned.  work: >= sb2st_work_bytes(n), shared with sb2st_apply_q2.
+// band_packed: the band already lies in sb2st_band(work, n) (kBandLd x n, column c = the 65 diagonals of column c followed
+// by zeros: pack_band, then -- on a team whose members hold only their own strips -- an all-gather of its columns)
+constexpr int kBandLd = 2 * kBandW;
+double *sb2st_band(void *work, int n);
+void pack_band(hipStream_t s, int n, const double *A, int lda, double *AB /* kBandLd x n */);
 void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, double *e, double *V2, int ldv2,
-                 int *d_flag, void *work);
+                 int *d_flag, void *work, bool band_packed = false);
 // Z(:, 0:ncols) <- Q2 Z (Z 16-byte aligned, ldz even); *d_flag |= 4 if the pipeline had to be abandoned
 void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2, double *Z, int ldz, int *d_flag,
                     void *work);

@@ -724,15 +724,11 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
 
 __global__ void set_word_kernel(unsigned *p, unsigned v) { *p = v; }
 
-// the band again if the position-owned kernel gave up half way, and the state chase_kernel starts from
-__global__ void repack_band_kernel(int n, const double *__restrict__ A, int lda, double *__restrict__ AB, const unsigned *ctl) {
+// the band again if the position-owned kernel gave up half way: the state chase_kernel starts from
+__global__ void repack_band_kernel(int n, const double *__restrict__ AB0, double *__restrict__ AB, const unsigned *ctl) {
   if (!ctl[3]) return;
   const int c = blockIdx.x;
-  for (int d = threadIdx.x; d < LDAB; d += blockDim.x) {
-    double v = 0.0;
-    if (d <= SB && c + d < n) v = A[(size_t)(c + d) + (size_t)c * lda];
-    AB[(size_t)d + (size_t)c * LDAB] = v;
-  }
+  for (int d = threadIdx.x; d < LDAB; d += blockDim.x) AB[(size_t)d + (size_t)c * LDAB] = AB0[(size_t)d + (size_t)c * LDAB];
 }
 
 // ------------------------------------------------------------------------ Q2: compact-WY factors
@@ -1091,7 +1087,7 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Layout {
   int nsweeps, nS, kmax, ldt;
-  size_t off_ab, off_tau, off_prog, off_mail, off_pmail, off_retired, off_ctl, off_T, off_qprog, off_offs, total;
+  size_t off_ab0, off_ab, off_tau, off_prog, off_mail, off_pmail, off_retired, off_ctl, off_T, off_qprog, off_offs, total;
   size_t nrec;
   explicit Layout(int n) {
     nsweeps = n > 2 ? n - 2 : 0;
@@ -1099,7 +1095,8 @@ struct Layout {
     kmax = q2_groups_of_block(n, 0); if (kmax < 1) kmax = 1;
     ldt = kmax + 1;
     size_t o = 0;
-    off_ab = o; o += al256((size_t)LDAB * (n + 1) * 8);
+    off_ab0 = o; o += al256((size_t)LDAB * (round_up(n + 1, 128)) * 8);   // the band as packed (and, on a team, gathered)
+    off_ab = o; o += al256((size_t)LDAB * (n + 1) * 8);        // the band the chase works in
     off_tau = o; o += al256((size_t)ldt * (nsweeps + 1) * 8);
     off_prog = o; o += al256((size_t)(nsweeps + 1) * 4);
     off_mail = o; o += al256((size_t)4 * (kmax + 1) * MAILW * 8);
@@ -1139,17 +1136,25 @@ size_t sb2st_work_bytes(int n) { return Layout(n).total; }
 // Band (lower band of A, half bandwidth 64) -> d, e; the reflectors go to V2 (n x n, ldv2, zero on
 // entry; column s = the reflectors of sweep s stacked) and into the workspace (tau).  *d_flag |= 4
 // if the persistent kernel had to be abandoned (a bounded spin ran out).
+double *sb2st_band(void *work, int n) { return (double *)((char *)work + Layout(n).off_ab0); }
+void pack_band(hipStream_t s, int n, const double *A, int lda, double *AB) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(pack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB);
+}
+
 void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, double *e, double *V2, int ldv2,
-                 int *d_flag, void *work) {
+                 int *d_flag, void *work, bool band_packed) {
   if (n <= 0) return;
   const Layout L(n);
   char *w = (char *)work;
+  double *AB0 = (double *)(w + L.off_ab0);
   double *AB = (double *)(w + L.off_ab), *tau2 = (double *)(w + L.off_tau);
   unsigned *prog = (unsigned *)(w + L.off_prog), *ctl = (unsigned *)(w + L.off_ctl);
   double *mail = (double *)(w + L.off_mail), *pmail = (double *)(w + L.off_pmail);
   unsigned *retired = (unsigned *)(w + L.off_retired);
   const int nmail = 4 * (L.kmax + 1) * MAILW, npmail = 2 * 4 * (L.kmax + 2) * PMAILW;
-  hipLaunchKernelGGL(pack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB);
+  if (!band_packed) hipLaunchKernelGGL(pack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB0);
+  (void)hipMemcpyAsync(AB, AB0, (size_t)LDAB * n * 8, hipMemcpyDeviceToDevice, s);
   (void)hipMemsetAsync(tau2, 0, (size_t)L.ldt * (L.nsweeps + 1) * 8, s);
   (void)hipMemsetAsync(prog, 0, (size_t)(L.nsweeps + 1) * 4 + 0, s);
   (void)hipMemsetAsync(ctl, 0, 256, s);
@@ -1173,7 +1178,7 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
       if (const char *ev = getenv("EK_SB2ST_CENSUS_SPINS")) census = (unsigned)atoi(ev);
       PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * PMAILW, retired, ctl, per, census, d_flag};
       hipLaunchKernelGGL(chase_pos_kernel, dim3(per > 0 ? per * 8 : K0), dim3(512), 0, s, a);
-      hipLaunchKernelGGL(repack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB, ctl);
+      hipLaunchKernelGGL(repack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, AB0, AB, ctl);
     }
     hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(nmail, 256)), dim3(256), 0, s, mail, nmail);
     ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, mail, L.kmax + 1, nullptr, pos ? 1 : 0, d_flag};

@@ -396,6 +396,9 @@ struct SymmArgs {
   const double *V; int ldv;             // m x 64
   double *Ypart; int ldy; long long sY; // per split: m x 64
   int T, tiles_per_split;
+  int P, rank, r0;                      // DIST: this member of a team of P sums only the entries of A22 whose COLUMN lies
+                                        // in a 128-wide global strip it owns (strip S on rank S mod P; A22 starts at global
+                                        // row and column r0); the members' Y add up to A22 V
 };
 constexpr int BK = 32, MC_LD = 128 + 16, KC_LD = BK + 2;   // K-contiguous images: 34 keeps (x, k) and (x + 1, k - 1) in different banks and row pairs 16-byte aligned
 constexpr int A_TILE = (BK * MC_LD > 128 * KC_LD) ? BK * MC_LD : 128 * KC_LD;
@@ -405,6 +408,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // K is walked in slabs of 32 (one barrier pair per slab); slabs that lie completely inside the matrix
 // and off the diagonal tile are fetched as 16-byte pairs without predicates (A22 starts on a multiple of
 // 64 rows and the leading dimensions are even, so the pairs are aligned), the others element by element.
+template <bool DIST>
 __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
   __shared__ __attribute__((aligned(16))) double sA[A_TILE];
   __shared__ __attribute__((aligned(16))) double sV[SB * V_LD];
@@ -420,6 +424,16 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   double2_t ra[8], rv[4];
+  // entry a(x, k) of the symmetric matrix lives in column min(x, k) of the lower triangle: direct tiles (k < x) belong to
+  // the owner of their K index, transposed tiles (x < k) to the owner of their output row
+  auto own = [&](int rel) -> bool { return !DIST || (((p.r0 + rel) >> 7) % p.P) == p.rank; };
+  const bool rowown[2] = {own(m0), own(m0 + 64)};
+  auto needed = [&](int kt, int k0) -> bool {
+    if (!DIST) return true;
+    if (kt < rb) return own(kt * 128 + k0);
+    if (kt > rb) return rowown[0] || rowown[1];
+    return true;
+  };
   // odd leading dimensions (odd n) or an unaligned base take the element path everywhere
   const bool vec_ok = (((p.lda | p.ldv) & 1) == 0) && ((((size_t)p.A | (size_t)p.V) & 15) == 0);
   const bool rows_in = vec_ok && m0 + 128 <= p.m;
@@ -447,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
           if (mode == 1) { k = 2 * (t & 15) + h; x = (t >> 4) + 16 * i; } else { x = 2 * (t & 63) + h; k = (t >> 6) + 4 * i; }
           const int gx = m0 + x, gk = gk0 + k;
           double e = 0.0;
-          if (gx < p.m && gk < p.m) {
+          if (gx < p.m && gk < p.m && (!DIST || mode != 2 || own(gx < gk ? gx : gk))) {
             const bool low = (mode == 0) || (mode == 2 && gx >= gk);
             e = low ? p.A[(size_t)gx + (size_t)gk * p.lda] : p.A[(size_t)gk + (size_t)gx * p.lda];
           }
@@ -455,6 +469,11 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
         }
         ra[i] = (double2_t){v[0], v[1]};
       }
+    }
+    if (DIST && mode == 1) {          // rows (t >> 4) + 16 i: i < 4 the first 64 rows of the block, i >= 4 the others
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (!rowown[i >> 2]) ra[i] = (double2_t){0.0, 0.0};
     }
   };
   // V slab: pair = k indices (2 kp, 2 kp + 1) of one column n; thread -> kp = t & 15, n = t >> 4 + 16 i
@@ -473,41 +492,51 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
       }
     }
   };
-  if (kt0 < kt1) { load_a(kt0, 0); load_v(kt0, 0); }
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool kc = kt > rb;     // K-contiguous image of the A slab (transposed tile)
-    for (int k0 = 0; k0 < 128; k0 += BK) {
-      if (kt * 128 + k0 >= p.m) break;
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (kc) { const int k = 2 * (t & 15), x = (t >> 4) + 16 * i; *reinterpret_cast<double2_t *>(&sA[x * KC_LD + k]) = ra[i]; }
-        else    { const int x = 2 * (t & 63), k = (t >> 6) + 4 * i; *reinterpret_cast<double2_t *>(&sA[k * MC_LD + x]) = ra[i]; }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { const int k = 2 * (t & 15), nn = (t >> 4) + 16 * i; *reinterpret_cast<double2_t *>(&sV[nn * V_LD + k]) = rv[i]; }
-      __syncthreads();
-      // next slab (possibly of the next tile) in flight during the MFMAs
-      int nkt = kt, nk0 = k0 + BK;
-      if (nk0 >= 128 || kt * 128 + nk0 >= p.m) { nkt = kt + 1; nk0 = 0; }
-      if (nkt < kt1 && nkt * 128 + nk0 < p.m) { load_a(nkt, nk0); load_v(nkt, nk0); }
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 4) {
-        double fa[4], fb[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int x = wm + i * 16 + l15, k = kk + l4;
-          fa[i] = kc ? sA[x * KC_LD + k] : sA[k * MC_LD + x];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fb[i] = sV[(wn + i * 16 + l15) * V_LD + kk + l4];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-      }
+  // the slabs of this workgroup in order (DIST: those that hold entries this member owns)
+  auto advance = [&](int &kt, int &k0) -> bool {
+    while (true) {
+      k0 += BK;
+      if (k0 >= 128 || kt * 128 + k0 >= p.m) { kt += 1; k0 = 0; }
+      if (kt >= kt1 || kt * 128 >= p.m) return false;
+      if (needed(kt, k0)) return true;
     }
+  };
+  int kt = kt0, k0 = 0;
+  bool have = kt0 < kt1 && kt0 * 128 < p.m;
+  if (have && !needed(kt, k0)) have = advance(kt, k0);
+  if (have) { load_a(kt, k0); load_v(kt, k0); }
+  while (have) {
+    const bool kc = kt > rb;     // K-contiguous image of the A slab (transposed tile)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (kc) { const int k = 2 * (t & 15), x = (t >> 4) + 16 * i; *reinterpret_cast<double2_t *>(&sA[x * KC_LD + k]) = ra[i]; }
+      else    { const int x = 2 * (t & 63), k = (t >> 6) + 4 * i; *reinterpret_cast<double2_t *>(&sA[k * MC_LD + x]) = ra[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int k = 2 * (t & 15), nn = (t >> 4) + 16 * i; *reinterpret_cast<double2_t *>(&sV[nn * V_LD + k]) = rv[i]; }
+    __syncthreads();
+    // next slab (possibly of the next tile) in flight during the MFMAs
+    int nkt = kt, nk0 = k0;
+    const bool hn = advance(nkt, nk0);
+    if (hn) { load_a(nkt, nk0); load_v(nkt, nk0); }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = wm + i * 16 + l15, k = kk + l4;
+        fa[i] = kc ? sA[x * KC_LD + k] : sA[k * MC_LD + x];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fb[i] = sV[(wn + i * 16 + l15) * V_LD + kk + l4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+    kt = nkt; k0 = nk0; have = hn;
   }
   double *Y = p.Ypart + (size_t)ks * p.sY;
 #pragma unroll
@@ -527,9 +556,10 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
 struct YredArgs {
   int m, nsplit;
   const double *Ypart; int ldy; long long sY;
-  double *Y;                 // m x 64, ld = ldy
+  double *Y;                 // m x 64, ld = ldyo (0: ldy)
   const double *V; int ldv;
   double *Gpart;
+  int ldyo = 0;
 };
 __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
   __shared__ double sY[IMG], sV[IMG];
@@ -552,7 +582,7 @@ __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) ys[s] = (s < p.nsplit) ? yp[(size_t)s * p.sY] : 0.0;
         y = ((ys[0] + ys[1]) + (ys[2] + ys[3])) + ((ys[4] + ys[5]) + (ys[6] + ys[7]));
-        p.Y[(size_t)row + (size_t)col * p.ldy] = y;
+        p.Y[(size_t)row + (size_t)col * (p.ldyo ? p.ldyo : p.ldy)] = y;
         v = p.V[(size_t)row + (size_t)col * p.ldv];
       }
       sY[r * LD + col] = y; sV[r * LD + col] = v;
@@ -648,7 +678,10 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 struct Layout {
   int mpad, nparts, maxsplit;
   size_t off_img, off_img2, off_qt, off_y, off_ypart, off_gpart, off_gpart2, off_small, total;
-  explicit Layout(int n) {
+  // team form (P > 0): the panel message [V | T | tau], the table of the strip updates
+  int maxb = 0, npanels = 0;
+  size_t off_msg = 0, off_offs = 0, off_dims = 0, msg_doubles = 0;
+  explicit Layout(int n, int P = 0) {
     mpad = round_up(n > 0 ? n : 1, 128);
     nparts = mpad / CH + 1;
     maxsplit = 8;
@@ -661,9 +694,88 @@ struct Layout {
     off_gpart = o; o += al256((size_t)nparts * SB * SB * 8);
     off_gpart2 = o; o += al256((size_t)nparts * SB * SB * 8);
     off_small = o; o += al256((size_t)16 * SB * SB * 8);   // [10 * 4096 ..): profile counters
+    if (P > 0) {
+      maxb = ceil_div(ceil_div(mpad, 128), P) + 1;
+      npanels = ceil_div(n > 0 ? n : 1, SB);
+      msg_doubles = (size_t)mpad * SB + SB * SB + SB;
+      off_msg = o; o += al256(msg_doubles * 8);
+      off_offs = o; o += al256((size_t)npanels * maxb * 3 * sizeof(long long));
+      off_dims = o; o += al256((size_t)npanels * maxb * 3 * sizeof(int));
+    }
     total = o;
   }
 };
+
+// everything a panel factorisation needs besides the panel
+struct ChainBufs {
+  int n, mpad;
+  double *Qt, *Gpart2, *Gred2, *R1, *R1inv, *M2, *L1, *Rband;
+  long long *prof;
+};
+
+void ensure_attrs() {
+  static bool attr = false;
+  if (attr) return;
+  (void)hipFuncSetAttribute((const void *)hr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * IMG * (int)sizeof(double));
+  (void)hipFuncSetAttribute((const void *)house_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (SMALL_ROWS * LD + 2 * IMG) * (int)sizeof(double));
+  attr = true;
+}
+
+// factorisation of the panel at column c0 of A into the image Vimg (V in its columns 64..127), T into Tp, the
+// reflectors into Vall, tau into tau1, issued on stream st
+void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double *Vall, int ldv, double *tau1, int *d_flag,
+                 int c0, double *Vimg, double *Tp) {
+  const int n = b.n, ldi = b.mpad;
+  const int r0 = c0 + SB, m = n - r0;
+  double *Ap = A + (size_t)r0 + (size_t)c0 * lda;
+  double *Vp = Vall + (size_t)r0 + (size_t)c0 * ldv;
+  const int nch = ceil_div(m, CH);
+  if (m <= SMALL_MAX) {
+    SmallArgs sa{m, Ap, lda, Vp, ldv, Vimg, ldi, Tp, tau1 + c0};
+    hipLaunchKernelGGL(house_small_kernel, dim3(1), dim3(256), (SMALL_ROWS * LD + 2 * IMG) * sizeof(double), st, sa);
+    return;
+  }
+  PanelArgs pa{};
+  pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = b.Gpart2;
+  hipLaunchKernelGGL(panel_kernel<0>, dim3(nch), dim3(256), 0, st, pa);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2);
+  hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, b.Gred2, b.R1, b.R1inv, d_flag);
+  pa.M = b.R1inv; pa.dst = b.Qt; pa.ldd = b.mpad;
+  hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, st, pa);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2);
+  HrArgs ha{b.Gred2, b.Qt, b.mpad, b.R1, b.M2, Tp, b.L1, b.Rband, tau1 + c0, d_flag, b.prof};
+  hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), st, ha);
+  PanelArgs pf{};
+  pf.m = m; pf.src = b.Qt; pf.lds_ = b.mpad; pf.M = b.M2; pf.L1 = b.L1; pf.Rband = b.Rband;
+  pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vimg = Vimg; pf.ldi = ldi;
+  hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, st, pf);
+}
+
+// team form: the strips a member updates after panel p (batched GEMM: one problem per owned strip that still has
+// columns at or beyond r0 = 64 (p + 1)).  Entry (panel, k): element offsets {A, B, C} and dims {M, N, K}; the
+// operands are the rows of the image [W | V | W] from the strip's first column on.
+__global__ void strip_table_kernel(int n, int lda, int P, int rank, int maxb, long long *offs, int *dims) {
+  const int panel = blockIdx.x, k = threadIdx.x;
+  if (k >= maxb) return;
+  const int r0 = (panel + 1) * SB;
+  const int Sf = r0 / 128;
+  const int Sfl = Sf + ((rank - Sf) % P + P) % P;
+  const int S = Sfl + k * P;
+  long long c0 = (long long)S * 128;
+  if (c0 < r0) c0 = r0;
+  int M = 0, N = 0;
+  if (c0 < n) {
+    M = n - (int)c0;
+    long long cend = (long long)(S + 1) * 128;
+    if (cend > n) cend = n;
+    N = (int)(cend - c0);
+  }
+  const size_t e = (size_t)panel * maxb + k;
+  offs[3 * e] = c0 - r0; offs[3 * e + 1] = c0 - r0; offs[3 * e + 2] = c0 * ((long long)lda + 1);
+  dims[3 * e] = M; dims[3 * e + 1] = N; dims[3 * e + 2] = 2 * SB;
+}
 
 }  // namespace
 
@@ -672,18 +784,15 @@ size_t sy2sb_work_bytes(int n) { return Layout(n).total; }
 void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
                  int *d_flag, void *work) {
   if (n <= 2) return;
-  static bool attr = false;
+  ensure_attrs();
+  static bool evs = false;
   static hipEvent_t evA[2], evB[2];
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void *)hr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              4 * IMG * (int)sizeof(double));
-    (void)hipFuncSetAttribute((const void *)house_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (SMALL_ROWS * LD + 2 * IMG) * (int)sizeof(double));
+  if (!evs) {
     for (int q = 0; q < 2; ++q) {
       (void)hipEventCreateWithFlags(&evA[q], hipEventDisableTiming);
       (void)hipEventCreateWithFlags(&evB[q], hipEventDisableTiming);
     }
-    attr = true;
+    evs = true;
   }
   const Layout L(n);
   char *w = (char *)work;
@@ -706,32 +815,9 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   static int la_min = -1;
   if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 5120; }
 
-  // factorisation of the panel at column c0 into image `im`, T into `Tp`, issued on stream `st`
+  const ChainBufs cb{n, L.mpad, Qt, Gpart2, Gred2, R1, R1inv, M2, L1, Rband, prof ? (long long *)(sm + 10 * 4096) : nullptr};
   auto panel_chain = [&](hipStream_t st, int c0, double *Vimg, double *Tp) {
-    const int r0 = c0 + SB, m = n - r0;
-    double *Ap = A + (size_t)r0 + (size_t)c0 * lda;
-    double *Vp = Vall + (size_t)r0 + (size_t)c0 * ldv;
-    const int nch = ceil_div(m, CH);
-    if (m <= SMALL_MAX) {
-      SmallArgs sa{m, Ap, lda, Vp, ldv, Vimg, ldi, Tp, tau1 + c0};
-      hipLaunchKernelGGL(house_small_kernel, dim3(1), dim3(256), (SMALL_ROWS * LD + 2 * IMG) * sizeof(double), st, sa);
-      return;
-    }
-    PanelArgs pa{};
-    pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = Gpart2;
-    hipLaunchKernelGGL(panel_kernel<0>, dim3(nch), dim3(256), 0, st, pa);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, Gpart2, Gred2);
-    hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, Gred2, R1, R1inv, d_flag);
-    pa.M = R1inv; pa.dst = Qt; pa.ldd = L.mpad;
-    hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, st, pa);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, Gpart2, Gred2);
-    HrArgs ha{Gred2, Qt, L.mpad, R1, M2, Tp, L1, Rband, tau1 + c0, d_flag, nullptr};
-    if (prof) ha.prof = (long long *)(sm + 10 * 4096);
-    hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), st, ha);
-    PanelArgs pf{};
-    pf.m = m; pf.src = Qt; pf.lds_ = L.mpad; pf.M = M2; pf.L1 = L1; pf.Rband = Rband;
-    pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vimg = Vimg; pf.ldi = ldi;
-    hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, st, pf);
+    ek::panel_chain(st, cb, A, lda, Vall, ldv, tau1, d_flag, c0, Vimg, Tp);
   };
 
   panel_chain(s, 0, img[0], Tm[0]);
@@ -753,10 +839,10 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     if (nsplit > T) nsplit = T;
     const int tps = ceil_div(T, nsplit);
     nsplit = ceil_div(T, tps);
-    SymmArgs sy{m, A22, lda, V, ldi, Ypart, L.mpad, (long long)L.mpad * SB, T, tps};
+    SymmArgs sy{m, A22, lda, V, ldi, Ypart, L.mpad, (long long)L.mpad * SB, T, tps, 1, 0, 0};
     const bool timed = kprof_enabled() && (p % 8 == 0);          // a uniform sample of the panels
     if (timed) kprof_begin(s, kProfSymm);
-    hipLaunchKernelGGL(symm_lower_kernel, dim3(T, nsplit), dim3(256), 0, s, sy);
+    hipLaunchKernelGGL(symm_lower_kernel<false>, dim3(T, nsplit), dim3(256), 0, s, sy);
     if (timed) kprof_end(s, kProfSymm);
     YredArgs ya{m, nsplit, Ypart, L.mpad, (long long)L.mpad * SB, Y, V, ldi, Gpart};
     hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
@@ -790,6 +876,122 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
       fprintf(stderr, "[hr_kernel prof] calls %lld; cycles: load %.0f chol %.0f inv %.0f qtop-mm %.0f lu %.0f tsolve+uinv %.0f "
               "r1-load %.0f mm2 %.0f\n", h[9], (double)h[0] / h[9], (double)h[1] / h[9], (double)h[2] / h[9], (double)h[3] / h[9],
               (double)h[4] / h[9], (double)h[5] / h[9], (double)h[6] / h[9], (double)h[7] / h[9]);
+  }
+}
+
+
+size_t sy2sb_dist_work_bytes(int n, int nranks) { return Layout(n, nranks > 0 ? nranks : 1).total; }
+
+// Team form of the dense -> band stage (the reference's PDSYTRD is distributed over its grid,
+// solver_scalapack_all.f90:59, processes.f90:17-36).  1 x P team, 128-wide column strips of the matrix, strip S on
+// rank S mod P -- the layout the distributed reduction to standard form leaves the matrix in, so nothing is
+// gathered in front of this stage.  Per panel (64 columns, all inside one strip):
+//   * the strip's owner factors the panel (the same CholeskyQR2 + reconstruction chain as on one GPU) and
+//     broadcasts [V | T | tau]: ONE message of 64 m + 4160 doubles;
+//   * every member forms its part of Y = A22 V from the entries of the lower triangle whose column it owns
+//     (symm_lower_kernel<DIST>: 1/P of the flops and of the matrix traffic each), ONE all-reduce of Y (64 m doubles);
+//   * W (replicated, small), then the rank-128 update of the member's own strips only (one batched GEMM).
+// Two bandwidth-bound exchanges per panel, n/64 panels; a member reads and writes only columns it owns.  V, T,
+// tau, and therefore the reflectors for the back-transformation, end up complete and identical on every member;
+// the band stays distributed by strips (the caller gathers its 65 diagonals: 8 n^2 / 128 bytes... 65 n doubles).
+void sy2sb_lower_dist(hipStream_t s, int n, int nmem, const Sy2sbMember *mem, const SytrdExchange &x) {
+  if (n <= 2 || nmem <= 0 || nmem > kMaxTeam) return;
+  ensure_attrs();
+  const int P = x.nranks;
+  const Layout L(n, P);
+  const int ldi = L.mpad;
+  struct St { double *img, *Qt, *Y, *Ypart, *Gpart, *sm, *msg; long long *offs; int *dims; ChainBufs cb; };
+  St st[kMaxTeam];
+  double *msgs[kMaxTeam], *ys[kMaxTeam];
+  for (int q = 0; q < nmem; ++q) {
+    char *w = (char *)mem[q].work;
+    St &m = st[q];
+    m.img = (double *)(w + L.off_img); m.Qt = (double *)(w + L.off_qt); m.Y = (double *)(w + L.off_y);
+    m.Ypart = (double *)(w + L.off_ypart); m.Gpart = (double *)(w + L.off_gpart); m.sm = (double *)(w + L.off_small);
+    m.msg = (double *)(w + L.off_msg); m.offs = (long long *)(w + L.off_offs); m.dims = (int *)(w + L.off_dims);
+    double *sm = m.sm;
+    m.cb = ChainBufs{n, L.mpad, m.Qt, (double *)(w + L.off_gpart2), sm + 11 * 4096, sm + 4096, sm + 2 * 4096, sm + 3 * 4096,
+                     sm + 5 * 4096, sm + 6 * 4096, nullptr};
+    msgs[q] = m.msg; ys[q] = m.Y;
+    hipLaunchKernelGGL(strip_table_kernel, dim3(L.npanels), dim3(round_up(L.maxb, 64)), 0, s, n, mem[q].lda, P, mem[q].rank,
+                       L.maxb, m.offs, m.dims);
+  }
+  int p = 0;
+  for (int c0 = 0; ; c0 += SB, ++p) {
+    const int r0 = c0 + SB, m = n - r0;
+    if (m < 2) break;
+    const int owner = (c0 / 128) % P;
+    const int ldy = round_up(m, 2);
+    const size_t vcount = (size_t)ldy * SB;
+    // ---- the owner factors the panel and packs the message
+    for (int q = 0; q < nmem; ++q) {
+      if (mem[q].rank != owner) continue;
+      St &M = st[q];
+      double *Tp = M.sm + 4 * 4096;
+      panel_chain(s, M.cb, mem[q].A, mem[q].lda, mem[q].Vall, mem[q].ldv, mem[q].tau1, mem[q].d_flag, c0, M.img, Tp);
+      if (P > 1) {                      // (only the m rows of the panel travel: V is packed with leading dimension ldy)
+        copy_matrix(s, m, SB, M.img + (size_t)SB * ldi, ldi, M.msg, ldy);
+        (void)hipMemcpyAsync(M.msg + vcount, Tp, (size_t)SB * SB * 8, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(M.msg + vcount + SB * SB, mem[q].tau1 + c0, (size_t)SB * 8, hipMemcpyDeviceToDevice, s);
+      }
+    }
+    if (P > 1) {
+      size_t offs[kMaxTeam], counts[kMaxTeam];
+      for (int r = 0; r < P; ++r) { offs[r] = 0; counts[r] = (r == owner) ? vcount + SB * SB + SB : 0; }
+      x.allgatherv(s, nmem, mem[0].rank, msgs, offs, counts, P, x.user);
+    }
+    // ---- everybody else unpacks: V into its image and into the reflector matrix, T, tau
+    for (int q = 0; q < nmem; ++q) {
+      if (mem[q].rank == owner) continue;
+      St &M = st[q];
+      copy_matrix(s, m, SB, M.msg, ldy, M.img + (size_t)SB * ldi, ldi);
+      (void)hipMemcpyAsync(M.sm + 4 * 4096, M.msg + vcount, (size_t)SB * SB * 8, hipMemcpyDeviceToDevice, s);
+      (void)hipMemcpyAsync(mem[q].tau1 + c0, M.msg + vcount + SB * SB, (size_t)SB * 8, hipMemcpyDeviceToDevice, s);
+      copy_matrix(s, m, SB, M.msg, ldy, mem[q].Vall + (size_t)r0 + (size_t)c0 * mem[q].ldv, mem[q].ldv);
+    }
+    // ---- Y = A22 V: every member its own entries, then the sum over the team
+    const int nch = ceil_div(m, CH);
+    const int T = ceil_div(m, 128);
+    int nsplit = (T >= 256) ? 2 : ceil_div(512, T);
+    if (nsplit > L.maxsplit) nsplit = L.maxsplit;
+    if (nsplit > T) nsplit = T;
+    const int tps = ceil_div(T, nsplit);
+    nsplit = ceil_div(T, tps);
+    for (int q = 0; q < nmem; ++q) {
+      St &M = st[q];
+      double *A22 = mem[q].A + (size_t)r0 + (size_t)r0 * mem[q].lda;
+      const double *V = M.img + (size_t)SB * ldi;
+      SymmArgs sy{m, A22, mem[q].lda, V, ldi, M.Ypart, L.mpad, (long long)L.mpad * SB, T, tps, P, mem[q].rank, r0};
+      hipLaunchKernelGGL(symm_lower_kernel<true>, dim3(T, nsplit), dim3(256), 0, s, sy);
+      YredArgs ya{m, nsplit, M.Ypart, L.mpad, (long long)L.mpad * SB, M.Y, V, ldi, M.Gpart};
+      ya.ldyo = ldy;
+      hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
+    }
+    if (P > 1) x.allreduce(s, nmem, ys, (size_t)ldy * SB, x.user);
+    for (int q = 0; q < nmem; ++q) {
+      St &M = st[q];
+      const double *V = M.img + (size_t)SB * ldi;
+      if (P > 1) {    // G = V^T Y of the summed Y
+        YredArgs yb{m, 1, M.Y, ldy, 0, M.Y, V, ldi, M.Gpart};
+        yb.ldyo = ldy;
+        hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, yb);
+      }
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s, nch, M.Gpart, M.sm);
+      WArgs wa{m, M.Y, ldy, V, ldi, M.sm, M.sm + 4 * 4096, M.img, ldi};
+      hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
+      // ---- A(:, own strips) -= [W | V] [V | W]^T rows of the strip
+      const int Sf = r0 / 128, rank = mem[q].rank;
+      const int Sfl = Sf + ((rank - Sf) % P + P) % P;
+      const int NRB = ceil_div(n, 128);
+      if (Sfl >= NRB) continue;
+      const int nb = ceil_div(NRB - Sfl, P);
+      GemmDesc g{};
+      g.M = m; g.N = 128; g.K = 2 * SB; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
+      g.A = M.img; g.lda = ldi; g.strideA = 0; g.B = M.img + (size_t)SB * ldi; g.ldb = ldi; g.strideB = 0;
+      g.C = mem[q].A; g.ldc = mem[q].lda; g.strideC = 0; g.batch = nb; g.lower_only = true;
+      g.d_offs = M.offs + (size_t)p * L.maxb * 3; g.d_dims = M.dims + (size_t)p * L.maxb * 3;
+      gemm(s, g);
+    }
   }
 }
 

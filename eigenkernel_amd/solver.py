@@ -117,6 +117,7 @@ def load_library(path=None):
         "ek_hip_profile_kernels": (c_int, [c_int]),
         "ek_hip_profile_kernels_get": (c_int, [_dp, _llp]),
         "ek_hip_debug_last_solve_stats": (c_int, [_dp, c_int]),
+        "ek_hip_debug_sy2sb_team": (c_int, [c_int, _dp, c_int, _dp, c_int, _dp, c_int, _ip, _llp]),
     }
     for name, (res, args) in sigs.items():
         try:
@@ -146,6 +147,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_comm_peer_enable", "ek_hip_comm_peer_disable", "ek_hip_debug_set_sytrd_maxcols", "ek_hip_debug_sytrd_work_bytes", "ek_hip_debug_sytrd_at", "ek_hip_debug_sytrd_split", "ek_hip_debug_gemm_at",
     "ek_hip_debug_sy2sb", "ek_hip_debug_sb2st", "ek_hip_debug_two_stage_timing", "ek_hip_debug_set_two_stage",
     "ek_hip_profile_kernels", "ek_hip_profile_kernels_get", "ek_hip_debug_last_solve_stats",
+    "ek_hip_debug_sy2sb_team",
 )
 
 
@@ -457,6 +459,20 @@ def sy2sb(A):
     if rc:
         raise RuntimeError("ek_hip_debug_sy2sb info=%d" % rc)
     return A, V, tau[:n], flag.value
+
+
+def sy2sb_team(A, nteam):
+    """Stage 1 over a team (rehearsed inside this process for nteam >= 1; nteam = 0: one rank of the attached
+    communicator): returns (band in the lower band of an otherwise zero matrix, V, tau, flag, mismatch)."""
+    lib = load_library()
+    A = np.array(_farr(A), order="F", copy=True)
+    n = A.shape[0]
+    V = np.zeros((n, n), order="F"); tau = np.zeros(max(n, 1)); flag = ctypes.c_int(-1); mism = ctypes.c_longlong(-1)
+    rc = lib.ek_hip_debug_sy2sb_team(n, _P(A), max(1, n), _P(V), max(1, n), _P(tau), int(nteam), ctypes.byref(flag),
+                                     ctypes.byref(mism))
+    if rc:
+        raise RuntimeError("ek_hip_debug_sy2sb_team info=%d" % rc)
+    return A, V, tau[:n], flag.value, mism.value
 
 
 def sb2st(Bd, Z=None):

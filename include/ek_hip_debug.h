@@ -51,6 +51,13 @@ int ek_hip_debug_sy2sb(int n, double *A, int lda, double *V, int ldv, double *ta
 int ek_hip_debug_sb2st(int n, const double *A, int lda, double *d, double *e, double *Z, int ldz, int ncols, int *flag);
 int ek_hip_debug_two_stage_timing(int n, int ncols, int reps, double *seconds, int *flag);
 int ek_hip_debug_set_two_stage(int min_order);
+/*   _sy2sb_team : the first stage over a 1 x P team (128-wide column strips, strip S on rank S mod P; per panel one
+ *            broadcast of [V | T | tau] and one all-reduce of Y): nteam >= 1 rehearses the whole team inside this
+ *            process (every member with its own copy of A -- NaN outside its strips when EK_HIP_TEAM_POISON=1), nteam = 0
+ *            makes this process one rank of the attached communicator.  Out: the gathered band in the lower band of A
+ *            (zero elsewhere), V and tau of member 0; *mismatch = entries in which the members' bands, V or tau differ. */
+int ek_hip_debug_sy2sb_team(int n, double *A, int lda, double *V, int ldv, double *tau, int nteam, int *flag,
+                            long long *mismatch);
 
 /* Counters of this process's last whole-path solve: out[0] = flops the merge products of the divide & conquer
  * executed (2 M N K over both GEMMs of every merge, with the dimensions deflation and the column selection left

@@ -92,6 +92,55 @@ def test_sytrd_team_reads_only_owned_strips(hip, oracle, monkeypatch):
     assert np.array_equal(np.tril(ref[0]), np.tril(got[0]))
 
 
+def _band_similarity(A, Ab, V, tau):
+    n = A.shape[0]
+    Bw = 64
+    L = np.tril(Ab) - np.tril(Ab, -(Bw + 1))
+    Bd = L + np.tril(L, -1).T
+    Q = np.eye(n)
+    for j in range(n - 1, -1, -1):
+        if tau[j] != 0.0:
+            v = V[:, j]
+            Q -= tau[j] * np.outer(v, v @ Q)
+    return (np.linalg.norm(Q.T @ Q - np.eye(n)), np.linalg.norm(Q.T @ A @ Q - Bd) / np.linalg.norm(A),
+            np.abs(np.linalg.eigvalsh(A) - np.linalg.eigvalsh(Bd)).max() / np.abs(np.linalg.eigvalsh(A)).max())
+
+
+@pytest.mark.parametrize("n,P", [(66, 2), (130, 2), (200, 3), (257, 4), (449, 2), (700, 8), (1000, 5), (1000, 16), (1537, 3)])
+def test_dense_to_band_team_rehearsal(hip, oracle, n, P):
+    """The first stage of the two-stage tridiagonalisation over a 1 x P team (the distributed form of
+    solver_scalapack_all.f90:59 for orders >= 512): the members' bands, reflectors and tau must be the same bits, and the
+    result an orthogonal similarity to a band matrix at rounding level, like the single-GPU stage."""
+    A = oracle.synth_matrix(n, 1)
+    Ab, V, tau, flag, mism = hip.sy2sb_team(A, P)
+    assert flag == 0 and mism == 0
+    assert np.abs(np.tril(Ab, -65)).max() == 0.0
+    orth, sim, ev = _band_similarity(A, Ab, V, tau)
+    assert orth <= 64 * n * EPS and sim <= 32 * n * EPS and ev <= 4 * n * EPS
+
+
+def test_dense_to_band_team_reads_only_owned_strips(hip, oracle, monkeypatch):
+    """Every member's copy of the matrix is NaN outside its own 128-wide strips: the team form must neither read nor
+    need them (what the distributed reduction to standard form leaves behind)."""
+    n, P = 900, 3
+    A = oracle.synth_matrix(n, 1)
+    ref = hip.sy2sb_team(A, P)
+    monkeypatch.setenv("EK_HIP_TEAM_POISON", "1")
+    Ab, V, tau, flag, mism = hip.sy2sb_team(A, P)
+    assert flag == 0 and mism == 0
+    assert np.array_equal(Ab, ref[0]) and np.array_equal(V, ref[1]) and np.array_equal(tau, ref[2])
+    assert np.isfinite(Ab).all() and np.isfinite(V).all()
+
+
+def test_dense_to_band_team_of_one_over_rccl(hip, oracle, comm1):
+    n = 700
+    A = oracle.synth_matrix(n, 1)
+    Ab, V, tau, flag, mism = hip.sy2sb_team(A, 0)
+    assert flag == 0 and mism == 0
+    orth, sim, ev = _band_similarity(A, Ab, V, tau)
+    assert orth <= 64 * n * EPS and sim <= 32 * n * EPS and ev <= 4 * n * EPS
+
+
 @pytest.mark.parametrize("n,P", [(5, 2), (128, 2), (130, 3), (300, 1), (640, 4), (1000, 8), (1000, 16), (1537, 5)])
 def test_sygst_team_rehearsal(hip, oracle, n, P):
     """PDSYGST on a 1 x P grid: column-sharded solves + one all-gather; every strip is taken from
