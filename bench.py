@@ -360,10 +360,10 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
 
     def measure(mode):
         m = {}
-        # "two_stage": the library's default at this order (dense -> band -> tridiagonal replicated on the
-        # ranks after ONE all-gather of the reduced matrix, back-transformations sharded by columns: no
-        # exchange per Householder column); "one_stage_*": the distributed one-stage PDSYTRD with its
-        # per-column exchange as an all-reduce or through peer windows
+        # "two_stage": the library's distributed form (dense -> band over the team's column strips: per panel one
+        # broadcast of [V | T | tau] and one all-reduce of Y; one all-gather of the band; bulge chasing replicated;
+        # back-transformations sharded by columns); "one_stage_*" (--grid-probe-modes all): the older distributed
+        # one-stage PDSYTRD with its per-column exchange as an all-reduce or through peer windows
         lib.ek_hip_debug_set_two_stage(-1 if mode == "two_stage" else 0)
         if mode == "one_stage_peer_windows":
             rc = lib.ek_hip_comm_peer_enable(n)
@@ -431,7 +431,9 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
         threading.Thread(target=watchdog, daemon=True).start()
         attach_communicator(solver, dist, rank, world, args.rehearse_on_one_gpu)
         w_first = None
-        for mode in ("two_stage", "one_stage_collective", "one_stage_peer_windows"):
+        modes = (("two_stage", "one_stage_collective", "one_stage_peer_windows") if args.grid_probe_modes == "all"
+                 else ("two_stage",))
+        for mode in modes:
             try:
                 m, w = measure(mode)
                 if mode == "one_stage_collective":
@@ -530,6 +532,11 @@ def main():
                     help="N>1 ranks that all use GPU 0 (a pool box has one): gloo process group, collective "
                          "tensors on the CPU, the library's HOST communicator instead of RCCL (which refuses two "
                          "ranks on one device).  Exercises the whole N>1 control flow; the timings mean nothing")
+    ap.add_argument("--grid-probe-modes", choices=["two_stage", "all"], default="two_stage",
+                    help="what the grid probe measures: 'two_stage' (default) = the library's one distributed form (dense -> "
+                         "band over the team, per panel one broadcast and one all-reduce; bulge chasing replicated; "
+                         "eigenvector stages sharded by columns); 'all' adds the older one-stage PDSYTRD with its per-column "
+                         "exchange as an all-reduce and through peer windows")
     ap.add_argument("--grid-probe-timeout", type=float, default=240.0,
                     help="seconds after which a stuck grid probe is abandoned (the main line is still printed)")
     args = ap.parse_args()

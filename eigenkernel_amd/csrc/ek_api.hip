@@ -1533,6 +1533,56 @@ int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds) {
   return g_comm.err ? -996 : 0;
 }
 
+// Tuning hook: the team form of the dense -> band stage on the synthetic matrix; *seconds = the whole team back to back
+// on this GPU when nteam >= 1 (divide by nteam for a rank's compute: the wire is not in it)
+int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds) {
+  if (n < 3) return -1;
+  if (nteam < 0 || nteam > kMaxTeam) return -2;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nteam == 0 && !g_comm.on) return -995;
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n);
+  const int nmem = nteam > 0 ? nteam : 1, P = nteam > 0 ? nteam : g_comm.nranks;
+  const size_t wb = sy2sb_dist_work_bytes(n, P);
+  const size_t per = 2 * al((size_t)ld * ld * 8) + al(wb) + al((size_t)ld * 8) + 256;
+  void *ws;
+  rc = workspace(per * nmem + 256, &ws);
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  int *d_flags = a.get<int>(kMaxTeam);
+  Sy2sbMember mem[kMaxTeam];
+  for (int m = 0; m < nmem; ++m) {
+    double *dA = a.get<double>((size_t)ld * ld), *dV = a.get<double>((size_t)ld * ld);
+    char *work = a.get<char>(wb);
+    double *dt = a.get<double>(ld);
+    mem[m] = Sy2sbMember{dA, ld, dV, ld, dt, d_flags + m, work, nteam > 0 ? m : g_comm.rank};
+  }
+  const SytrdExchange x = team_exchange(nteam, 0);
+  hipEvent_t e0, e1;
+  EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
+  double tot = 0.0;
+  g_comm.err = 0;
+  for (int r = 0; r < reps; ++r) {
+    EK_HIP_CHECK(hipMemsetAsync(d_flags, 0, kMaxTeam * sizeof(int), s));
+    for (int m = 0; m < nmem; ++m) {
+      EK_HIP_CHECK(hipMemsetAsync(mem[m].A, 0, (size_t)ld * ld * 8, s));
+      EK_HIP_CHECK(hipMemsetAsync(mem[m].Vall, 0, (size_t)ld * ld * 8, s));
+      EK_HIP_CHECK(hipMemsetAsync(mem[m].tau1, 0, (size_t)ld * 8, s));
+      synth_matrix(s, n, 1, mem[m].A, ld);
+    }
+    EK_HIP_CHECK(hipEventRecord(e0, s));
+    sy2sb_lower_dist(s, n, nmem, mem, x);
+    EK_HIP_CHECK(hipEventRecord(e1, s));
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0.f; EK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    tot += ms * 1e-3;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (seconds) *seconds = tot / (reps > 0 ? reps : 1);
+  return g_comm.err ? -996 : 0;
+}
+
 // Tuning hook: Cholesky + reduction to standard form of the synthetic pair, distributed form;
 // seconds[0] = potrf, seconds[1] = sygst (whole team back to back when nteam >= 1).
 int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds) {

@@ -118,6 +118,7 @@ def load_library(path=None):
         "ek_hip_profile_kernels_get": (c_int, [_dp, _llp]),
         "ek_hip_debug_last_solve_stats": (c_int, [_dp, c_int]),
         "ek_hip_debug_sy2sb_team": (c_int, [c_int, _dp, c_int, _dp, c_int, _dp, c_int, _ip, _llp]),
+        "ek_hip_debug_sy2sb_team_timing": (c_int, [c_int, c_int, c_int, _dp]),
     }
     for name, (res, args) in sigs.items():
         try:
@@ -147,7 +148,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_comm_peer_enable", "ek_hip_comm_peer_disable", "ek_hip_debug_set_sytrd_maxcols", "ek_hip_debug_sytrd_work_bytes", "ek_hip_debug_sytrd_at", "ek_hip_debug_sytrd_split", "ek_hip_debug_gemm_at",
     "ek_hip_debug_sy2sb", "ek_hip_debug_sb2st", "ek_hip_debug_two_stage_timing", "ek_hip_debug_set_two_stage",
     "ek_hip_profile_kernels", "ek_hip_profile_kernels_get", "ek_hip_debug_last_solve_stats",
-    "ek_hip_debug_sy2sb_team",
+    "ek_hip_debug_sy2sb_team", "ek_hip_debug_sy2sb_team_timing",
 )
 
 

@@ -58,6 +58,7 @@ int ek_hip_debug_set_two_stage(int min_order);
  *            (zero elsewhere), V and tau of member 0; *mismatch = entries in which the members' bands, V or tau differ. */
 int ek_hip_debug_sy2sb_team(int n, double *A, int lda, double *V, int ldv, double *tau, int nteam, int *flag,
                             long long *mismatch);
+int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds);   /* device-generated matrix; whole team */
 
 /* Counters of this process's last whole-path solve: out[0] = flops the merge products of the divide & conquer
  * executed (2 M N K over both GEMMs of every merge, with the dimensions deflation and the column selection left

@@ -20,6 +20,19 @@ teams = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
 lib = solver.load_library()
 assert lib.ek_hip_init(0) == 0
 sec = ctypes.c_double(0)
+# the team form of the dense -> band stage (what a team runs from order 512 on: the stages after it are replicated
+# -- bulge chasing -- or sharded by eigenvector columns)
+ts = (ctypes.c_double * 4)(); flag = ctypes.c_int(0)
+lib.ek_hip_debug_two_stage_timing(n, min(n, 1024), 1, ts, ctypes.byref(flag))
+lib.ek_hip_debug_two_stage_timing(n, min(n, 1024), 2, ts, ctypes.byref(flag))
+print("n=%d single GPU: dense->band %.4f s, band->tridiagonal %.4f s" % (n, ts[0], ts[1]), flush=True)
+for P in teams:
+    if P >= 1:
+        assert lib.ek_hip_debug_sy2sb_team_timing(n, P, 1, ctypes.byref(sec)) == 0
+        assert lib.ek_hip_debug_sy2sb_team_timing(n, P, 2, ctypes.byref(sec)) == 0
+        print("n=%d team of %d rehearsed: dense->band %.4f s total, %.4f s per rank" % (n, P, sec.value, sec.value / P), flush=True)
+if os.environ.get("EK_TEAM_TWO_STAGE_ONLY"):
+    sys.exit(0)
 assert lib.ek_hip_debug_sytrd(n, 0, 1, ctypes.byref(sec)) == 0
 assert lib.ek_hip_debug_sytrd(n, 0, 2, ctypes.byref(sec)) == 0
 print("n=%d single-GPU sytrd: %.4f s" % (n, sec.value), flush=True)
