@@ -13,7 +13,10 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -1719,6 +1722,108 @@ int ek_hip_synth_matrix_device(int n, unsigned long long seed, double *dM, int l
 // Whole path on device-resident data.
 namespace {
 
+// Staging pipeline of ek_hip_solve on a 1 x 1 grid (host arrays in, host arrays out: solver_main.f90:64-65).  The
+// copies run on worker threads with their own non-blocking streams while the main thread issues the stages:
+//   in : B, then A (B is needed first: the Cholesky factorisation runs while A is still on its way);
+//   out: L as soon as it is final (it leaves during the reduction), the reflectors / band of A after the
+//        tridiagonalisation, Z in column slabs as the last stage finishes them, w last.
+// A copy of pageable host memory keeps its calling thread busy (the runtime stages it through pinned buffers), which
+// is why the copies have threads of their own; a matrix is cut into column pieces so that two threads share it.
+struct HostPipe {
+  struct Job { double *dev; int ldd; double *host; int ldh; int m, n; hipEvent_t after; int tag; bool to_host; };
+  static constexpr int kThreads = 2;         // per direction
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Job> in_q, out_q;
+  int pending_in[2] = {0, 0};                // tag 0 = B, 1 = A: pieces not yet in HBM
+  int pending_out = 0;
+  bool closing = false;
+  int err = 0;
+  std::vector<std::thread> th;
+  hipStream_t cs[2 * kThreads] = {};
+  int device = 0;
+  int z_slab = 2048;
+
+  int start(int dev) {
+    device = dev;
+    for (auto &c : cs) EK_HIP_CHECK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    for (int i = 0; i < 2 * kThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i]); });
+    return 0;
+  }
+  void run(bool input, hipStream_t c) {
+    (void)hipSetDevice(device);
+    std::deque<Job> &q = input ? in_q : out_q;
+    while (true) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return !q.empty() || closing; });
+        if (q.empty()) return;
+        j = q.front(); q.pop_front();
+      }
+      hipError_t e = hipSuccess;
+      if (j.after) e = hipEventSynchronize(j.after);
+      if (e == hipSuccess && j.m > 0 && j.n > 0) {
+        if (j.to_host)
+          e = hipMemcpy2DAsync(j.host, (size_t)j.ldh * 8, j.dev, (size_t)j.ldd * 8, (size_t)j.m * 8, j.n, hipMemcpyDeviceToHost, c);
+        else
+          e = hipMemcpy2DAsync(j.dev, (size_t)j.ldd * 8, j.host, (size_t)j.ldh * 8, (size_t)j.m * 8, j.n, hipMemcpyHostToDevice, c);
+        if (e == hipSuccess) e = hipStreamSynchronize(c);
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (e != hipSuccess && !err) err = -1000 - (int)e;
+        if (input) --pending_in[j.tag]; else --pending_out;
+      }
+      cv.notify_all();
+    }
+  }
+  // host array (m x n, ldh) <-> device image (ldd), cut into column pieces for the threads
+  void push(bool to_host, double *dev, int ldd, double *host, int ldh, int m, int n, hipEvent_t after, int tag) {
+    const int pieces = (n >= 256) ? 2 * kThreads : 1;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (int p = 0; p < pieces; ++p) {
+        const int c0 = (int)((long long)n * p / pieces), c1 = (int)((long long)n * (p + 1) / pieces);
+        Job j{dev + (size_t)c0 * ldd, ldd, host + (size_t)c0 * ldh, ldh, m, c1 - c0, after, tag, to_host};
+        if (to_host) { out_q.push_back(j); ++pending_out; } else { in_q.push_back(j); ++pending_in[tag]; }
+      }
+    }
+    cv.notify_all();
+  }
+  int wait_in(int tag) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&]() { return pending_in[tag] == 0; });
+    return err;
+  }
+  int finish() {                              // all copies done; threads joined; streams released
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&]() { return pending_out == 0 && pending_in[0] == 0 && pending_in[1] == 0; });
+      closing = true;
+    }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+    th.clear();
+    for (auto &c : cs) if (c) { (void)hipStreamDestroy(c); c = nullptr; }
+    for (auto &e : evs) (void)hipEventDestroy(e);
+    evs.clear();
+    return err;
+  }
+  ~HostPipe() { if (!th.empty()) (void)finish(); }
+  // an event recorded on stream s now (the device image is final there)
+  std::vector<hipEvent_t> evs;
+  hipEvent_t mark(hipStream_t s) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    (void)hipEventRecord(e, s);
+    evs.push_back(e);
+    return e;
+  }
+  // what the solve hands over: host destinations of the in-place results
+  double *hA = nullptr, *hB = nullptr, *hZ = nullptr; int ldha = 0, ldhb = 0, ldhz = 0;
+};
+
 struct StageTimer {      // events are released when the timer goes out of scope, whichever way the call ends
   hipEvent_t ev[EK_HIP_N_STAGES + 1];
   int made = 0;
@@ -1740,7 +1845,7 @@ struct StageTimer {      // events are released when the timer goes out of scope
 // block-cyclic piece numroc(n, nb, myrow, nprow) x numroc(n_vec, nb, mycol, npcol).
 int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
                         double *dw, double *dZ, int ldz, double *stage_seconds, int n_stages,
-                        const GridCell *cell = nullptr) {
+                        const GridCell *cell = nullptr, HostPipe *pipe = nullptr) {
   hipStream_t s = g_ctx.stream;
   const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
   const int nc_loc = cell ? numroc0(n_vec, cell->nb, cell->mycol, cell->npcol) : n_vec;
@@ -1810,19 +1915,24 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
 
   EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, 4 * sizeof(int), s));
   mark();                                                              // 0
-  // stage-in: padded, zero-filled work copies
-  if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s));   // (the copy covers all of an unpadded array)
-  copy_matrix(s, n, n, dA, lda, wA, ld);
-  if (problem == 1) {
-    if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wB, 0, (size_t)ld * ld * 8, s));
-    copy_matrix(s, n, n, dB, ldb, wB, ld);
-  }
+  // stage-in: padded, zero-filled work copies.  With a staging pipeline B comes first and A is waited for only
+  // after the Cholesky factorisation has been issued (it is still crossing PCIe meanwhile).
   EK_HIP_CHECK(hipMemsetAsync(wV, 0, (size_t)ld * ld * 8, s));
   EK_HIP_CHECK(hipMemsetAsync(dd, 0, 4 * al((size_t)ld * 8), s));
-  // Scale A into the safe range when its entries are extreme (as DSYEV / PDSYEV do before
-  // DSYTRD): the Householder norms are plain sums of squares.  Eigenvalues scale back linearly.
   double sigma = 1.0;
-  {
+  auto stage_in_B = [&]() -> int {
+    if (problem != 1) return 0;
+    if (pipe) { const int e = pipe->wait_in(0); if (e) return e; }
+    if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wB, 0, (size_t)ld * ld * 8, s));
+    copy_matrix(s, n, n, dB, ldb, wB, ld);
+    return 0;
+  };
+  auto stage_in_A = [&]() -> int {
+    if (pipe) { const int e = pipe->wait_in(1); if (e) return e; }
+    if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s));   // (the copy covers all of an unpadded array)
+    copy_matrix(s, n, n, dA, lda, wA, ld);
+    // Scale A into the safe range when its entries are extreme (as DSYEV / PDSYEV do before
+    // DSYTRD): the Householder norms are plain sums of squares.  Eigenvalues scale back linearly.
     double *d_part = (double *)work;   // stage scratch, free until the reduction starts
     maxabs_lower(s, n, wA, ld, d_part);
     double part[256];
@@ -1830,13 +1940,16 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     EK_HIP_CHECK(hipStreamSynchronize(s));
     double anrm = 0.0;
     for (double v : part) if (v > anrm) anrm = v;
-    if (!(anrm <= 1.7e308)) { tm.destroy(); return -4; }   // NaN / Inf in A: illegal value, as XERBLA
+    if (!(anrm <= 1.7e308)) return -4;   // NaN / Inf in A: illegal value, as XERBLA
     // the tridiagonalisation forms x^T A x of the unscaled column (|A|^3 n^2): keep cubes in range
     const double rmin = 1e-90, rmax = 1e90;
     if (anrm > 0.0 && anrm < rmin) sigma = rmin / anrm;
     else if (anrm > rmax) sigma = rmax / anrm;
     if (sigma != 1.0) scale_lower(s, n, sigma, wA, ld);
-  }
+    return 0;
+  };
+  if (!pipe) { rc = stage_in_A(); if (rc) { tm.destroy(); return rc; } }
+  rc = stage_in_B(); if (rc) { tm.destroy(); return rc; }
   mark();                                                              // 1
   g_comm.err = 0;
   if (problem == 1) {
@@ -1851,6 +1964,13 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     }
   }
   mark();                                                              // 2
+  if (pipe) {
+    if (problem == 1) {        // L is final: it leaves while the reduction runs
+      copy_matrix(s, n, n, wB, ld, dB, ldb);
+      pipe->push(true, dB, ldb, pipe->hB, pipe->ldhb, n, n, pipe->mark(s), 0);
+    }
+    rc = stage_in_A(); if (rc) { tm.destroy(); return rc; }
+  }
   if (problem == 1) {
     // sharding the two solves costs 2 n^3 / P flops per rank against 1.0 - 1.57 n^3 replicated
     if (dist && g_comm.nranks >= dist_min_ranks()) {
@@ -1910,6 +2030,10 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   } else {
     sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
   }
+  if (pipe) {                  // what the call leaves in A (reflectors / band) is final
+    copy_matrix(s, n, n, wA, ld, dA, lda);
+    pipe->push(true, dA, lda, pipe->hA, pipe->ldha, n, n, pipe->mark(s), 0);
+  }
   mark();                                                              // 4
   // eigenvector columns wanted: the first n_vec, or this grid cell's share of them; the D&C
   // forms only those (columns 0..nc_loc-1 of wZ) and the two remaining stages treat the
@@ -1918,27 +2042,56 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats);
   mark();                                                              // 5
   double *zc = wZ;
+  // with a staging pipeline the LAST stage (the recovery; the back-transformation of a standard problem) runs in column
+  // slabs, each leaving for the host while the next is computed (columns of Z are independent there)
+  const int zslab = (pipe && two_stage_done && nc_loc > pipe->z_slab) ? pipe->z_slab : nc_loc;
+  auto z_out = [&](int c0, int nc) {
+    copy_matrix(s, n, nc, wZ + (size_t)c0 * ld, ld, dZ + (size_t)c0 * ldz, ldz);
+    pipe->push(true, dZ + (size_t)c0 * ldz, ldz, pipe->hZ + (size_t)c0 * pipe->ldhz, pipe->ldhz, n, nc, pipe->mark(s), 0);
+  };
   if (two_stage_done) {
     sb2st_apply_q2(s, n, nc_loc, wV2, ld, zc, ld, g_ctx.d_info + 2, work_sb2st);
     // (the T factors of the block reflectors do not depend on Z; forming them on the second stream beside the
     // bulge chasing was measured: the skinny GEMMs take CUs and issue slots from the latency-bound pipeline,
     // which loses 11 ms to gain 6)
     ormtr_prepare(s, n, wV, ld, dt1, q1prep);
-    ormtr_apply(s, n, nc_loc, wV, ld, q1prep, zc, ld, work, n_vec);
+    if (pipe && problem == 0 && zslab < nc_loc) {
+      for (int c0 = 0; c0 < nc_loc; c0 += zslab) {
+        const int nc = (nc_loc - c0 < zslab) ? nc_loc - c0 : zslab;
+        ormtr_apply(s, n, nc, wV, ld, q1prep, zc + (size_t)c0 * ld, ld, work, n_vec);
+        z_out(c0, nc);
+      }
+    } else {
+      ormtr_apply(s, n, nc_loc, wV, ld, q1prep, zc, ld, work, n_vec);
+    }
   } else {
     ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work, n_vec);
   }
   mark();                                                              // 6
-  if (problem == 1) trsm_llt(s, n, nc_loc, wB, ld, dInv, zc, ld, twork);
+  if (problem == 1) {
+    if (pipe) {
+      for (int c0 = 0; c0 < nc_loc; c0 += zslab) {
+        const int nc = (nc_loc - c0 < zslab) ? nc_loc - c0 : zslab;
+        trsm_llt(s, n, nc, wB, ld, dInv, zc + (size_t)c0 * ld, ld, twork);
+        z_out(c0, nc);
+      }
+    } else {
+      trsm_llt(s, n, nc_loc, wB, ld, dInv, zc, ld, twork);
+    }
+  } else if (pipe && !(two_stage_done && zslab < nc_loc)) {
+    z_out(0, nc_loc);
+  }
   mark();                                                              // 7
   // stage-out: eigenvalues, eigenvectors, and the in-place results the reference leaves
   // behind (L in B, reflectors in A)
   if (sigma != 1.0) scale_vector(s, n, 1.0 / sigma, dwv);
   EK_HIP_CHECK(hipMemcpyAsync(dw, dwv, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-  if (cell) gather_block_cyclic(s, nr_loc, nc_loc, zc, ld, cell->nb, cell->nprow, cell->myrow, 1, 0, dZ, ldz);
-  else copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
-  copy_matrix(s, n, n, wA, ld, dA, lda);
-  if (problem == 1) copy_matrix(s, n, n, wB, ld, dB, ldb);
+  if (!pipe) {
+    if (cell) gather_block_cyclic(s, nr_loc, nc_loc, zc, ld, cell->nb, cell->nprow, cell->myrow, 1, 0, dZ, ldz);
+    else copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
+    copy_matrix(s, n, n, wA, ld, dA, lda);
+    if (problem == 1) copy_matrix(s, n, n, wB, ld, dB, ldb);
+  }
   mark();                                                              // 8
   EK_HIP_CHECK(hipGetLastError());
   int info[4] = {0, 0, 0, 0};
@@ -2253,6 +2406,36 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
   if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
   if (!rc && problem == 1) rc = mem.alloc(&uB, nn);
   if (rc) return rc;
+  int pipe_min = 2048;           // EK_HIP_PIPE_MIN: order from which the host path stages through the pipeline (0: never)
+  if (const char *e = getenv("EK_HIP_PIPE_MIN")) pipe_min = atoi(e);
+  if (pipe_min > 0 && n >= pipe_min) {
+    // staging pipeline: the copies overlap the stages (HostPipe): what remains exposed is B's way in, the rest of A's
+    // behind the Cholesky factorisation, and the last slab of Z
+    HostPipe pipe;
+    pipe.hA = A_loc; pipe.ldha = desc_A[8]; pipe.hB = B_loc; pipe.ldhb = problem == 1 ? desc_B[8] : 0;
+    pipe.hZ = Z_loc; pipe.ldhz = desc_Z[8];
+    rc = pipe.start(g_ctx.device);
+    if (rc) return rc;
+    if (problem == 1) pipe.push(false, uB, n, B_loc, desc_B[8], n, n, nullptr, 0);
+    pipe.push(false, uA, n, A_loc, desc_A[8], n, n, nullptr, 1);
+    double st[EK_HIP_N_STAGES] = {0};
+    int info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, n, st, EK_HIP_N_STAGES, nullptr, &pipe);
+    const int rcp = pipe.finish();
+    if (info == 0 && rcp) info = rcp;
+    if (info > -1000) {
+      hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess && info == 0) info = -1000 - (int)e;
+    }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stage_seconds) {
+      double dev = 0.0;
+      for (int i = 0; i < EK_HIP_N_STAGES; ++i) if (i != EK_STAGE_COPY) dev += st[i];
+      st[EK_STAGE_COPY] = wall > dev ? wall - dev : 0.0;     // what the copies add to the stages: their exposed part
+      for (int i = 0; i < n_stages && i < EK_HIP_N_STAGES; ++i) stage_seconds[i] = st[i];
+    }
+    return info;
+  }
   rc = h2d_matrix(n, n, A_loc, desc_A[8], uA, n, s);
   if (!rc && problem == 1) rc = h2d_matrix(n, n, B_loc, desc_B[8], uB, n, s);
   if (!rc) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc = -1000 - (int)e; }
