@@ -1982,6 +1982,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   }
   mark();                                                              // 3
   bool two_stage_done = false;
+  double rescued_panels = 0.0;
   if (dist && !two_stage) {
     const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
     sytrd_lower_dist(s, n, 1, &me, team_exchange(0, n));
@@ -2012,6 +2013,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     int flag = 0;
     EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
     EK_HIP_CHECK(hipStreamSynchronize(s));
+    rescued_panels = (double)(flag >> 8);      // panels of the first stage that took the Householder rescue
+    flag &= 0xff;                              // the low byte says why the two-stage form gave up, if it did
     // a team decides together: a flag that only one rank has raised (an abandoned wait depends on timing, not on the
     // data) must not leave the ranks with eigenvectors of two different decompositions
     if (dist) { flag = comm_any(flag); if (flag < 0) return flag; }
@@ -2099,6 +2102,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   EK_HIP_CHECK(hipMemcpyAsync(g_ctx.stats, g_ctx.d_stats, sizeof(g_ctx.stats), hipMemcpyDeviceToHost, s));
   EK_HIP_CHECK(hipStreamSynchronize(s));
   g_ctx.stats[1] = two_stage_done ? 1.0 : 0.0;
+  g_ctx.stats[2] = rescued_panels;
+  info[2] &= 0xff;
   if (timing) {
     float ms[8];
     for (int i = 0; i < 8; ++i) (void)hipEventElapsedTime(&ms[i], tm.ev[i], tm.ev[i + 1]);

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64 * NW) void chase_kernel(ChaseArgs p) {
   const int c0w = CW * wave;                               // this wave's columns of a block
   double *AB = p.AB;
   if (p.only_if_abandoned && !__hip_atomic_load(&p.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-  if (p.skip && *p.skip) return;
+  if (p.skip && (*p.skip & 0xff)) return;
   if (t == 0) s_ok = 1;
   auto give_up = [&]() { __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   // bounded wait until *w >= need
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int k = p.per > 0 ? (int)(blockIdx.x & 7) * p.per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (k >= p.K0) return;
-  if (p.skip && *p.skip) return;
+  if (p.skip && (*p.skip & 0xff)) return;
   const int n = p.n;
   const int c0w = CW * wave;
   double *AB = p.AB;

@@ -55,6 +55,7 @@ struct PanelArgs {
   double *Vall; int ldv;    // explicit reflector matrix of the back-transformation, at (r0, c0)
   double *Apanel; int lda;  // the panel inside A, at (r0, c0)
   double *Vimg; int ldi;    // [W | V | W] image: V goes to columns 64..127
+  const int *pflag;         // FINAL pass: non-zero = this panel goes to the rescue: leave it untouched
 };
 
 // out slab (64 x 64, LDS, row-major) = in slab * M^T-image; see mm64 for the operand convention
@@ -102,6 +103,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p) {
   __shared__ double sS[IMG], sO[IMG], sMT[MODE ? IMG : 1];
   const int t = threadIdx.x, r = t & 63, cg = t >> 6;
+  if (MODE == 2 && p.pflag && *p.pflag) return;
   if (MODE) {
     for (int idx = t; idx < SB * SB; idx += 256) {
       const int k = idx & 63, j = idx >> 6;
@@ -159,8 +161,9 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p) {
 // entry meet in LDS.  (One thread per entry over all partials was a chain of npart dependent-latency loads:
 // with 64-row chunks a panel of 16 000 rows has 250 partials.)
 __global__ __launch_bounds__(256) void reduce_parts_kernel(int npart, const double *__restrict__ part,
-                                                           double *__restrict__ out) {
+                                                           double *__restrict__ out, const int *only_if = nullptr) {
   __shared__ double s_sum[8][32];
+  if (only_if && !*only_if) return;
   const int t = threadIdx.x, q = t >> 5, el = t & 31, e = blockIdx.x * 32 + el;
   double a0 = 0.0, a1 = 0.0;
   int p = q;
@@ -173,8 +176,10 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(int npart, const doub
 }
 
 // first CholeskyQR pass: G (64x64, symmetric, stored j + 64 i) -> R1 (column-major) and R1^-1
+// (*pflag: the flag of THIS panel, written here -- 0 or 1 -- and possibly raised by hr_kernel: a panel CholeskyQR2
+// cannot factor goes to the Householder rescue below)
 __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G, double *__restrict__ R,
-                                                   double *__restrict__ Rinv, int *flag) {
+                                                   double *__restrict__ Rinv, int *pflag) {
   __shared__ double sA[IMG], sB[IMG];
   __shared__ double s_inv[kScratch];
   const int t = threadIdx.x;
@@ -184,7 +189,8 @@ __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G,
 #pragma unroll
   for (int k = 0; k < 16; ++k) { const int idx = t + 256 * k; sA[(idx >> 6) * LD + (idx & 63)] = gv[k]; }
   __syncthreads();
-  if (chol64_upper_wg(sA, s_inv) >= 0 && t == 0) atomicExch(flag, 1);
+  const int bad = chol64_upper_wg(sA, s_inv);
+  if (t == 0) *pflag = (bad >= 0) ? 1 : 0;
   triinv64_upper_wg(sA, sB, s_inv);
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
@@ -235,10 +241,10 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   if (t == 0) {
     double dmax = 0.0;
     for (int w = 0; w < 4; ++w) dmax = (s_red[w] > dmax || s_red[w] != s_red[w]) ? s_red[w] : dmax;
-    if (!(dmax <= 0.25)) atomicExch(p.flag, 2);
+    if (!(dmax <= 0.25)) atomicOr(p.flag, 2);
   }
   if (prof) tc[nt++] = clock64();
-  if (chol64_upper_wg(sA, s_inv) >= 0 && t == 0) atomicExch(p.flag, 1);      // sA = R2
+  if (chol64_upper_wg(sA, s_inv) >= 0 && t == 0) atomicOr(p.flag, 1);        // sA = R2
   if (prof) tc[nt++] = clock64();
   triinv64_upper_wg(sA, sB, s_inv);                                      // sB = R2^-1
   if (prof) tc[nt++] = clock64();
@@ -383,6 +389,218 @@ __global__ __launch_bounds__(256) void house_small_kernel(SmallArgs p) {
     const double v = sP[r * LD + c];
     p.Vall[(size_t)r + (size_t)c * p.ldv] = v;
     p.Vimg[(size_t)r + (size_t)(SB + c) * p.ldi] = v;
+  }
+}
+
+// ---------------------------------------------------------------- rescue: Householder QR of a tall panel
+// A panel CholeskyQR2 cannot factor (rank deficient or cond > 1e7: a zero or repeated column, an input that is
+// already banded, low rank plus identity, ...) is factored by Householder reflections instead -- any rank, any
+// conditioning, like PDSYTRD's own panels (solver_scalapack_all.f90:59) -- by ONE workgroup that walks the panel in
+// blocks of 8 columns: the block is factored column by column (norm, reflector, application to the rest of the
+// block: three passes over its rows), then the block's compact-WY factor is applied to the columns to its right, 8 at
+// a time (two passes).  About 15 passes of the panel's bytes through one compute unit: 1 - 3 ms for the largest
+// panels, paid only by the panels that need it (the kernels below leave at once when the panel's flag is clear).
+// In place: R in the upper triangle, the reflectors below the diagonal (DGEQR2's storage), tau.
+constexpr int HT = 512;                 // threads of the rescue workgroup
+constexpr int HB = 8;                   // columns per block
+template <int K>
+__device__ __forceinline__ void ht_reduce(double (&a)[K], double *s_part /* [HT / 64][K] */, double *s_out /* [K] */) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double v = a[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) s_part[wave * K + k] = v;
+  }
+  __syncthreads();
+  if (t < K) {
+    double v = 0.0;
+    for (int w = 0; w < HT / 64; ++w) v += s_part[w * K + t];
+    s_out[t] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) a[k] = s_out[k];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(HT) void house_tall_kernel(int m, double *__restrict__ P, int ldp, double *__restrict__ tau_out,
+                                                        const int *pflag, int *d_flag) {
+  __shared__ double s_part[(HT / 64) * HB * HB], s_out[HB * HB];
+  __shared__ double s_T[HB * HB], s_X[HB * HB], s_tau[SB];
+  if (!*pflag) return;
+  const int t = threadIdx.x;
+  if (t == 0) atomicAdd(d_flag, 256);                      // bits 8..: panels that took this path (informational)
+  auto vget = [&](int r, int j) -> double {                // entry (r, j) of the unit lower trapezoidal V
+    return (r > j) ? P[(size_t)r + (size_t)j * ldp] : (r == j ? 1.0 : 0.0);
+  };
+  for (int jb = 0; jb < SB; jb += HB) {
+    // ---- the block, column by column
+    for (int j = jb; j < jb + HB; ++j) {
+      double a1[1] = {0.0};
+      for (int r = j + 1 + t; r < m; r += HT) { const double x = P[(size_t)r + (size_t)j * ldp]; a1[0] += x * x; }
+      ht_reduce<1>(a1, s_part, s_out);
+      const double ssq = a1[0], alpha = P[(size_t)j + (size_t)j * ldp];
+      double tau = 0.0, beta = alpha, scale = 0.0;
+      if (ssq != 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + ssq), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      __syncthreads();                                     // everybody has read alpha
+      if (t == 0) { s_tau[j] = tau; tau_out[j] = tau; P[(size_t)j + (size_t)j * ldp] = beta; }
+      // v = x * scale (stored), w_c = v^T p_c for the columns of the block to the right of j
+      double w[HB - 1];
+#pragma unroll
+      for (int c = 0; c < HB - 1; ++c) w[c] = 0.0;
+      const int nc = jb + HB - 1 - j;                      // columns j+1 .. jb+HB-1
+      for (int r = j + t; r < m; r += HT) {
+        double v = 1.0;
+        if (r > j) { v = P[(size_t)r + (size_t)j * ldp] * scale; P[(size_t)r + (size_t)j * ldp] = v; }
+#pragma unroll
+        for (int c = 0; c < HB - 1; ++c)
+          if (c < nc) w[c] += v * P[(size_t)r + (size_t)(j + 1 + c) * ldp];
+      }
+      ht_reduce<HB - 1>(w, s_part, s_out);
+      if (tau != 0.0) {
+        for (int r = j + t; r < m; r += HT) {
+          const double v = (r > j) ? P[(size_t)r + (size_t)j * ldp] : 1.0;
+#pragma unroll
+          for (int c = 0; c < HB - 1; ++c)
+            if (c < nc) P[(size_t)r + (size_t)(j + 1 + c) * ldp] -= tau * w[c] * v;
+        }
+      }
+      __syncthreads();
+    }
+    if (jb + HB >= SB) break;
+    // ---- T of the block (DLARFT, forward columnwise) from G = V^T V
+    {
+      double g[HB * HB];
+#pragma unroll
+      for (int q = 0; q < HB * HB; ++q) g[q] = 0.0;
+      for (int r = jb + t; r < m; r += HT) {
+        double v[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) v[k] = vget(r, jb + k);
+#pragma unroll
+        for (int a = 0; a < HB; ++a)
+#pragma unroll
+          for (int b = a + 1; b < HB; ++b) g[a * HB + b] += v[a] * v[b];
+      }
+      ht_reduce<HB * HB>(g, s_part, s_out);
+      if (t == 0) {
+        for (int q = 0; q < HB * HB; ++q) s_T[q] = 0.0;
+        for (int i = 0; i < HB; ++i) {
+          const double ti = s_tau[jb + i];
+          for (int a = 0; a < i; ++a) {
+            double acc = 0.0;
+            for (int l = a; l < i; ++l) acc += s_T[a * HB + l] * g[l * HB + i];
+            s_T[a * HB + i] = -ti * acc;
+          }
+          s_T[i * HB + i] = ti;
+        }
+      }
+      __syncthreads();
+    }
+    // ---- (I - V T V^T)^T C = C - V T^T (V^T C) on the columns to the right, 8 at a time
+    for (int c0 = jb + HB; c0 < SB; c0 += HB) {
+      double wv[HB * HB];                                  // W(k, c) = sum_r V(r, k) C(r, c)
+#pragma unroll
+      for (int q = 0; q < HB * HB; ++q) wv[q] = 0.0;
+      for (int r = jb + t; r < m; r += HT) {
+        double v[HB], cc[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) { v[k] = vget(r, jb + k); cc[k] = P[(size_t)r + (size_t)(c0 + k) * ldp]; }
+#pragma unroll
+        for (int k = 0; k < HB; ++k)
+#pragma unroll
+          for (int c = 0; c < HB; ++c) wv[k * HB + c] += v[k] * cc[c];
+      }
+      ht_reduce<HB * HB>(wv, s_part, s_out);
+      if (t < HB * HB) {                                   // X = T^T W
+        const int k = t / HB, c = t % HB;
+        double acc = 0.0;
+        for (int l = 0; l <= k; ++l) acc += s_T[l * HB + k] * wv[l * HB + c];
+        s_X[k * HB + c] = acc;
+      }
+      __syncthreads();
+      double x[HB * HB];
+#pragma unroll
+      for (int q = 0; q < HB * HB; ++q) x[q] = s_X[q];
+      for (int r = jb + t; r < m; r += HT) {
+        double v[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) v[k] = vget(r, jb + k);
+#pragma unroll
+        for (int c = 0; c < HB; ++c) {
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < HB; ++k) acc += v[k] * x[k * HB + c];
+          P[(size_t)r + (size_t)(c0 + c) * ldp] -= acc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// the outputs of a rescued panel: V into the image and the reflector matrix, R alone left in the panel, Gram partials
+// of V for its T factor
+struct TallFinishArgs {
+  int m; double *Apanel; int lda; double *Vall; int ldv; double *Vimg; int ldi; double *Gpart; const int *pflag;
+};
+__global__ __launch_bounds__(256) void tall_finish_kernel(TallFinishArgs p) {
+  __shared__ double sV[IMG];
+  if (!*p.pflag) return;
+  const int t = threadIdx.x, r = t & 63, cg = t >> 6;
+  double4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int slab = 0; slab < CH / SB; ++slab) {
+    const int row0 = blockIdx.x * CH + slab * SB;
+    if (row0 >= p.m) break;
+    const int row = row0 + r;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int col = 16 * cg + c;
+      double v = 0.0;
+      if (row < p.m) {
+        const double x = p.Apanel[(size_t)row + (size_t)col * p.lda];
+        v = (row > col) ? x : (row == col ? 1.0 : 0.0);
+        p.Apanel[(size_t)row + (size_t)col * p.lda] = (row <= col) ? x : 0.0;
+        p.Vall[(size_t)row + (size_t)col * p.ldv] = v;
+        p.Vimg[(size_t)row + (size_t)(SB + col) * p.ldi] = v;
+      }
+      sV[r * LD + col] = v;
+    }
+    __syncthreads();
+    slab_gram(sV, sV, acc);
+  }
+  store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
+}
+
+// T (column-major, ld 64) of a rescued panel from G = V^T V and tau (DLARFT, forward columnwise)
+__global__ __launch_bounds__(256) void t_from_gram_kernel(const double *__restrict__ G, const double *__restrict__ tau,
+                                                          double *__restrict__ T, const int *pflag) {
+  __shared__ double sG[IMG], sT[IMG], s_tau[SB];
+  if (!*pflag) return;
+  const int t = threadIdx.x;
+  for (int idx = t; idx < SB * SB; idx += 256) { sG[(idx >> 6) * LD + (idx & 63)] = G[idx]; sT[(idx >> 6) * LD + (idx & 63)] = 0.0; }
+  if (t < SB) s_tau[t] = tau[t];
+  __syncthreads();
+  for (int i = 0; i < SB; ++i) {
+    const double ti = s_tau[i];
+    if (t < i) {
+      double a = 0.0;
+      for (int l = t; l < i; ++l) a += sT[t * LD + l] * sG[l * LD + i];
+      sT[t * LD + i] = -ti * a;
+    } else if (t == i) sT[i * LD + i] = ti;
+    __syncthreads();
+  }
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    const int i = idx & 63, j = idx >> 6;
+    T[idx] = sT[i * LD + j];
   }
 }
 
@@ -711,6 +929,7 @@ struct ChainBufs {
   int n, mpad;
   double *Qt, *Gpart2, *Gred2, *R1, *R1inv, *M2, *L1, *Rband;
   long long *prof;
+  int *pflag;               // the flag of the panel in flight (device)
 };
 
 void ensure_attrs() {
@@ -741,16 +960,22 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
   pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = b.Gpart2;
   hipLaunchKernelGGL(panel_kernel<0>, dim3(nch), dim3(256), 0, st, pa);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2);
-  hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, b.Gred2, b.R1, b.R1inv, d_flag);
+  hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, b.Gred2, b.R1, b.R1inv, b.pflag);
   pa.M = b.R1inv; pa.dst = b.Qt; pa.ldd = b.mpad;
   hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, st, pa);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2);
-  HrArgs ha{b.Gred2, b.Qt, b.mpad, b.R1, b.M2, Tp, b.L1, b.Rband, tau1 + c0, d_flag, b.prof};
+  HrArgs ha{b.Gred2, b.Qt, b.mpad, b.R1, b.M2, Tp, b.L1, b.Rband, tau1 + c0, b.pflag, b.prof};
   hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), st, ha);
   PanelArgs pf{};
   pf.m = m; pf.src = b.Qt; pf.lds_ = b.mpad; pf.M = b.M2; pf.L1 = b.L1; pf.Rband = b.Rband;
-  pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vimg = Vimg; pf.ldi = ldi;
+  pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vimg = Vimg; pf.ldi = ldi; pf.pflag = b.pflag;
   hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, st, pf);
+  // the rescue of a panel CholeskyQR2 could not factor (the four kernels leave at once otherwise)
+  hipLaunchKernelGGL(house_tall_kernel, dim3(1), dim3(HT), 0, st, m, Ap, lda, tau1 + c0, b.pflag, d_flag);
+  TallFinishArgs tf{m, Ap, lda, Vp, ldv, Vimg, ldi, b.Gpart2, b.pflag};
+  hipLaunchKernelGGL(tall_finish_kernel, dim3(nch), dim3(256), 0, st, tf);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2, b.pflag);
+  hipLaunchKernelGGL(t_from_gram_kernel, dim3(1), dim3(256), 0, st, b.Gred2, tau1 + c0, Tp, b.pflag);
 }
 
 // team form: the strips a member updates after panel p (batched GEMM: one problem per owned strip that still has
@@ -815,7 +1040,8 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   static int la_min = -1;
   if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 5120; }
 
-  const ChainBufs cb{n, L.mpad, Qt, Gpart2, Gred2, R1, R1inv, M2, L1, Rband, prof ? (long long *)(sm + 10 * 4096) : nullptr};
+  const ChainBufs cb{n, L.mpad, Qt, Gpart2, Gred2, R1, R1inv, M2, L1, Rband, prof ? (long long *)(sm + 10 * 4096) : nullptr,
+                     (int *)(sm + 12 * 4096)};
   auto panel_chain = [&](hipStream_t st, int c0, double *Vimg, double *Tp) {
     ek::panel_chain(st, cb, A, lda, Vall, ldv, tau1, d_flag, c0, Vimg, Tp);
   };
@@ -911,7 +1137,7 @@ void sy2sb_lower_dist(hipStream_t s, int n, int nmem, const Sy2sbMember *mem, co
     m.msg = (double *)(w + L.off_msg); m.offs = (long long *)(w + L.off_offs); m.dims = (int *)(w + L.off_dims);
     double *sm = m.sm;
     m.cb = ChainBufs{n, L.mpad, m.Qt, (double *)(w + L.off_gpart2), sm + 11 * 4096, sm + 4096, sm + 2 * 4096, sm + 3 * 4096,
-                     sm + 5 * 4096, sm + 6 * 4096, nullptr};
+                     sm + 5 * 4096, sm + 6 * 4096, nullptr, (int *)(sm + 12 * 4096)};
     msgs[q] = m.msg; ys[q] = m.Y;
     hipLaunchKernelGGL(strip_table_kernel, dim3(L.npanels), dim3(round_up(L.maxb, 64)), 0, s, n, mem[q].lda, P, mem[q].rank,
                        L.maxb, m.offs, m.dims);

@@ -40,8 +40,8 @@ int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds /* [2]:
 /* Two-stage tridiagonalisation, piece by piece on host arrays.
  *   _sy2sb : A (n x n, lda, symmetric, lower referenced) -> band (half bandwidth 64) left in the lower
  *            band of A, explicit reflectors V (n x n, ldv: column j = v_j, unit entry at row j + 64),
- *            tau (n); *flag = 0 or why the CholeskyQR2 panel factorisation gave up (1 Cholesky pivot,
- *            2 loss of orthogonality): the whole-path call then takes the one-stage path.
+ *            tau (n); *flag: low byte 0 (a panel CholeskyQR2 cannot factor -- rank deficient, cond > 1e7 -- is factored
+ *            by Householder reflections inside the stage), bits 8.. = the number of panels that took that rescue.
  *   _sb2st : the lower band of A -> d (n), e (n-1) by bulge chasing; Z (n x ncols, ldz; may be NULL
  *            with ncols = 0) <- Q2 Z; *flag bit 2 = the persistent kernel was abandoned.
  *   _two_stage_timing : seconds[0..3] = dense->band, band->tridiagonal, Q2 applied to ncols columns,
@@ -63,7 +63,8 @@ int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds);
 /* Counters of this process's last whole-path solve: out[0] = flops the merge products of the divide & conquer
  * executed (2 M N K over both GEMMs of every merge, with the dimensions deflation and the column selection left
  * on the device: what bench.py prices that stage with, the nominal 4 n^3 / 3 being an upper bound), out[1] = 1
- * if the tridiagonalisation ran in two stages. */
+ * if the tridiagonalisation ran in two stages, out[2] = panels of the dense -> band stage that CholeskyQR2 could not
+ * factor and the Householder rescue did. */
 int ek_hip_debug_last_solve_stats(double *out, int count);
 
 #ifdef __cplusplus

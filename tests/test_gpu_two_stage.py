@@ -220,23 +220,78 @@ def test_two_stage_and_one_stage_agree(hip, oracle):
     assert np.abs(dots - 1.0).max() <= 1e-9
 
 
-@pytest.mark.parametrize("kind", ["banded", "diagonal", "rank_deficient_panel", "low_rank_plus_identity"])
-def test_inputs_cholesky_qr_cannot_factor_fall_back_to_one_stage(hip, oracle, forced_two_stage, kind):
-    """A panel without full column rank makes CholeskyQR2 raise its flag on the device (stage level:
-    flag != 0); the whole-path call then repeats the reduction with the one-stage algorithm and still
-    returns correct pairs."""
-    n = 500
-    rng = np.random.default_rng(3)
+def _hard_input(oracle, kind, n, seed=3):
+    rng = np.random.default_rng(seed)
     if kind == "banded":
-        M = np.tril(rng.standard_normal((n, n))); M = M - np.tril(M, -5); A = M + np.tril(M, -1).T
-    elif kind == "diagonal":
-        A = np.diag(rng.uniform(1, 2, n))
-    elif kind == "rank_deficient_panel":
+        M = np.tril(rng.standard_normal((n, n))); M = M - np.tril(M, -5); return M + np.tril(M, -1).T
+    if kind == "diagonal":
+        return np.diag(rng.uniform(1, 2, n))
+    if kind == "rank_deficient_panel":
         A = oracle.synth_matrix(n, 1); A[64:, 3] = 0.0; A[3, 64:] = 0.0          # a zero column in the first panel
-    else:
-        u = rng.standard_normal((n, 3)); A = u @ u.T + np.eye(n)
-    _, _, _, flag = hip.sy2sb(A)
-    assert flag != 0
+        return A
+    if kind == "low_rank_plus_identity":
+        u = rng.standard_normal((n, 3)); return u @ u.T + np.eye(n)
+    if kind == "sparse_pattern":           # the reference's own family: few entries per row, anywhere in the row
+        A = np.zeros((n, n))
+        for i in range(n):
+            for j in rng.integers(0, n, 4):
+                A[i, j] += rng.standard_normal(); A[j, i] = A[i, j]
+        return A + np.diag(rng.uniform(2, 3, n))
+    if kind == "ill_conditioned_panel":    # two nearly parallel columns: cond of the first panel ~ 1e12
+        A = oracle.synth_matrix(n, 1); A[64:, 5] = A[64:, 4] * (1.0 + 1e-12) ; A[5, 64:] = A[64:, 5]
+        return A
+    raise ValueError(kind)
+
+
+HARD = ["banded", "diagonal", "rank_deficient_panel", "low_rank_plus_identity", "sparse_pattern", "ill_conditioned_panel"]
+
+
+@pytest.mark.parametrize("kind", HARD)
+def test_panels_cholesky_qr_cannot_factor_are_rescued_inside_the_stage(hip, oracle, forced_two_stage, kind):
+    """A panel without full column rank (or too ill-conditioned) makes CholeskyQR2's device-side check fail; THAT panel is
+    then factored by Householder reflections (any rank, as PDSYTRD's panels are) and the stage goes on in two stages:
+    no flag, an orthogonal similarity to a band matrix at rounding level, correct pairs from the whole path."""
+    n = 500
+    A = _hard_input(oracle, kind, n)
+    Ab, V, tau, flag = hip.sy2sb(A)
+    assert flag & 0xff == 0
+    if kind != "sparse_pattern":
+        assert flag >> 8 >= 1                       # at least one panel went through the rescue
+    assert np.abs(np.tril(Ab, -(B + 1))).max() == 0.0
+    Q = _q_from_reflectors(V, tau)
+    nrm = max(np.linalg.norm(A), 1.0)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 64 * n * EPS
+    assert np.linalg.norm(Q.T @ A @ Q - _band_of(Ab)) <= 32 * n * EPS * nrm
+    w_or = np.linalg.eigvalsh(A)
+    ep, _ = hip.eigen_solver("hip", A)
+    assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * max(np.abs(w_or).max(), 1.0)
+    _check_pairs(A, None, ep.values, ep.Vectors)
+    import ctypes
+    st = (ctypes.c_double * 8)()
+    hip.load_library().ek_hip_debug_last_solve_stats(st, 8)
+    assert st[1] == 1.0                             # the solve stayed on the two-stage path
+
+
+def test_reference_matrix_through_two_stages(hip, golden_dir, forced_two_stage):
+    """The reference's own sparse Hamiltonian (VCNT400std, 8 200 non-zeros of 160 000) with the two-stage form forced on:
+    its first panels are rank deficient; eigenvalues against the reference's golden file (12 digits)."""
+    from eigenkernel_amd import matrix_io
+    A = matrix_io.read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_VCNT400std_A.mtx")).to_dense()
+    w_ref = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_VCNT400std_E.txt"))[:, 1]
+    ep, _ = hip.eigen_solver("hip", A)
+    assert np.abs(ep.values - w_ref).max() <= 5e-12 * max(1.0, np.abs(w_ref).max())
+    _check_pairs(A, None, ep.values, ep.Vectors)
+    import ctypes
+    st = (ctypes.c_double * 8)()
+    hip.load_library().ek_hip_debug_last_solve_stats(st, 8)
+    assert st[1] == 1.0
+
+
+@pytest.mark.parametrize("kind", ["banded", "sparse_pattern", "low_rank_plus_identity"])
+def test_hard_inputs_at_a_two_stage_order(hip, oracle, kind):
+    """N = 4096 (well inside the two-stage range) against numpy: the rescue at full panel heights."""
+    n = 4096
+    A = _hard_input(oracle, kind, n, seed=5)
     w_or = np.linalg.eigvalsh(A)
     ep, _ = hip.eigen_solver("hip", A)
     assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * max(np.abs(w_or).max(), 1.0)
