@@ -139,8 +139,14 @@ __device__ __forceinline__ Reflector reflector_of(double x, int lane) {
   Reflector r;
   r.beta = alpha0; r.tau = 0.0;
   double scale = 0.0;
-  if (ssq != 0.0) {
-    r.beta = -copysign(sqrt(__builtin_fma(alpha0, alpha0, ssq)), alpha0);   // the path keeps |A| within 1e+-90
+  // The path keeps |A| within 1e+-90, but the fill of a NARROW band decays geometrically across the 64 diagonals: a
+  // column of a bulge can consist of entries around 1e-160, whose squares are denormal -- a norm with three
+  // significant bits, and a "reflector" that is not orthogonal in the third digit (seen: a bandwidth-5 input of order
+  // 5000 lost its spectrum at the 1e-2 level).  A column whose squared norm is below 1e-290 is 1e-55 of the smallest
+  // matrix the path admits: it is dropped (H = I; its entries below the first are the zeros the caller stores anyway).
+  const double nrm2 = __builtin_fma(alpha0, alpha0, ssq);
+  if (ssq != 0.0 && nrm2 > 1e-290) {
+    r.beta = -copysign(sqrt(nrm2), alpha0);
     r.tau = (r.beta - alpha0) / r.beta;
     scale = 1.0 / (alpha0 - r.beta);
   }

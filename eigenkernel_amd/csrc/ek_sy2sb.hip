@@ -189,8 +189,15 @@ __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G,
 #pragma unroll
   for (int k = 0; k < 16; ++k) { const int idx = t + 256 * k; sA[(idx >> 6) * LD + (idx & 63)] = gv[k]; }
   __syncthreads();
+  // (an all-zero panel -- an input that is already banded -- has a zero Gram matrix: flag 4, the rescue's short cut)
+  __shared__ int s_nz;
+  if (t == 0) s_nz = 0;
+  __syncthreads();
+  if (t < SB && sA[t * LD + t] != 0.0) atomicOr(&s_nz, 1);
+  __syncthreads();
+  const int zero_panel = !s_nz;
   const int bad = chol64_upper_wg(sA, s_inv);
-  if (t == 0) *pflag = (bad >= 0) ? 1 : 0;
+  if (t == 0) *pflag = zero_panel ? 4 : ((bad >= 0) ? 1 : 0);
   triinv64_upper_wg(sA, sB, s_inv);
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256) void house_small_kernel(SmallArgs p) {
       __syncthreads();
       ssq = s_red[0] + s_red[1];
       const double alpha = sP[j * LD + j];
-      if (ssq != 0.0) {                    // uniform
+      if (ssq != 0.0 && alpha * alpha + ssq > 1e-290) {   // uniform (a column of denormal squares is dropped: reflector_of, ek_sb2st.hip)
         const double beta = -copysign(hypot(alpha, sqrt(ssq)), alpha);
         tau = (beta - alpha) / beta;
         const double scale = 1.0 / (alpha - beta);
@@ -431,24 +438,35 @@ __global__ __launch_bounds__(HT) void house_tall_kernel(int m, double *__restric
   if (!*pflag) return;
   const int t = threadIdx.x;
   if (t == 0) atomicAdd(d_flag, 256);                      // bits 8..: panels that took this path (informational)
+  if (*pflag & 4) {                                        // the panel is exactly zero: R = 0, H = I
+    if (t < SB) tau_out[t] = 0.0;
+    return;
+  }
   auto vget = [&](int r, int j) -> double {                // entry (r, j) of the unit lower trapezoidal V
     return (r > j) ? P[(size_t)r + (size_t)j * ldp] : (r == j ? 1.0 : 0.0);
   };
   for (int jb = 0; jb < SB; jb += HB) {
     // ---- the block, column by column
+    bool block_active = false;
     for (int j = jb; j < jb + HB; ++j) {
       double a1[1] = {0.0};
       for (int r = j + 1 + t; r < m; r += HT) { const double x = P[(size_t)r + (size_t)j * ldp]; a1[0] += x * x; }
       ht_reduce<1>(a1, s_part, s_out);
       const double ssq = a1[0], alpha = P[(size_t)j + (size_t)j * ldp];
       double tau = 0.0, beta = alpha, scale = 0.0;
-      if (ssq != 0.0) {
+      if (ssq != 0.0 && alpha * alpha + ssq > 1e-290) {     // (a column of denormal squares is dropped: see reflector_of, ek_sb2st.hip)
         beta = -copysign(sqrt(alpha * alpha + ssq), alpha);
         tau = (beta - alpha) / beta;
         scale = 1.0 / (alpha - beta);
       }
       __syncthreads();                                     // everybody has read alpha
       if (t == 0) { s_tau[j] = tau; tau_out[j] = tau; P[(size_t)j + (size_t)j * ldp] = beta; }
+      if (tau == 0.0) {                                    // nothing to annihilate in this column: H = I (uniform)
+        if (ssq != 0.0)                                    // (a dropped column of denormal squares: its entries are zeros now)
+          for (int r = j + 1 + t; r < m; r += HT) P[(size_t)r + (size_t)j * ldp] = 0.0;
+        continue;
+      }
+      block_active = true;
       // v = x * scale (stored), w_c = v^T p_c for the columns of the block to the right of j
       double w[HB - 1];
 #pragma unroll
@@ -462,16 +480,15 @@ __global__ __launch_bounds__(HT) void house_tall_kernel(int m, double *__restric
           if (c < nc) w[c] += v * P[(size_t)r + (size_t)(j + 1 + c) * ldp];
       }
       ht_reduce<HB - 1>(w, s_part, s_out);
-      if (tau != 0.0) {
-        for (int r = j + t; r < m; r += HT) {
-          const double v = (r > j) ? P[(size_t)r + (size_t)j * ldp] : 1.0;
+      for (int r = j + t; r < m; r += HT) {
+        const double v = (r > j) ? P[(size_t)r + (size_t)j * ldp] : 1.0;
 #pragma unroll
-          for (int c = 0; c < HB - 1; ++c)
-            if (c < nc) P[(size_t)r + (size_t)(j + 1 + c) * ldp] -= tau * w[c] * v;
-        }
+        for (int c = 0; c < HB - 1; ++c)
+          if (c < nc) P[(size_t)r + (size_t)(j + 1 + c) * ldp] -= tau * w[c] * v;
       }
       __syncthreads();
     }
+    if (!block_active) continue;                           // a block without a reflector (a panel that is already triangular)
     if (jb + HB >= SB) break;
     // ---- T of the block (DLARFT, forward columnwise) from G = V^T V
     {

@@ -96,6 +96,24 @@ def test_band_to_tridiagonal_degenerate_bands(hip, kind):
     assert np.linalg.norm(Q2.T @ Bd @ Q2 - T) <= 32 * n * EPS * scale
 
 
+def test_narrow_band_whose_fill_decays_into_the_denormal_range(hip):
+    """A bandwidth-5 matrix inside the 64-diagonal band: the fill decays geometrically across the band, columns of the
+    bulges come to consist of entries around 1e-160 whose SQUARES are denormal; a reflector made from such a norm is
+    not orthogonal (this input lost its spectrum at the 1e-2 level before reflector_of dropped such columns)."""
+    from scipy.linalg import eigvalsh_tridiagonal
+    n = 5000
+    rng = np.random.default_rng(1)
+    A = np.zeros((n, n), order="F")
+    for dgn in range(5):
+        v = rng.standard_normal(n - dgn)
+        A[np.arange(dgn, n), np.arange(0, n - dgn)] = v
+        A[np.arange(0, n - dgn), np.arange(dgn, n)] = v
+    d, e, _, f = hip.sb2st(A)
+    assert f == 0
+    w_ref = np.linalg.eigvalsh(A)
+    assert np.abs(eigvalsh_tridiagonal(d, e) - w_ref).max() <= 4 * n * EPS * np.abs(w_ref).max()
+
+
 def test_bulge_chasing_is_bitwise_reproducible(hip):
     """The sweeps hand blocks to each other through agent-scope loads and stores guarded by progress
     words; a stale read would show up as run-to-run differences."""

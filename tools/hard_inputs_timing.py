@@ -34,7 +34,8 @@ def make(kind):
     if kind == "sparse_pattern":
         A = np.zeros((n, n), order="F")
         i = np.repeat(np.arange(n), 4); j = rng.integers(0, n, 4 * n); v = rng.standard_normal(4 * n)
-        A[i, j] = v; A[j, i] = v
+        A[i, j] = v
+        A = np.tril(A); A = np.asfortranarray(A + np.tril(A, -1).T)
         A[np.arange(n), np.arange(n)] = rng.uniform(2, 3, n)
         return A
     raise ValueError(kind)
