@@ -1080,6 +1080,223 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------ Q2: NBLK blocks of sweeps per pass
+// The same pipeline with a BUNDLE of NBLK blocks of sweeps (NBLK q .. NBLK q + NBLK - 1) per pass: the window grows
+// to 2 NBLK + 4 row tiles (block b of the bundle acts on window rows 32 b .. 32 b + 95), a step applies the groups
+// (S + NBLK - 1, k), ..., (S, k) and then stores the first 64 rows of the window and takes in 64 new ones -- which
+// are chunk k + 1 of the bundle ABOVE (it starts 32 NBLK rows further down), so the hand-off between passes is the one
+// of the pair kernel.  Z is streamed once per NBLK blocks (n^3 / (8 NBLK) bytes each way for all columns) and the
+// fetch, the two LDS transposes and the store of a chunk are shared by NBLK groups instead of two.  Same groups, same
+// order on every element as in q2_apply_kernel: the same bits.  NBLK = 3: 10 tiles = 80 registers of window; four do
+// not fit beside the record prefetch.
+template <int NBLK>
+__global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
+  constexpr int WT = 2 * NBLK + 4;                        // row tiles of the window
+  extern __shared__ __attribute__((aligned(16))) double q2smem[];
+  double *sOp = q2smem;
+  __shared__ int s_pass, s_ok;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+  double *st = q2smem + QOPSZ + wave * 16 * QSTLD;      // this wave's transposing buffer
+  const int n = p.g.n;
+  const double *sV = sOp, *sVT = sOp + QR * QVLD;
+  while (true) {
+    __syncthreads();
+    if (t == 0) s_pass = (int)atomicAdd(&p.ctl[2], 1u);
+    __syncthreads();
+    const int pass = s_pass;
+    if (pass >= p.npass) break;
+    const int bundle = p.npair - 1 - pass / p.nslab, slab = pass % p.nslab;      // (npair: number of bundles)
+    const int S = NBLK * bundle;                         // lowest block of the bundle
+    int KSb[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) KSb[b] = (S + b < p.g.nS) ? q2_groups_of_block(n, S + b) : 0;
+    const int KS = KSb[0];
+    const int colw = slab * QNC + 16 * wave;
+    const unsigned *pprog = (bundle + 1 < p.npair) ? p.prog + (size_t)(pass - p.nslab) : nullptr;   // the bundle above, same slab
+    unsigned *myprog = p.prog + pass;
+    if (KS <= 0) { if (t == 0) __hip_atomic_store(myprog, kQ2Done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
+    const int o0 = S * QG;                               // first row of the window at step 0 (even)
+    auto wait_for = [&](unsigned need) -> bool {         // thread 0 only
+      if (!pprog) return true;
+      unsigned spins = 0;
+      while (__hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 63u) == 0u &&
+            (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+          return false;
+      }
+      return true;
+    };
+    double4_t w[WT];
+    constexpr int NPAIR = QREC / 2, NOP = (NPAIR + 255) / 256;   // 13 pairs of a record per thread
+    double zreg[16];
+    d2_t oreg[NOP];
+    auto fetch_ops = [&](int Sb, int k) {                // the record is the LDS image itself: a linear copy
+      const d2_t *rec = reinterpret_cast<const d2_t *>(p.Rec + ((size_t)p.g.offS[Sb] + k) * QREC);
+#pragma unroll
+      for (int q = 0; q < NOP; ++q) oreg[q] = (q < NOP - 1 || t + 256 * q < NPAIR) ? rec[t + 256 * q] : (d2_t){0.0, 0.0};
+    };
+    auto put_ops = [&]() {
+      d2_t *dst = reinterpret_cast<d2_t *>(sOp);
+#pragma unroll
+      for (int q = 0; q < NOP; ++q)
+        if (q < NOP - 1 || t + 256 * q < NPAIR) dst[t + 256 * q] = oreg[q];
+    };
+    const bool cols_in = colw + 16 <= p.ncols;
+    // 64 rows from global row `row0` on -> zreg: lane = row, 16 columns (sc1: another pass may have written them)
+    auto fetch_rows = [&](int row0) {
+      const int row = row0 + lane;
+      const double *src = p.Z + (size_t)row + (size_t)colw * p.ldz;
+      if (cols_in && row0 + SB <= n) {                   // interior: no predicates
+#pragma unroll
+        for (int c = 0; c < 16; ++c) zreg[c] = ld_sc1(src + (size_t)c * p.ldz);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          zreg[c] = (row < n && colw + c < p.ncols) ? ld_sc1(src + (size_t)c * p.ldz) : 0.0;
+      }
+    };
+    // half h (32 rows) of zreg -> two tiles in the accumulator layout, through the per-wave buffer
+    auto half_to_tiles = [&](int h, double4_t &ta, double4_t &tb) {
+      if ((lane >> 5) == h) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) st[c * QSTLD + (lane & 31)] = zreg[c];
+      }
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ta[r] = st[l15 * QSTLD + l4 + 4 * r]; tb[r] = st[l15 * QSTLD + 16 + l4 + 4 * r]; }
+      wave_sync();
+    };
+    // two tiles (32 rows from global row `row0`) -> memory as aligned row pairs (16-byte write-through stores)
+    auto tiles_to_rows = [&](int row0, const double4_t &ta, const double4_t &tb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st[l15 * QSTLD + l4 + 4 * r] = ta[r]; st[l15 * QSTLD + 16 + l4 + 4 * r] = tb[r]; }
+      wave_sync();
+      {
+        const int pr = lane & 15, cg = lane >> 4;        // row pair, 4 columns per lane
+        const int row = row0 + 2 * pr;
+        double *dst0 = p.Z + (size_t)row + (size_t)(colw + 4 * cg) * p.ldz;
+        if (cols_in && row0 + 32 <= n) {                 // interior: no predicates
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = 4 * cg + q;
+            st_sc1_x2(dst0 + (size_t)q * p.ldz, st[c * QSTLD + 2 * pr], st[c * QSTLD + 2 * pr + 1]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = 4 * cg + q;
+            if (colw + c < p.ncols) {
+              const double a = st[c * QSTLD + 2 * pr], b = st[c * QSTLD + 2 * pr + 1];
+              if (row + 1 < n) st_sc1_x2(dst0 + (size_t)q * p.ldz, a, b);
+              else if (row < n) st_sc1(dst0 + (size_t)q * p.ldz, a);
+            }
+          }
+        }
+      }
+      wave_sync();
+    };
+    // one group on window tiles OFF .. OFF + 5
+    auto apply_group = [&](auto off_c) {
+      constexpr int OFF = decltype(off_c)::value;
+      double4_t w1[2];
+      w1[0] = (double4_t){0.0, 0.0, 0.0, 0.0}; w1[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int tile = 0; tile < 6; ++tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double y = w[tile + OFF][r];
+          const double *vrow = sV + (16 * tile + 4 * r + l4) * QVLD + l15;
+          if (tile < 5) w1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[0], y, w1[0], 0, 0, 0);
+          if (tile > 0) w1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[16], y, w1[1], 0, 0, 0);
+        }
+#pragma unroll
+      for (int tile = 0; tile < 6; ++tile) {
+        double4_t acc = w[tile + OFF];
+        const double *xrow = sVT + (16 * tile + l15) * QVLD + l4;
+#pragma unroll
+        for (int kk = (tile == 5 ? 16 : 0); kk < QG; kk += 4)      // rows 80.. of V T: columns 16.. only
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xrow[kk], w1[kk >> 4][(kk & 15) >> 2], acc, 0, 0, 0);
+        w[tile + OFF] = acc;
+      }
+    };
+    // the groups in the order they are applied: step k ascending, inside a step the blocks descending
+    auto first_block = [&](int k) -> int {               // highest block that has a group k (block 0 has: k < KS)
+      int b = 0;
+#pragma unroll
+      for (int q = 1; q < NBLK; ++q) if (k < KSb[q]) b = q;
+      return b;
+    };
+    auto prefetch_next = [&](int k, int b) {             // the record of the group after (b, k)
+      int nb = -1, nk = k;
+#pragma unroll
+      for (int q = NBLK - 1; q >= 0; --q) if (q < b && nb < 0 && k < KSb[q]) nb = q;
+      if (nb < 0) { nk = k + 1; if (nk < KS) nb = first_block(nk); }
+      if (nb >= 0) fetch_ops(S + nb, nk);
+    };
+    // ---- prologue: the window at step 0; its rows from 32 NBLK on are chunk 0 of the bundle above (+ slack)
+    if (t == 0) s_ok = wait_for((unsigned)(1 + p.extra)) ? 1 : 0;
+    __syncthreads();
+    if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+#pragma unroll
+    for (int c = 0; c < WT / 4; ++c) {
+      fetch_rows(o0 + 64 * c);
+      half_to_tiles(0, w[4 * c], w[4 * c + 1]);
+      half_to_tiles(1, w[4 * c + 2], w[4 * c + 3]);
+    }
+    if (WT % 4) {                                        // NBLK odd: half a chunk more
+      fetch_rows(o0 + 64 * (WT / 4));
+      half_to_tiles(0, w[WT - 2], w[WT - 1]);
+    }
+    fetch_ops(S + first_block(0), 0);
+    unsigned early = 0;                                   // thread 0: an early look at the predecessor's progress
+    for (int k = 0; k < KS; ++k) {
+      // gate of this step: the 64 rows fetched below are chunk k + 1 of the bundle above
+      if (t == 0) {
+        const unsigned need = (unsigned)(k + 2 + p.extra);
+        s_ok = (!pprog || early >= need || wait_for(need)) ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+      // every wave has passed the drain in front of its stores of chunk k-1, so chunks <= k-2 are in memory
+      if (t == 0 && k > 1) __hip_atomic_store(myprog, (unsigned)(k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int bfirst = first_block(k);
+      auto do_group = [&](auto b_c) {
+        constexpr int B = decltype(b_c)::value;
+        if (k >= KSb[B]) return;                         // (uniform)
+        put_ops();
+        __syncthreads();
+        if (B == bfirst && t == 0 && pprog) early = __hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prefetch_next(k, B);
+        if (B == bfirst && k + 1 < KS) fetch_rows(o0 + 64 * (k + 1) + 16 * (WT - 4));
+        apply_group(std::integral_constant<int, 2 * B>());
+        if (B > 0) __syncthreads();                      // all waves have read the images of this group
+      };
+      if constexpr (NBLK >= 4) do_group(std::integral_constant<int, 3>());
+      if constexpr (NBLK >= 3) do_group(std::integral_constant<int, 2>());
+      if constexpr (NBLK >= 2) do_group(std::integral_constant<int, 1>());
+      do_group(std::integral_constant<int, 0>());
+      // (the stores of the previous chunk, issued a whole step ago, have long completed: this wait
+      // only makes that certain before the progress word of the next step tells the follower)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tiles_to_rows(o0 + 64 * k, w[0], w[1]);            // chunk k is final for every block of the bundle
+      tiles_to_rows(o0 + 64 * k + 32, w[2], w[3]);
+#pragma unroll
+      for (int i = 0; i + 4 < WT; ++i) w[i] = w[i + 4];
+      if (k + 1 < KS) {
+        half_to_tiles(0, w[WT - 4], w[WT - 3]);
+        half_to_tiles(1, w[WT - 2], w[WT - 1]);
+      } else {
+#pragma unroll
+        for (int i = 0; i + 4 < WT; i += 2) tiles_to_rows(o0 + 64 * (k + 1) + 16 * i, w[i], w[i + 1]);   // the rest of the window
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(myprog, kQ2Done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ void forward_abort_kernel(const unsigned *ctl, int *flag) { if (ctl[1]) atomicOr(flag, 4); }
 __global__ void q2_offsets_kernel(int n, int nS, unsigned *offS) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1234,8 +1451,18 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   hipLaunchKernelGGL(q2_tfactor_kernel, dim3(L.kmax, L.nS), dim3(256), 0, s, g, V2, ldv2, tau2, L.ldt, Rec);
   constexpr size_t lds = (size_t)(QOPSZ + 4 * 16 * QSTLD) * sizeof(double);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)q2_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  const int nslab = ceil_div(ncols, QNC), npair = ceil_div(L.nS, 2), npass = npair * nslab;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)q2_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)q2_apply_nb_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)q2_apply_nb_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  // blocks of sweeps per pass: 3 (q2_apply_nb_kernel<3>); EK_Q2_NBLK=2 the pair kernel of round 2, 22 the general
+  // kernel with pairs (all three give the same bits)
+  int nblk = 3;
+  if (const char *ev = getenv("EK_Q2_NBLK")) nblk = atoi(ev);
+  const int per = (nblk == 3) ? 3 : 2;
+  const int nslab = ceil_div(ncols, QNC), npair = ceil_div(L.nS, per), npass = npair * nslab;
   (void)hipMemsetAsync(qprog, 0, (size_t)npass * 4, s);
   (void)hipMemsetAsync(ctl + 2, 0, 4, s);
   // extra: how many further steps a pass stays behind its predecessor in the slab (fetch distance).  With few slabs
@@ -1248,7 +1475,9 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   if (const char *ev = getenv("EK_Q2_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
   if (nwg > npass) nwg = npass;
   kprof_begin(s, kProfQ2Apply);
-  hipLaunchKernelGGL(q2_apply_kernel, dim3(nwg), dim3(256), lds, s, a);
+  if (nblk == 3) hipLaunchKernelGGL(q2_apply_nb_kernel<3>, dim3(nwg), dim3(256), lds, s, a);
+  else if (nblk == 22) hipLaunchKernelGGL(q2_apply_nb_kernel<2>, dim3(nwg), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(q2_apply_kernel, dim3(nwg), dim3(256), lds, s, a);
   kprof_end(s, kProfQ2Apply);
   if (d_flag) hipLaunchKernelGGL(forward_abort_kernel, dim3(1), dim3(1), 0, s, ctl, d_flag);
 }

@@ -174,6 +174,30 @@ def test_both_bulge_chasing_kernels_give_the_same_bits(hip, n):
     assert np.abs(np.linalg.eigvalsh(Bd) - np.linalg.eigvalsh(T)).max() <= 8 * n * EPS * np.abs(d2).max()
 
 
+@pytest.mark.parametrize("n,ncols", [(3, 3), (66, 66), (130, 17), (200, 200), (321, 64), (777, 100), (1000, 1000), (1500, 333)])
+def test_q2_application_does_not_depend_on_the_blocks_of_sweeps_per_pass(hip, n, ncols):
+    """Z <- Q2 Z streams Z once per bundle of blocks of 32 sweeps: three per pass (the default), two (the round-2
+    kernel, EK_Q2_NBLK=2, and the general kernel with pairs, 22).  Same groups in the same order on every element:
+    the results must be the same bits, and Q2 orthogonal."""
+    Bd = _random_band(n, 7 * n + 3)
+    rng = np.random.default_rng(n)
+    Z0 = rng.standard_normal((n, ncols))
+    res = {}
+    try:
+        for nblk in ("2", "22", "3"):
+            os.environ["EK_Q2_NBLK"] = nblk
+            d, e, Z, f = hip.sb2st(Bd, Z0)
+            assert f == 0
+            res[nblk] = (d, e, Z)
+    finally:
+        os.environ.pop("EK_Q2_NBLK", None)
+    for nblk in ("22", "3"):
+        assert np.array_equal(res["2"][2], res[nblk][2]), nblk
+    if ncols == n:
+        _, _, Q2, _ = hip.sb2st(Bd, np.eye(n))
+        assert np.linalg.norm(Q2.T @ Q2 - np.eye(n)) <= 64 * n * EPS
+
+
 def test_position_kernel_falls_back_when_its_workgroups_cannot_all_be_resident(hip):
     """The position-owned kernel needs every workgroup on the chip at once; its census gives up after a bounded
     wait and the sweep kernel behind it redoes the stage from the repacked band (same bits).  A census of zero
