@@ -15,7 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def counter(path, kernel, name):
     for line in open(path):
         f = line.split()
-        if len(f) >= 5 and f[0].startswith(kernel) and f[1] == name:
+        if len(f) >= 5 and f[0].startswith(kernel) and name in f:
+            i = f.index(name)
+            return float(f[i + 1]), float(f[i + 2])
+        if False:
             return float(f[2]), float(f[3])
     raise SystemExit("no %s for %s in %s" % (name, kernel, path))
 
@@ -24,15 +27,15 @@ def main():
     tag = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
     d = os.path.join(ROOT, "gpurun_out", "r03prof_" + tag)
-    nf, fetch = counter(os.path.join(d, "pmc_fetch_c3.txt"), "q2_apply_kernel", "FETCH_SIZE")
-    nw, write = counter(os.path.join(d, "pmc_write_c3.txt"), "q2_apply_kernel", "WRITE_SIZE")
+    nf, fetch = counter(os.path.join(d, "pmc_fetch_c3.txt"), "q2_apply", "FETCH_SIZE")
+    nw, write = counter(os.path.join(d, "pmc_write_c3.txt"), "q2_apply", "WRITE_SIZE")
     sha_box = open(os.path.join(d, "source_sha256.txt")).read().split()[0]
     src = os.path.join(ROOT, "eigenkernel_amd", "csrc", "ek_sb2st.hip")
     sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
     if sha != sha_box:
         raise SystemExit("ek_sb2st.hip has changed since the measurement (%s vs %s)" % (sha[:12], sha_box[:12]))
     git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-    rec = {"n": n, "ncols": n, "kernel": "q2_apply_kernel", "git": git, "source_sha256": sha,
+    rec = {"n": n, "ncols": n, "kernel": "q2_apply_nb_kernel<3>", "git": git, "source_sha256": sha,
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex) on "
                      "`python3 bench.py --steps 1 --warmup 0 ...` (tools/r03_profile.sh); counters are KiB; FETCH_SIZE doubled as "
                      "MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE taken as is (16-byte stores)",
