@@ -1,0 +1,843 @@
+// ek_solve.hip -- the whole path behind the reference's solver arms (solver_main.f90:52-99): the driver on
+// device-resident data (solve_device_locked), the staging pipeline of the host path, the replicated- and
+// distributed-input forms on process grids, and the C entries ek_hip_solve* of include/ek_hip.h.
+#include "ek_api_internal.h"
+
+#include <condition_variable>
+#include <deque>
+#include <thread>
+
+namespace ek {
+namespace api {
+
+// all-gather of the packed band of a team whose members hold the columns of their own strips (strip S on rank S mod P):
+// one exchange per round of P strips
+void gather_band_strips(hipStream_t s, int n, int nmem, int rank0, double *const *ABs, const SytrdExchange &x) {
+  const int NRB = ceil_div(n, 128), P = x.nranks;
+  if (P <= 1) return;
+  for (int q = 0; q * P < NRB; ++q) {
+    size_t offs[kMaxTeam], counts[kMaxTeam];
+    for (int r = 0; r < P; ++r) {
+      const int S = q * P + r;
+      const int cols = (S < NRB) ? ((n - S * 128 < 128) ? n - S * 128 : 128) : 0;
+      offs[r] = (S < NRB) ? (size_t)S * 128 * kBandLd : 0; counts[r] = (size_t)cols * kBandLd;
+    }
+    x.allgatherv(s, nmem, rank0, ABs, offs, counts, P, x.user);
+  }
+}
+
+
+}  // namespace api
+}  // namespace ek
+
+using namespace ek;
+using namespace ek::api;
+
+namespace {
+
+// local piece (nr x nc, lld) <-> its place in the full matrix; blocks of nb rows are contiguous
+template <typename F>
+void for_each_local_block(int m, int n, int nb, int pr, int nprow, int pc, int npcol, F f) {
+  const int nr = numroc0(m, nb, pr, nprow), nc = numroc0(n, nb, pc, npcol);
+  for (int lc = 0; lc < nc; ++lc) {
+    const size_t gc = (size_t)((lc / nb) * npcol + pc) * nb + lc % nb;
+    for (int lr0 = 0; lr0 < nr; lr0 += nb) {
+      const size_t gr0 = (size_t)((lr0 / nb) * nprow + pr) * nb;
+      f(lr0, lc, gr0, gc, (nr - lr0 < nb) ? nr - lr0 : nb, nr);
+    }
+  }
+}
+
+// M_full (m x n, ldf) <- all ranks' pieces of a block-cyclic matrix, through the host hook.
+int gather_full(int m, int n, const double *M_loc, const int *desc, const GridCell &g, double *M_full,
+                int ldf) {
+  if (!g_allgatherv) return -998;
+  const int nb = desc[4], P = g.nprow * g.npcol;
+  std::vector<long long> counts(P), displs(P);
+  long long tot = 0;
+  for (int r = 0; r < P; ++r) {            // ranks in row-major grid order (processes.f90:23, 'R')
+    counts[r] = (long long)numroc0(m, nb, r / g.npcol, g.nprow) * numroc0(n, nb, r % g.npcol, g.npcol);
+    displs[r] = tot; tot += counts[r];
+  }
+  const int me = g.myrow * g.npcol + g.mycol;
+  double *send = (double *)malloc((size_t)(counts[me] > 0 ? counts[me] : 1) * 8);
+  double *recv = (double *)malloc((size_t)(tot > 0 ? tot : 1) * 8);
+  if (!send || !recv) { free(send); free(recv); return -1000 - (int)hipErrorOutOfMemory; }
+  const int lld = desc[8];
+  for_each_local_block(m, n, nb, g.myrow, g.nprow, g.mycol, g.npcol,
+                       [&](int lr0, int lc, size_t, size_t, int len, int nr) {
+                         memcpy(send + (size_t)lr0 + (size_t)lc * nr, M_loc + (size_t)lr0 + (size_t)lc * lld,
+                                (size_t)len * 8);
+                       });
+  const int rc = g_allgatherv(send, counts[me], recv, counts.data(), displs.data(), g_allgatherv_user);
+  if (rc == 0) {
+    for (int r = 0; r < P; ++r) {
+      const double *piece = recv + displs[r];
+      for_each_local_block(m, n, nb, r / g.npcol, g.nprow, r % g.npcol, g.npcol,
+                           [&](int lr0, int lc, size_t gr0, size_t gc, int len, int nr) {
+                             memcpy(M_full + gr0 + gc * (size_t)ldf, piece + (size_t)lr0 + (size_t)lc * nr,
+                                    (size_t)len * 8);
+                           });
+    }
+  }
+  free(send); free(recv);
+  return rc == 0 ? 0 : -999;
+}
+
+// M_loc <- this cell's piece of M_full
+void extract_local(int m, int n, const double *M_full, int ldf, const int *desc, const GridCell &g,
+                   double *M_loc) {
+  const int lld = desc[8];
+  for_each_local_block(m, n, desc[4], g.myrow, g.nprow, g.mycol, g.npcol,
+                       [&](int lr0, int lc, size_t gr0, size_t gc, int len, int) {
+                         memcpy(M_loc + (size_t)lr0 + (size_t)lc * lld, M_full + gr0 + gc * (size_t)ldf,
+                                (size_t)len * 8);
+                       });
+}
+
+
+// Staging pipeline of ek_hip_solve on a 1 x 1 grid (host arrays in, host arrays out: solver_main.f90:64-65).  The
+// copies run on worker threads with their own non-blocking streams while the main thread issues the stages:
+//   in : B, then A (B is needed first: the Cholesky factorisation runs while A is still on its way);
+//   out: L as soon as it is final (it leaves during the reduction), the reflectors / band of A after the
+//        tridiagonalisation, Z in column slabs as the last stage finishes them, w last.
+// A copy of pageable host memory keeps its calling thread busy (the runtime stages it through pinned buffers), which
+// is why the copies have threads of their own; a matrix is cut into column pieces so that two threads share it.
+struct HostPipe {
+  struct Job { double *dev; int ldd; double *host; int ldh; int m, n; hipEvent_t after; int tag; bool to_host; };
+  static constexpr int kThreads = 2;         // per direction
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Job> in_q, out_q;
+  int pending_in[2] = {0, 0};                // tag 0 = B, 1 = A: pieces not yet in HBM
+  int pending_out = 0;
+  bool closing = false;
+  int err = 0;
+  std::vector<std::thread> th;
+  hipStream_t cs[2 * kThreads] = {};
+  int device = 0;
+  int z_slab = 2048;
+
+  int start(int dev) {
+    device = dev;
+    for (auto &c : cs) EK_HIP_CHECK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    for (int i = 0; i < 2 * kThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i]); });
+    return 0;
+  }
+  void run(bool input, hipStream_t c) {
+    (void)hipSetDevice(device);
+    std::deque<Job> &q = input ? in_q : out_q;
+    while (true) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return !q.empty() || closing; });
+        if (q.empty()) return;
+        j = q.front(); q.pop_front();
+      }
+      hipError_t e = hipSuccess;
+      if (j.after) e = hipEventSynchronize(j.after);
+      if (e == hipSuccess && j.m > 0 && j.n > 0) {
+        if (j.to_host)
+          e = hipMemcpy2DAsync(j.host, (size_t)j.ldh * 8, j.dev, (size_t)j.ldd * 8, (size_t)j.m * 8, j.n, hipMemcpyDeviceToHost, c);
+        else
+          e = hipMemcpy2DAsync(j.dev, (size_t)j.ldd * 8, j.host, (size_t)j.ldh * 8, (size_t)j.m * 8, j.n, hipMemcpyHostToDevice, c);
+        if (e == hipSuccess) e = hipStreamSynchronize(c);
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (e != hipSuccess && !err) err = -1000 - (int)e;
+        if (input) --pending_in[j.tag]; else --pending_out;
+      }
+      cv.notify_all();
+    }
+  }
+  // host array (m x n, ldh) <-> device image (ldd), cut into column pieces for the threads
+  void push(bool to_host, double *dev, int ldd, double *host, int ldh, int m, int n, hipEvent_t after, int tag) {
+    const int pieces = (n >= 256) ? 2 * kThreads : 1;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (int p = 0; p < pieces; ++p) {
+        const int c0 = (int)((long long)n * p / pieces), c1 = (int)((long long)n * (p + 1) / pieces);
+        Job j{dev + (size_t)c0 * ldd, ldd, host + (size_t)c0 * ldh, ldh, m, c1 - c0, after, tag, to_host};
+        if (to_host) { out_q.push_back(j); ++pending_out; } else { in_q.push_back(j); ++pending_in[tag]; }
+      }
+    }
+    cv.notify_all();
+  }
+  int wait_in(int tag) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&]() { return pending_in[tag] == 0; });
+    return err;
+  }
+  int finish() {                              // all copies done; threads joined; streams released
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&]() { return pending_out == 0 && pending_in[0] == 0 && pending_in[1] == 0; });
+      closing = true;
+    }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+    th.clear();
+    for (auto &c : cs) if (c) { (void)hipStreamDestroy(c); c = nullptr; }
+    for (auto &e : evs) (void)hipEventDestroy(e);
+    evs.clear();
+    return err;
+  }
+  ~HostPipe() { if (!th.empty()) (void)finish(); }
+  // an event recorded on stream s now (the device image is final there)
+  std::vector<hipEvent_t> evs;
+  hipEvent_t mark(hipStream_t s) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    (void)hipEventRecord(e, s);
+    evs.push_back(e);
+    return e;
+  }
+  // what the solve hands over: host destinations of the in-place results
+  double *hA = nullptr, *hB = nullptr, *hZ = nullptr; int ldha = 0, ldhb = 0, ldhz = 0;
+};
+
+struct StageTimer {      // events are released when the timer goes out of scope, whichever way the call ends
+  hipEvent_t ev[EK_HIP_N_STAGES + 1];
+  int made = 0;
+  bool on = false;
+  int init() {
+    for (auto &e : ev) { EK_HIP_CHECK(hipEventCreate(&e)); ++made; }
+    on = true; return 0;
+  }
+  void destroy() { for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]); made = 0; on = false; }
+  ~StageTimer() { destroy(); }
+};
+
+// Runs the path on user device arrays dA, dB, dZ (column-major, any ld >= n) by way of padded
+// internal work arrays (ld multiple of 128, zero padding), so the kernels see aligned tiles.
+//
+// cell == nullptr: dZ receives the first n_vec eigenvectors (n x n_vec).  Otherwise the reduction
+// and the tridiagonal eigenproblem are computed as usual (replicated on every rank) and only the
+// eigenvector columns this grid cell owns are back-transformed; dZ receives the local
+// block-cyclic piece numroc(n, nb, myrow, nprow) x numroc(n_vec, nb, mycol, npcol).
+int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
+                        double *dw, double *dZ, int ldz, double *stage_seconds, int n_stages,
+                        const GridCell *cell = nullptr, HostPipe *pipe = nullptr) {
+  hipStream_t s = g_ctx.stream;
+  const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
+  const int nc_loc = cell ? numroc0(n_vec, cell->nb, cell->mycol, cell->npcol) : n_vec;
+  const int nr_loc = cell ? numroc0(n, cell->nb, cell->myrow, cell->nprow) : n;
+  // A communicator attached by the host (ek_hip_comm_init) whose size is the grid's: the
+  // tridiagonalisation is distributed over the ranks (one RCCL all-reduce per column); the other
+  // stages are as in the replicated-input mode.
+  const bool dist = cell && g_comm.on && g_comm.nranks == cell->nprow * cell->npcol;
+  if (dist && g_comm.rank != cell->myrow * cell->npcol + cell->mycol) return -994;
+  const size_t wb_sytrd = dist ? sytrd_dist_work_bytes(n, g_comm.nranks) : sytrd_work_bytes(n),
+               wb_stedc = stedc_work_bytes(n), wb_ormtr = ormtr_work_bytes(n, nc_loc, n_vec);
+  const size_t mat = al((size_t)ld * ld * 8);
+  size_t scratch = wb_sytrd;
+  if (wb_stedc > scratch) scratch = wb_stedc;
+  if (wb_ormtr > scratch) scratch = wb_ormtr;
+  const size_t trsm_work = al((size_t)128 * ld * 8);
+  void *ws;
+  size_t sygst_dbl = (problem == 1) ? sygst_scratch_doubles(n) : 0;
+  if (problem == 1 && dist) {
+    const size_t dd = sygst_dist_scratch_doubles(n, ld, g_comm.nranks);
+    if (dd > sygst_dbl) sygst_dbl = dd;
+  }
+  const size_t sygst_scr = al(sygst_dbl * 8);
+  // right-looking Cholesky with look-ahead from this order on (below it the recursion is as fast)
+  const bool potrf_rl = problem == 1 && n >= kPotrfRlMin;
+  size_t potrf_wb = (problem == 1 && dist) ? al(potrf_dist_work_bytes(n, ld, g_comm.nranks)) : 0;
+  if (potrf_rl && al(potrf_rl_work_bytes(n, ld)) > potrf_wb) potrf_wb = al(potrf_rl_work_bytes(n, ld));
+  int rc = 0;
+  // two-stage tridiagonalisation: one more matrix for the reflectors of the bulge chasing, a copy of
+  // the reduced matrix for the (rare) fall-back to the one-stage path, and the stages' own scratch
+  const int ts_min = two_stage_min();
+  const bool two_stage = ts_min > 0 && n >= ts_min && n >= 3;
+  const size_t wb_sy2sb = two_stage ? al(dist ? sy2sb_dist_work_bytes(n, g_comm.nranks) : sy2sb_work_bytes(n)) : 0,
+               wb_sb2st = two_stage ? al(sb2st_work_bytes(n)) : 0;
+  const size_t wb_q1prep = two_stage ? al(ormtr_prep_bytes(n)) : 0;
+  const size_t ws_need = 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
+                         4 * al((size_t)ld * 8) + sygst_scr + potrf_wb +
+                         (two_stage ? 2 * mat + wb_sy2sb + wb_sb2st + wb_q1prep + al((size_t)ld * 8) : 0);
+  rc = workspace(ws_need, &ws);
+  if (dist) rc = comm_agree(rc);         // a rank that cannot get its workspace takes the team out with it (-993)
+  if (rc) return rc;
+  Arena a(ws, g_ctx.ws_bytes);
+  double *wA = a.get<double>((size_t)ld * ld);
+  double *wB = a.get<double>((size_t)ld * ld);
+  double *wZ = a.get<double>((size_t)ld * ld);
+  double *wV = a.get<double>((size_t)ld * ld);
+  double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
+  double *twork = a.get<double>((size_t)128 * ld);
+  char *work = a.get<char>(scratch);
+  double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
+  double *sscr = (problem == 1) ? a.get<double>(sygst_dbl) : nullptr;
+  char *pwork = potrf_wb ? a.get<char>(potrf_wb) : nullptr;
+  double *wV2 = two_stage ? a.get<double>((size_t)ld * ld) : nullptr;
+  double *wA0 = two_stage ? a.get<double>((size_t)ld * ld) : nullptr;
+  char *work_sy2sb = two_stage ? a.get<char>(wb_sy2sb) : nullptr;
+  char *work_sb2st = two_stage ? a.get<char>(wb_sb2st) : nullptr;
+  char *q1prep = two_stage ? a.get<char>(wb_q1prep) : nullptr;
+  double *dt1 = two_stage ? a.get<double>(ld) : nullptr;
+  // where the tridiagonalisation keeps x, the panel and its partial sums (probed once per workspace)
+  void *sytrd_work = two_stage ? (void *)work : choose_sytrd_scratch(n, ld, wA, work, dd, wb_sytrd);
+
+  StageTimer tm;
+  const bool timing = stage_seconds && n_stages > 0;
+  if (timing) { rc = tm.init(); if (rc) return rc; }
+  int evi = 0;
+  auto mark = [&]() { if (timing) (void)hipEventRecord(tm.ev[evi++], s); };
+
+  EK_HIP_CHECK(hipMemsetAsync(g_ctx.d_info, 0, 4 * sizeof(int), s));
+  mark();                                                              // 0
+  // stage-in: padded, zero-filled work copies.  With a staging pipeline B comes first and A is waited for only
+  // after the Cholesky factorisation has been issued (it is still crossing PCIe meanwhile).
+  EK_HIP_CHECK(hipMemsetAsync(wV, 0, (size_t)ld * ld * 8, s));
+  EK_HIP_CHECK(hipMemsetAsync(dd, 0, 4 * al((size_t)ld * 8), s));
+  double sigma = 1.0;
+  auto stage_in_B = [&]() -> int {
+    if (problem != 1) return 0;
+    if (pipe) { const int e = pipe->wait_in(0); if (e) return e; }
+    if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wB, 0, (size_t)ld * ld * 8, s));
+    copy_matrix(s, n, n, dB, ldb, wB, ld);
+    return 0;
+  };
+  auto stage_in_A = [&]() -> int {
+    if (pipe) { const int e = pipe->wait_in(1); if (e) return e; }
+    if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s));   // (the copy covers all of an unpadded array)
+    copy_matrix(s, n, n, dA, lda, wA, ld);
+    // Scale A into the safe range when its entries are extreme (as DSYEV / PDSYEV do before
+    // DSYTRD): the Householder norms are plain sums of squares.  Eigenvalues scale back linearly.
+    double *d_part = (double *)work;   // stage scratch, free until the reduction starts
+    maxabs_lower(s, n, wA, ld, d_part);
+    double part[256];
+    EK_HIP_CHECK(hipMemcpyAsync(part, d_part, sizeof(part), hipMemcpyDeviceToHost, s));
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    double anrm = 0.0;
+    for (double v : part) if (v > anrm) anrm = v;
+    if (!(anrm <= 1.7e308)) return -4;   // NaN / Inf in A: illegal value, as XERBLA
+    // the tridiagonalisation forms x^T A x of the unscaled column (|A|^3 n^2): keep cubes in range
+    const double rmin = 1e-90, rmax = 1e90;
+    if (anrm > 0.0 && anrm < rmin) sigma = rmin / anrm;
+    else if (anrm > rmax) sigma = rmax / anrm;
+    if (sigma != 1.0) scale_lower(s, n, sigma, wA, ld);
+    return 0;
+  };
+  if (!pipe) { rc = stage_in_A(); if (rc) { tm.destroy(); return rc; } }
+  rc = stage_in_B(); if (rc) { tm.destroy(); return rc; }
+  mark();                                                              // 1
+  g_comm.err = 0;
+  if (problem == 1) {
+    // right-looking sweep with one panel broadcast per strip: pays from three ranks on
+    if (dist && g_comm.nranks >= dist_min_ranks()) {
+      const PotrfMember me{wB, ld, dInv, g_ctx.d_info, pwork, g_comm.rank};
+      potrf_lower_dist(s, n, 1, &me, team_exchange(0));
+    } else if (potrf_rl) {
+      potrf_lower_rl(s, g_ctx.stream2, n, wB, ld, dInv, g_ctx.d_info, pwork);
+    } else {
+      potrf_lower(s, n, wB, ld, dInv, g_ctx.d_info, twork);
+    }
+  }
+  mark();                                                              // 2
+  if (pipe) {
+    if (problem == 1) {        // L is final: it leaves while the reduction runs
+      copy_matrix(s, n, n, wB, ld, dB, ldb);
+      pipe->push(true, dB, ldb, pipe->hB, pipe->ldhb, n, n, pipe->mark(s), 0);
+    }
+    rc = stage_in_A(); if (rc) { tm.destroy(); return rc; }
+  }
+  if (problem == 1) {
+    // sharding the two solves costs 2 n^3 / P flops per rank against 1.0 - 1.57 n^3 replicated
+    if (dist && g_comm.nranks >= dist_min_ranks()) {
+      const SygstMember me{wA, ld, wB, ld, dInv, twork, sscr, g_comm.rank};
+      sygst_lower_dist(s, n, 1, &me, team_exchange(0));
+    } else {
+      sygst_lower(s, n, wA, ld, wB, ld, dInv, twork, sscr);
+    }
+  }
+  mark();                                                              // 3
+  bool two_stage_done = false;
+  double rescued_panels = 0.0;
+  if (dist && !two_stage) {
+    const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
+    sytrd_lower_dist(s, n, 1, &me, team_exchange(0, n));
+  } else if (two_stage) {
+    // dense -> band -> tridiagonal.  The panel factorisation of the first stage is CholeskyQR2 with a
+    // device-side check; a matrix it cannot handle (rank-deficient or very ill-conditioned panels,
+    // e.g. an input that is already banded) takes the one-stage path from a copy instead.
+    EK_HIP_CHECK(hipMemcpyAsync(wA0, wA, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
+    EK_HIP_CHECK(hipMemsetAsync(wV2, 0, (size_t)ld * ld * 8, s));
+    EK_HIP_CHECK(hipMemsetAsync(dt1, 0, (size_t)ld * 8, s));
+    if (dist) {
+      // On a team the first stage is distributed over the 128-wide column strips (strip S on rank S mod P: where
+      // the distributed reduction to standard form left the matrix, so nothing is gathered in front of it): per panel
+      // one broadcast of [V | T | tau] and one all-reduce of Y (ek_sy2sb.hip).  Then ONE all-gather of the band
+      // (65 n doubles); the bulge chasing and the D&C below its top merge run replicated, bit-identical on all ranks.
+      const SytrdExchange x = team_exchange(0);
+      const Sy2sbMember me{wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb, g_comm.rank};
+      sy2sb_lower_dist(s, n, 1, &me, x);
+      double *ABs[1] = {sb2st_band(work_sb2st, n)};
+      pack_band(s, n, wA, ld, ABs[0]);
+      gather_band_strips(s, n, 1, g_comm.rank, ABs, x);
+      sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st, /*band_packed=*/true);
+    } else {
+      sy2sb_lower(s, g_ctx.stream2, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
+      sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st);
+    }
+    // (the bulge chasing does nothing when the first stage has raised its flag: the band is not valid then)
+    int flag = 0;
+    EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    EK_HIP_CHECK(hipStreamSynchronize(s));
+    rescued_panels = (double)(flag >> 8);      // panels of the first stage that took the Householder rescue
+    flag &= 0xff;                              // the low byte says why the two-stage form gave up, if it did
+    // a team decides together: a flag that only one rank has raised (an abandoned wait depends on timing, not on the
+    // data) must not leave the ranks with eigenvectors of two different decompositions
+    if (dist) { flag = comm_any(flag); if (flag < 0) return flag; }
+    if (flag == 0) two_stage_done = true;
+    else {
+      EK_HIP_CHECK(hipMemcpyAsync(wA, wA0, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
+      EK_HIP_CHECK(hipMemsetAsync(wV, 0, (size_t)ld * ld * 8, s));
+      EK_HIP_CHECK(hipMemsetAsync(dd, 0, 3 * al((size_t)ld * 8), s));
+      if (dist) {     // (the copy holds the matrix in this rank's strips only: the one-stage form over the team)
+        const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
+        sytrd_lower_dist(s, n, 1, &me, team_exchange(0, n));
+      } else {
+        sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
+      }
+    }
+  } else {
+    sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
+  }
+  if (pipe) {                  // what the call leaves in A (reflectors / band) is final
+    copy_matrix(s, n, n, wA, ld, dA, lda);
+    pipe->push(true, dA, lda, pipe->hA, pipe->ldha, n, n, pipe->mark(s), 0);
+  }
+  mark();                                                              // 4
+  // eigenvector columns wanted: the first n_vec, or this grid cell's share of them; the D&C
+  // forms only those (columns 0..nc_loc-1 of wZ) and the two remaining stages treat the
+  // columns of Z independently
+  const StedcSelect pick{nc_loc, cell ? cell->nb : (n > 0 ? n : 1), cell ? cell->npcol : 1, cell ? cell->mycol : 0};
+  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats);
+  mark();                                                              // 5
+  double *zc = wZ;
+  // with a staging pipeline the LAST stage (the recovery; the back-transformation of a standard problem) runs in column
+  // slabs, each leaving for the host while the next is computed (columns of Z are independent there)
+  const int zslab = (pipe && two_stage_done && nc_loc > pipe->z_slab) ? pipe->z_slab : nc_loc;
+  auto z_out = [&](int c0, int nc) {
+    copy_matrix(s, n, nc, wZ + (size_t)c0 * ld, ld, dZ + (size_t)c0 * ldz, ldz);
+    pipe->push(true, dZ + (size_t)c0 * ldz, ldz, pipe->hZ + (size_t)c0 * pipe->ldhz, pipe->ldhz, n, nc, pipe->mark(s), 0);
+  };
+  if (two_stage_done) {
+    sb2st_apply_q2(s, n, nc_loc, wV2, ld, zc, ld, g_ctx.d_info + 2, work_sb2st);
+    // (the T factors of the block reflectors do not depend on Z; forming them on the second stream beside the
+    // bulge chasing was measured: the skinny GEMMs take CUs and issue slots from the latency-bound pipeline,
+    // which loses 11 ms to gain 6)
+    ormtr_prepare(s, n, wV, ld, dt1, q1prep);
+    if (pipe && problem == 0 && zslab < nc_loc) {
+      for (int c0 = 0; c0 < nc_loc; c0 += zslab) {
+        const int nc = (nc_loc - c0 < zslab) ? nc_loc - c0 : zslab;
+        ormtr_apply(s, n, nc, wV, ld, q1prep, zc + (size_t)c0 * ld, ld, work, n_vec);
+        z_out(c0, nc);
+      }
+    } else {
+      ormtr_apply(s, n, nc_loc, wV, ld, q1prep, zc, ld, work, n_vec);
+    }
+  } else {
+    ormtr_lower(s, n, nc_loc, wV, ld, dt, zc, ld, work, n_vec);
+  }
+  mark();                                                              // 6
+  if (problem == 1) {
+    if (pipe) {
+      for (int c0 = 0; c0 < nc_loc; c0 += zslab) {
+        const int nc = (nc_loc - c0 < zslab) ? nc_loc - c0 : zslab;
+        trsm_llt(s, n, nc, wB, ld, dInv, zc + (size_t)c0 * ld, ld, twork);
+        z_out(c0, nc);
+      }
+    } else {
+      trsm_llt(s, n, nc_loc, wB, ld, dInv, zc, ld, twork);
+    }
+  } else if (pipe && !(two_stage_done && zslab < nc_loc)) {
+    z_out(0, nc_loc);
+  }
+  mark();                                                              // 7
+  // stage-out: eigenvalues, eigenvectors, and the in-place results the reference leaves
+  // behind (L in B, reflectors in A)
+  if (sigma != 1.0) scale_vector(s, n, 1.0 / sigma, dwv);
+  EK_HIP_CHECK(hipMemcpyAsync(dw, dwv, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+  if (!pipe) {
+    if (cell) gather_block_cyclic(s, nr_loc, nc_loc, zc, ld, cell->nb, cell->nprow, cell->myrow, 1, 0, dZ, ldz);
+    else copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
+    copy_matrix(s, n, n, wA, ld, dA, lda);
+    if (problem == 1) copy_matrix(s, n, n, wB, ld, dB, ldb);
+  }
+  mark();                                                              // 8
+  EK_HIP_CHECK(hipGetLastError());
+  int info[4] = {0, 0, 0, 0};
+  EK_HIP_CHECK(hipMemcpyAsync(info, g_ctx.d_info, sizeof(info), hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipMemcpyAsync(g_ctx.stats, g_ctx.d_stats, sizeof(g_ctx.stats), hipMemcpyDeviceToHost, s));
+  EK_HIP_CHECK(hipStreamSynchronize(s));
+  g_ctx.stats[1] = two_stage_done ? 1.0 : 0.0;
+  g_ctx.stats[2] = rescued_panels;
+  info[2] &= 0xff;
+  if (timing) {
+    float ms[8];
+    for (int i = 0; i < 8; ++i) (void)hipEventElapsedTime(&ms[i], tm.ev[i], tm.ev[i + 1]);
+    double st[EK_HIP_N_STAGES] = {0};
+    st[EK_STAGE_COPY] = (ms[0] + ms[7]) * 1e-3;
+    st[EK_STAGE_POTRF] = ms[1] * 1e-3; st[EK_STAGE_SYGST] = ms[2] * 1e-3;
+    st[EK_STAGE_SYTRD] = ms[3] * 1e-3; st[EK_STAGE_GATHER] = 0.0;
+    st[EK_STAGE_STEDC] = ms[4] * 1e-3; st[EK_STAGE_ORMTR] = ms[5] * 1e-3;
+    st[EK_STAGE_TRTRS] = ms[6] * 1e-3;
+    for (int i = 0; i < n_stages && i < EK_HIP_N_STAGES; ++i) stage_seconds[i] = st[i];
+    tm.destroy();
+  }
+  if (dist && g_comm.err) {
+    fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", comm_error_string());
+    return -996;
+  }
+  if (two_stage_done) {   // the pipelined back-transformation was abandoned (a bounded wait ran out): on a team, for all ranks
+    int bad = info[2] != 0;
+    if (dist) bad = comm_any(bad);
+    if (bad) return bad < 0 ? bad : -992;
+  }
+  if (info[0] != 0) return info[0];          // Cholesky: leading minor not positive definite
+  if (info[1] != 0) return 100000 + info[1];  // tridiagonal eigensolver did not converge
+  return 0;
+}
+
+// Replicated host inputs (full A, B on every rank) -> this cell's block-cyclic piece of Z.
+int replicated_host_locked(int problem, int n, int n_vec, double *A, int lda, double *B, int ldb, double *w,
+                           double *Z_loc, int lldz, const GridCell &cell, double *stage_seconds,
+                           int n_stages) {
+  hipStream_t s = g_ctx.stream;
+  const int nr_loc = numroc0(n, cell.nb, cell.myrow, cell.nprow);
+  const int nc_loc = numroc0(n_vec, cell.nb, cell.mycol, cell.npcol);
+  double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
+  const size_t nn = (size_t)n * n * 8;
+  const int ldzl = nr_loc > 1 ? nr_loc : 1;
+  auto t0 = std::chrono::steady_clock::now();
+  DevMem mem;
+  int rc = mem.alloc(&uA, nn);
+  if (!rc) rc = mem.alloc(&uZ, (size_t)ldzl * (nc_loc > 0 ? nc_loc : 1) * 8);
+  if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
+  if (!rc && problem == 1) rc = mem.alloc(&uB, nn);
+  if (rc) return rc;
+  rc = h2d_matrix(n, n, A, lda, uA, n, s);
+  if (!rc && problem == 1) rc = h2d_matrix(n, n, B, ldb, uB, n, s);
+  if (!rc) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc = -1000 - (int)e; }
+  auto t1 = std::chrono::steady_clock::now();
+  int info = rc;
+  if (!rc) info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, ldzl, stage_seconds, n_stages, &cell);
+  auto t2 = std::chrono::steady_clock::now();
+  if (info > -1000) {
+    int rc2 = 0;
+    if (nr_loc > 0 && nc_loc > 0) rc2 = d2h_matrix(nr_loc, nc_loc, uZ, ldzl, Z_loc, lldz, s);
+    if (!rc2) rc2 = d2h_matrix(n, n, uA, n, A, lda, s);
+    if (!rc2 && problem == 1) rc2 = d2h_matrix(n, n, uB, n, B, ldb, s);
+    if (!rc2) { hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (rc2 && info == 0) info = rc2;
+  }
+  auto t3 = std::chrono::steady_clock::now();
+  if (stage_seconds && n_stages > EK_STAGE_COPY)
+    stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() +
+                                    std::chrono::duration<double>(t3 - t2).count();
+  return info;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int ek_hip_solve_device(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
+                        double *dw, double *dZ, int ldz, double *stage_seconds, int n_stages) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_vec < 0 || n_vec > n) return -3;
+  if (n > 0 && !dA) return -4;
+  if (lda < (n > 1 ? n : 1)) return -5;
+  if (problem == 1 && n > 0 && !dB) return -6;
+  if (problem == 1 && ldb < (n > 1 ? n : 1)) return -7;
+  if (n > 0 && !dw) return -8;
+  if (n > 0 && !dZ) return -9;
+  if (ldz < (n > 1 ? n : 1)) return -10;
+  int rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return solve_device_locked(problem, n, n_vec, dA, lda, dB, ldb, dw, dZ, ldz, stage_seconds, n_stages);
+}
+
+int ek_hip_set_allgatherv(ek_hip_allgatherv_fn fn, void *user) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_allgatherv = fn; g_allgatherv_user = user;
+  return 0;
+}
+
+// Pure host code (no GPU needed): the exchange step of ek_hip_solve for distributed inputs.
+int ek_hip_gather_matrix(int m, int n, const double *M_loc, const int desc[9], int nprow, int npcol,
+                         int myrow, int mycol, double *M_full, int ldf) {
+  if (m < 0) return -1;
+  if (n < 0) return -2;
+  if (m > 0 && n > 0 && !M_loc) return -3;
+  if (nprow < 1) return -5;
+  if (npcol < 1) return -6;
+  if (myrow < 0 || myrow >= nprow) return -7;
+  if (mycol < 0 || mycol >= npcol) return -8;
+  if (!desc) return -4;
+  if (desc[4] < 1) return -405;
+  int rc = check_desc(desc, 4, m, n, numroc0(m, desc[4], myrow, nprow)); if (rc) return rc;
+  if (m > 0 && n > 0 && !M_full) return -9;
+  if (ldf < (m > 1 ? m : 1)) return -10;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_allgatherv) return -998;
+  if (m == 0 || n == 0) return 0;
+  const GridCell cell{desc[4], nprow, npcol, myrow, mycol};
+  return gather_full(m, n, M_loc, desc, cell, M_full, ldf);
+}
+
+int ek_hip_solve_device_grid(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
+                             double *dw, double *dZ_loc, int ldz_loc, int nb, int nprow, int npcol,
+                             int myrow, int mycol, double *stage_seconds, int n_stages) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_vec < 0 || n_vec > n) return -3;
+  if (n > 0 && !dA) return -4;
+  if (lda < (n > 1 ? n : 1)) return -5;
+  if (problem == 1 && n > 0 && !dB) return -6;
+  if (problem == 1 && ldb < (n > 1 ? n : 1)) return -7;
+  if (n > 0 && !dw) return -8;
+  if (n > 0 && !dZ_loc) return -9;
+  if (nb < 1) return -11;
+  if (nprow < 1) return -12;
+  if (npcol < 1) return -13;
+  if (myrow < 0 || myrow >= nprow) return -14;
+  if (mycol < 0 || mycol >= npcol) return -15;
+  const int nr_loc = numroc0(n, nb, myrow, nprow);
+  if (ldz_loc < (nr_loc > 1 ? nr_loc : 1)) return -10;
+  int rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const GridCell cell{nb, nprow, npcol, myrow, mycol};
+  return solve_device_locked(problem, n, n_vec, dA, lda, dB, ldb, dw, dZ_loc, ldz_loc, stage_seconds,
+                             n_stages, &cell);
+}
+
+int ek_hip_solve_replicated(int problem, int n, int n_vec, double *A, int lda, double *B, int ldb,
+                            double *w, double *Z_loc, const int desc_Z[9], int nprow, int npcol,
+                            int myrow, int mycol, double *stage_seconds, int n_stages) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_vec < 0 || n_vec > n) return -3;
+  if (n > 0 && !A) return -4;
+  if (lda < (n > 1 ? n : 1)) return -5;
+  if (problem == 1 && n > 0 && !B) return -6;
+  if (problem == 1 && ldb < (n > 1 ? n : 1)) return -7;
+  if (n > 0 && !w) return -8;
+  if (n > 0 && !Z_loc) return -9;
+  if (nprow < 1) return -11;
+  if (npcol < 1) return -12;
+  if (myrow < 0 || myrow >= nprow) return -13;
+  if (mycol < 0 || mycol >= npcol) return -14;
+  if (!desc_Z) return -10;
+  if (desc_Z[4] < 1) return -(10 * 100 + 5);
+  int rc = check_desc(desc_Z, 10, n, n, numroc0(n, desc_Z[4], myrow, nprow)); if (rc) return rc;
+  rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const GridCell cell{desc_Z[4], nprow, npcol, myrow, mycol};
+  return replicated_host_locked(problem, n, n_vec, A, lda, B, ldb, w, Z_loc, desc_Z[8], cell, stage_seconds,
+                                n_stages);
+}
+
+int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[9], double *B_loc,
+                 const int desc_B[9], double *w, double *Z_loc, const int desc_Z[9], int nprow,
+                 int npcol, int myrow, int mycol, double *stage_seconds, int n_stages) {
+  if (problem != 0 && problem != 1) return -1;
+  if (n < 0) return -2;
+  if (n_vec < 0 || n_vec > n) return -3;
+  if (n > 0 && !A_loc) return -4;
+  const bool cell_ok = nprow >= 1 && npcol >= 1 && myrow >= 0 && myrow < nprow;
+  auto rows_of = [&](const int *d) {   // local row count the descriptor's lld must cover
+    return (d && d[4] >= 1 && cell_ok) ? numroc0(n, d[4], myrow, nprow) : n;
+  };
+  int rc = check_desc(desc_A, 5, n, n, rows_of(desc_A)); if (rc) return rc;
+  if (problem == 1) {
+    if (n > 0 && !B_loc) return -6;
+    rc = check_desc(desc_B, 7, n, n, rows_of(desc_B)); if (rc) return rc;
+  }
+  if (n > 0 && !w) return -8;
+  if (n > 0 && !Z_loc) return -9;
+  rc = check_desc(desc_Z, 10, n, n, rows_of(desc_Z)); if (rc) return rc;
+  // grids other than 1x1 need the host's exchange hook (ek_hip_set_allgatherv)
+  const bool have_exchange = g_allgatherv || (g_comm.on && nprow > 0 && npcol > 0 && g_comm.nranks == nprow * npcol);
+  if (nprow != 1 && !(nprow > 1 && have_exchange)) return -11;
+  if (npcol != 1 && !(npcol > 1 && have_exchange)) return -12;
+  if (myrow < 0 || myrow >= nprow) return -13;
+  if (mycol < 0 || mycol >= npcol) return -14;
+  rc = ensure_init(); if (rc) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nprow * npcol > 1 && g_comm.on && g_comm.nranks == nprow * npcol) {
+    // distributed inputs with a communicator attached: only the local pieces cross PCIe; the full
+    // matrices are assembled in HBM by one all-gather per matrix (RCCL over xGMI, or the host hook
+    // of a host communicator) and the pieces of the reflectors / of L are cut out on the device
+    const GridCell cell{desc_Z[4], nprow, npcol, myrow, mycol};
+    if (g_comm.rank != myrow * npcol + mycol) return -994;
+    hipStream_t s = g_ctx.stream;
+    const int P = nprow * npcol, me = g_comm.rank;
+    const SytrdExchange x = team_exchange(0);
+    auto t0 = std::chrono::steady_clock::now();
+    DevMem mem;
+    double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr, *pk = nullptr;
+    const size_t nn = (size_t)n * n;
+    const int nrz = numroc0(n, cell.nb, myrow, nprow), ncz = numroc0(n_vec, cell.nb, mycol, npcol);
+    const int ldzl = nrz > 1 ? nrz : 1;
+    rc = mem.alloc(&uA, nn * 8);
+    if (!rc && problem == 1) rc = mem.alloc(&uB, nn * 8);
+    if (!rc) rc = mem.alloc(&pk, nn * 8);
+    if (!rc) rc = mem.alloc(&uZ, (size_t)ldzl * (ncz > 0 ? ncz : 1) * 8);
+    if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
+    rc = comm_agree(rc);                 // nobody enters the all-gathers below unless everybody can
+    if (rc) return rc;
+    g_comm.err = 0;
+    auto assemble = [&](const double *M_loc, const int *desc, double *full) -> int {
+      const int nb = desc[4];
+      size_t offs[kMaxTeam], counts[kMaxTeam];
+      size_t tot = 0;
+      for (int r = 0; r < P; ++r) {
+        counts[r] = (size_t)numroc0(n, nb, r / npcol, nprow) * numroc0(n, nb, r % npcol, npcol);
+        offs[r] = tot; tot += counts[r];
+      }
+      const int nr = numroc0(n, nb, myrow, nprow), nc = numroc0(n, nb, mycol, npcol);
+      if (nr > 0 && nc > 0) { int r2 = h2d_matrix(nr, nc, M_loc, desc[8], pk + offs[me], nr, s); if (r2) return r2; }
+      double *bufs[1] = {pk};
+      x.allgatherv(s, 1, me, bufs, offs, counts, P, x.user);
+      for (int r = 0; r < P; ++r)
+        scatter_block_cyclic(s, numroc0(n, nb, r / npcol, nprow), numroc0(n, nb, r % npcol, npcol), pk + offs[r],
+                             numroc0(n, nb, r / npcol, nprow) > 1 ? numroc0(n, nb, r / npcol, nprow) : 1, nb, nprow,
+                             r / npcol, npcol, r % npcol, full, n);
+      return 0;
+    };
+    auto tg0 = std::chrono::steady_clock::now();
+    int info = assemble(A_loc, desc_A, uA);
+    if (!info && problem == 1) info = assemble(B_loc, desc_B, uB);
+    if (!info) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) info = -1000 - (int)e; }
+    if (!info && g_comm.err) info = -996;
+    info = comm_agree(info);             // a staging failure on one rank ends the call on all of them
+    const double tg = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
+    auto t1 = std::chrono::steady_clock::now();
+    if (!info) info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, ldzl, stage_seconds, n_stages, &cell);
+    auto t2 = std::chrono::steady_clock::now();
+    if (info > -1000) {
+      int rc2 = 0;
+      if (nrz > 0 && ncz > 0) rc2 = d2h_matrix(nrz, ncz, uZ, ldzl, Z_loc, desc_Z[8], s);
+      auto cut = [&](const double *full, const int *desc, double *M_loc) -> int {
+        const int nb = desc[4], nr = numroc0(n, nb, myrow, nprow), nc = numroc0(n, nb, mycol, npcol);
+        if (nr <= 0 || nc <= 0) return 0;
+        gather_block_cyclic(s, nr, nc, full, n, nb, nprow, myrow, npcol, mycol, pk, nr);
+        return d2h_matrix(nr, nc, pk, nr, M_loc, desc[8], s);
+      };
+      if (!rc2) rc2 = cut(uA, desc_A, A_loc);
+      if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }   // pk is reused
+      if (!rc2 && problem == 1) rc2 = cut(uB, desc_B, B_loc);
+      if (!rc2) { hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+      if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+      if (rc2 && info == 0) info = rc2;
+    }
+    auto t3 = std::chrono::steady_clock::now();
+    if (stage_seconds && n_stages > EK_STAGE_COPY)
+      stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() - tg +
+                                      std::chrono::duration<double>(t3 - t2).count();
+    if (stage_seconds && n_stages > EK_STAGE_GATHER) stage_seconds[EK_STAGE_GATHER] += tg;
+    return info;
+  }
+  if (nprow * npcol > 1) {
+    // distributed inputs: assemble the full matrices on every rank through the hook, then
+    // proceed as in the replicated-input mode; A_loc / B_loc receive their pieces of the
+    // reflectors / of L, as every rank of the reference ends up with
+    const GridCell cell{desc_Z[4], nprow, npcol, myrow, mycol};
+    double *Af = (double *)malloc((size_t)n * n * 8);
+    double *Bf = problem == 1 ? (double *)malloc((size_t)n * n * 8) : nullptr;
+    int info = (!Af || (problem == 1 && !Bf)) ? -1000 - (int)hipErrorOutOfMemory : 0;
+    auto t0 = std::chrono::steady_clock::now();
+    if (!info) info = gather_full(n, n, A_loc, desc_A, cell, Af, n);
+    if (!info && problem == 1) info = gather_full(n, n, B_loc, desc_B, cell, Bf, n);
+    const double tg = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!info) {
+      info = replicated_host_locked(problem, n, n_vec, Af, n, Bf, n, w, Z_loc, desc_Z[8], cell,
+                                    stage_seconds, n_stages);
+      if (info > -1000) {
+        extract_local(n, n, Af, n, desc_A, cell, A_loc);
+        if (problem == 1) extract_local(n, n, Bf, n, desc_B, cell, B_loc);
+      }
+      if (stage_seconds && n_stages > EK_STAGE_GATHER) stage_seconds[EK_STAGE_GATHER] += tg;
+    }
+    free(Af); free(Bf);
+    return info;
+  }
+  hipStream_t s = g_ctx.stream;
+  // user-side device images (exact n x n); freed before returning: the library keeps nothing
+  double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
+  const size_t nn = (size_t)n * n * 8;
+  auto t0 = std::chrono::steady_clock::now();
+  DevMem mem;
+  rc = mem.alloc(&uA, nn);
+  if (!rc) rc = mem.alloc(&uZ, nn);
+  if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
+  if (!rc && problem == 1) rc = mem.alloc(&uB, nn);
+  if (rc) return rc;
+  int pipe_min = 2048;           // EK_HIP_PIPE_MIN: order from which the host path stages through the pipeline (0: never)
+  if (const char *e = getenv("EK_HIP_PIPE_MIN")) pipe_min = atoi(e);
+  if (pipe_min > 0 && n >= pipe_min) {
+    // staging pipeline: the copies overlap the stages (HostPipe): what remains exposed is B's way in, the rest of A's
+    // behind the Cholesky factorisation, and the last slab of Z
+    HostPipe pipe;
+    pipe.hA = A_loc; pipe.ldha = desc_A[8]; pipe.hB = B_loc; pipe.ldhb = problem == 1 ? desc_B[8] : 0;
+    pipe.hZ = Z_loc; pipe.ldhz = desc_Z[8];
+    rc = pipe.start(g_ctx.device);
+    if (rc) return rc;
+    if (problem == 1) pipe.push(false, uB, n, B_loc, desc_B[8], n, n, nullptr, 0);
+    pipe.push(false, uA, n, A_loc, desc_A[8], n, n, nullptr, 1);
+    double st[EK_HIP_N_STAGES] = {0};
+    int info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, n, st, EK_HIP_N_STAGES, nullptr, &pipe);
+    const int rcp = pipe.finish();
+    if (info == 0 && rcp) info = rcp;
+    if (info > -1000) {
+      hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess && info == 0) info = -1000 - (int)e;
+    }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stage_seconds) {
+      double dev = 0.0;
+      for (int i = 0; i < EK_HIP_N_STAGES; ++i) if (i != EK_STAGE_COPY) dev += st[i];
+      st[EK_STAGE_COPY] = wall > dev ? wall - dev : 0.0;     // what the copies add to the stages: their exposed part
+      for (int i = 0; i < n_stages && i < EK_HIP_N_STAGES; ++i) stage_seconds[i] = st[i];
+    }
+    return info;
+  }
+  rc = h2d_matrix(n, n, A_loc, desc_A[8], uA, n, s);
+  if (!rc && problem == 1) rc = h2d_matrix(n, n, B_loc, desc_B[8], uB, n, s);
+  if (!rc) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc = -1000 - (int)e; }
+  auto t1 = std::chrono::steady_clock::now();
+  int info = rc;
+  if (!rc) info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, n, stage_seconds, n_stages);
+  auto t2 = std::chrono::steady_clock::now();
+  if (info >= 0 || info > -1000) {
+    // results travel back even when info > 0 so the host can inspect them, as with ScaLAPACK
+    int rc2 = d2h_matrix(n, n_vec, uZ, n, Z_loc, desc_Z[8], s);
+    if (!rc2) rc2 = d2h_matrix(n, n, uA, n, A_loc, desc_A[8], s);
+    if (!rc2 && problem == 1) rc2 = d2h_matrix(n, n, uB, n, B_loc, desc_B[8], s);
+    if (!rc2) { hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
+    if (rc2 && info == 0) info = rc2;
+  }
+  auto t3 = std::chrono::steady_clock::now();
+  if (stage_seconds && n_stages > EK_STAGE_COPY)
+    stage_seconds[EK_STAGE_COPY] += std::chrono::duration<double>(t1 - t0).count() +
+                                    std::chrono::duration<double>(t3 - t2).count();
+  return info;
+}
+
+
+}  // extern "C"

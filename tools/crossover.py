@@ -1,5 +1,5 @@
 """One-stage against two-stage tridiagonalisation through the whole-path call, standard problem, a few orders:
-the measurement behind the default of EK_HIP_TWO_STAGE_MIN (ek_api.hip two_stage_min)."""
+the measurement behind the default of EK_HIP_TWO_STAGE_MIN (ek_comm.hip two_stage_min)."""
 import ctypes, sys, time, numpy as np
 sys.path.insert(0, '.')
 from eigenkernel_amd import solver
