@@ -29,15 +29,21 @@ the ranks there are).
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline"        : the dominant kernel, timed live with HIP events on its launch stream in the
                       timed region: with the two-stage tridiagonalisation (orders >= 512) the
-                      MFMA-bound application of the bulge-chasing reflectors (q2_apply_kernel),
-                      else the HBM-bound symv of the one-stage reduction;
+                      MFMA-bound application of the bulge-chasing reflectors (q2_apply_nb_kernel<3>),
+                      else the HBM-bound symv of the one-stage reduction; "traffic" from the committed PMC
+                      record only while the kernel's source file is the one it was measured with;
   "roofline_stages" : per stage of the path, algorithmic flops / device seconds
-                      against the fp64 matrix peak;
+                      against the fp64 matrix peak, and the flops the path executed where that differs
+                      (divide & conquer after deflation, counted on the device; both back-transformations);
   "value_incl_copies": the same solve through ek_hip_solve on HOST arrays (PCIe staging of A, B in
-                      and Z, A, B, w out included; SURVEY.md 8(d)), one step, outside the timed region;
+                      and Z, A, B, w out included -- SURVEY.md 8(d)'s t_solve; the copies overlap the stages),
+                      one step, outside the timed region;
+  "other_configs"   : the other BASELINE configurations at full size on this GPU (c2 x10, c5 x5, c4 x2 steps:
+                      ms_per_step, parity, the dominant kernel's fraction), after the headline region;
   "cpu_baseline"    : the reference's ScaLAPACK call sequence on the host cores on a bounded sample
                       (smaller N) of the same generator, rank 0 at N=1 only, with the GPU path timed
                       at that SAME order beside it ("gpu_same_order").
+Every extra runs after the headline exists and is caught on its own: none of them can take the line down.
 """
 import argparse
 import numpy as np
@@ -715,8 +721,8 @@ def main():
             ach = fl / dur / 1e12
             traffic, tsrc = q2_traffic_record(n, k)
             out["roofline"] = {
-                "kernel": "q2_apply_kernel (Z <- Q2 Z: reflectors of the band->tridiagonal stage, compact-WY blocks of 32 "
-                          "sweeps applied two blocks per pass, window of Z resident in MFMA accumulator registers)",
+                "kernel": "q2_apply_nb_kernel<3> (Z <- Q2 Z: reflectors of the band->tridiagonal stage, compact-WY blocks of 32 "
+                          "sweeps applied three blocks per pass, window of Z resident in MFMA accumulator registers)",
                 "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                 "launches": int(kp_l[0]), "avg_launch_us": 1e6 * dur, "algorithmic_flops_per_launch": fl,

@@ -450,3 +450,28 @@ def test_fortran_mpi_host_argument_contract(tmp_path):
     bad = subprocess.run([mpiexec, "-np", "2", exe, "-s", "hip", "-n", "5", "--synthetic", "64"], cwd=tmp_path,
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "-n is only legal" in bad.stderr
+
+
+def test_bench_reports_no_traffic_from_a_stale_pmc_record(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a committed rocprofv3 PMC record that carries the sha256 of the kernel's
+    source file: a record measured with another ek_sb2st.hip (or for another shape) must not be reported."""
+    import hashlib
+    import importlib
+    import json
+    bench = importlib.import_module("bench")
+    root = tmp_path
+    (root / "profiles").mkdir()
+    (root / "eigenkernel_amd" / "csrc").mkdir(parents=True)
+    src = root / "eigenkernel_amd" / "csrc" / "ek_sb2st.hip"
+    src.write_text("// kernel source, version 1\n")
+    sha = hashlib.sha256(src.read_bytes()).hexdigest()
+    rec = {"n": 16384, "ncols": 16384, "hbm_bytes_per_launch": 1.0e12, "source_sha256": sha, "git": "abc1234"}
+    (root / "profiles" / "r03_q2_apply_traffic.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    t, why = bench.q2_traffic_record(16384, 16384)
+    assert t == 1.0e12 and "abc1234" in why
+    t, why = bench.q2_traffic_record(4096, 4096)
+    assert t is None and "another shape" in why
+    src.write_text("// kernel source, version 2\n")
+    t, why = bench.q2_traffic_record(16384, 16384)
+    assert t is None and "stale" in why
