@@ -1089,6 +1089,9 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
 // fetch, the two LDS transposes and the store of a chunk are shared by NBLK groups instead of two.  Same groups, same
 // order on every element as in q2_apply_kernel: the same bits.  NBLK = 3: 10 tiles = 80 registers of window; four do
 // not fit beside the record prefetch.
+#ifndef Q2_PF
+#define Q2_PF 2
+#endif
 template <int NBLK>
 __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
   constexpr int WT = 2 * NBLK + 4;                        // row tiles of the window
@@ -1196,28 +1199,52 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
       }
       wave_sync();
     };
-    // one group on window tiles OFF .. OFF + 5
+    // one group on window tiles OFF .. OFF + 5.  The operands of the matrix instructions come from LDS one to two
+    // steps AHEAD of their use (PF): left to itself the compiler reads an operand pair, waits for it, and issues the two
+    // instructions that need it -- an LDS round trip every 128 cycles of the matrix pipe.  In the second product the
+    // accumulation chains of two tiles alternate (a chain on one accumulator issues only every other slot).
     auto apply_group = [&](auto off_c) {
       constexpr int OFF = decltype(off_c)::value;
+      constexpr int PF = Q2_PF;                            // steps of look-ahead
       double4_t w1[2];
       w1[0] = (double4_t){0.0, 0.0, 0.0, 0.0}; w1[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      {
+        double pa[PF + 1][2];
+        auto ld1 = [&](int sidx, int slot) {
+          const double *vrow = sV + (16 * (sidx >> 2) + 4 * (sidx & 3) + l4) * QVLD + l15;
+          pa[slot][0] = vrow[0]; pa[slot][1] = vrow[16];
+        };
 #pragma unroll
-      for (int tile = 0; tile < 6; ++tile)
+        for (int q = 0; q < PF; ++q) ld1(q, q);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int sidx = 0; sidx < 24; ++sidx) {
+          if (sidx + PF < 24) ld1(sidx + PF, (sidx + PF) % (PF + 1));
+          const int tile = sidx >> 2, r = sidx & 3;
           const double y = w[tile + OFF][r];
-          const double *vrow = sV + (16 * tile + 4 * r + l4) * QVLD + l15;
-          if (tile < 5) w1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[0], y, w1[0], 0, 0, 0);
-          if (tile > 0) w1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[16], y, w1[1], 0, 0, 0);
+          if (tile < 5) w1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[sidx % (PF + 1)][0], y, w1[0], 0, 0, 0);
+          if (tile > 0) w1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[sidx % (PF + 1)][1], y, w1[1], 0, 0, 0);
         }
+      }
+      {
+        // tiles in pairs (0,1), (2,3), (4,5): step q of a pair = k-step kk = 4 (q / 2) of tile 2 pr + (q & 1); tile 5 has
+        // only the k-steps 16.. (rows 80.. of V T: columns 16.. only), its first four slots are skipped
+        double px[PF + 1];
+        auto seq_tile = [](int q) { return 2 * (q >> 4) + (q & 1); };
+        auto seq_kk = [](int q) { return 4 * ((q & 15) >> 1); };
+        auto seq_ok = [&](int q) { return !(seq_tile(q) == 5 && seq_kk(q) < 16); };
+        auto ld2 = [&](int q, int slot) {
+          if (seq_ok(q)) px[slot] = sVT[(16 * seq_tile(q) + l15) * QVLD + l4 + seq_kk(q)];
+        };
 #pragma unroll
-      for (int tile = 0; tile < 6; ++tile) {
-        double4_t acc = w[tile + OFF];
-        const double *xrow = sVT + (16 * tile + l15) * QVLD + l4;
+        for (int q = 0; q < PF; ++q) ld2(q, q);
 #pragma unroll
-        for (int kk = (tile == 5 ? 16 : 0); kk < QG; kk += 4)      // rows 80.. of V T: columns 16.. only
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xrow[kk], w1[kk >> 4][(kk & 15) >> 2], acc, 0, 0, 0);
-        w[tile + OFF] = acc;
+        for (int q = 0; q < 48; ++q) {
+          if (q + PF < 48) ld2(q + PF, (q + PF) % (PF + 1));
+          if (seq_ok(q)) {
+            const int tile = seq_tile(q), kk = seq_kk(q);
+            w[tile + OFF] = __builtin_amdgcn_mfma_f64_16x16x4f64(px[q % (PF + 1)], w1[kk >> 4][(kk & 15) >> 2], w[tile + OFF], 0, 0, 0);
+          }
+        }
       }
     };
     // the groups in the order they are applied: step k ascending, inside a step the blocks descending
