@@ -31,6 +31,38 @@ for P in teams:
         assert lib.ek_hip_debug_sy2sb_team_timing(n, P, 1, ctypes.byref(sec)) == 0
         assert lib.ek_hip_debug_sy2sb_team_timing(n, P, 2, ctypes.byref(sec)) == 0
         print("n=%d team of %d rehearsed: dense->band %.4f s total, %.4f s per rank" % (n, P, sec.value, sec.value / P), flush=True)
+# what a rank of a 1 x P team computes per solve (generalized problem, full spectrum), stage by stage: the distributed
+# stages rehearsed above / below (seconds / P), the replicated bulge chasing, and the column-sharded stages measured by
+# playing one grid cell of the replicated-input mode (ek_hip_solve_device_grid: no exchange, so a cell's stage times do
+# not depend on the others).  The wire (two exchanges per panel, the all-gathers) is NOT in it.
+def dmalloc(nbytes):
+    ptr = ctypes.c_void_p()
+    assert lib.ek_hip_malloc(ctypes.byref(ptr), int(nbytes)) == 0
+    return ptr
+
+
+dA, dB, dw = dmalloc(n * n * 8), dmalloc(n * n * 8), dmalloc(n * 8)
+red = (ctypes.c_double * 2)()
+stage = (ctypes.c_double * 8)()
+for P in teams:
+    if P < 2:
+        continue
+    assert lib.ek_hip_debug_reduce_team(n, P, 1, red) == 0
+    assert lib.ek_hip_debug_reduce_team(n, P, 2, red) == 0
+    assert lib.ek_hip_debug_sy2sb_team_timing(n, P, 2, ctypes.byref(sec)) == 0
+    ncl = (n + P - 1) // P
+    dZ = dmalloc((ncl + 64) * n * 8)
+    for rep in range(2):
+        assert lib.ek_hip_synth_matrix_device(n, 1, dA, n) == 0
+        assert lib.ek_hip_synth_matrix_device(n, 2, dB, n) == 0
+        rc = lib.ek_hip_solve_device_grid(1, n, n, dA, n, dB, n, dw, dZ, n, 64, 1, P, 0, 0, stage, 8)
+        assert rc == 0, rc
+    parts = {"potrf (team)": red[0] / P, "sygst (team)": red[1] / P, "dense->band (team)": sec.value / P,
+             "band->tridiagonal (replicated)": ts[1], "stedc (top merge on own columns)": stage[4],
+             "Q2 + Q1 (own columns)": stage[5], "recovery (own columns)": stage[6]}
+    print("n=%d P=%d per-rank compute: %.3f s = %s" % (n, P, sum(parts.values()),
+          ", ".join("%s %.3f" % kv for kv in parts.items())), flush=True)
+    lib.ek_hip_free(dZ)
 if os.environ.get("EK_TEAM_TWO_STAGE_ONLY"):
     sys.exit(0)
 assert lib.ek_hip_debug_sytrd(n, 0, 1, ctypes.byref(sec)) == 0
