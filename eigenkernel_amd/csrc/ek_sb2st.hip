@@ -497,6 +497,7 @@ struct PosArgs {
   int per;               // 0: workgroup b holds position b; > 0: position (b & 7) * per + (b >> 3), neighbours mostly on one XCD
   unsigned census_spins;
   const int *skip;       // device: non-zero = the band is not valid (the first stage raised its flag): do nothing
+  unsigned jitter;       // test aid (EK_SB2ST_JITTER): pseudo-random pauses of single positions, to shake the timing
 };
 
 template <int CTRL>
@@ -584,6 +585,10 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
     const bool lead = s > 0 && k + 1 < Kprev;              // position k+1 had a task in sweep s-1: its late numbers come by mail
     // every store of the previous task (mail, emptied lines) has completed before this task sends anything
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.jitter) {                                        // (uniform per workgroup and sweep)
+      const unsigned h = ((unsigned)s * 2654435761u) ^ ((unsigned)k * 40503u * p.jitter);
+      if (((h >> 9) & 15u) == 0u) for (unsigned q = 0; q < ((h >> 3) & 63u); ++q) __builtin_amdgcn_s_sleep(64);
+    }
     // ---- the reflector of this task: position 0 makes it from its own column, the others receive it
     if (wave == 0) {
       if (k == 0) {
@@ -1426,7 +1431,8 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
       if (const char *ev = getenv("EK_SB2ST_XCDMAP")) { if (atoi(ev) != 0) per = ceil_div(K0, 8); }
       unsigned census = 1u << 16;                            // x ~0.3 us: what a workgroup waits for the others to arrive
       if (const char *ev = getenv("EK_SB2ST_CENSUS_SPINS")) census = (unsigned)atoi(ev);
-      PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * PMAILW, retired, ctl, per, census, d_flag};
+      PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * PMAILW, retired, ctl, per, census, d_flag,
+                getenv("EK_SB2ST_JITTER") ? (unsigned)atoi(getenv("EK_SB2ST_JITTER")) : 0u};
       hipLaunchKernelGGL(chase_pos_kernel, dim3(per > 0 ? per * 8 : K0), dim3(512), 0, s, a);
       hipLaunchKernelGGL(repack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, AB0, AB, ctl);
     }

@@ -198,6 +198,23 @@ def test_q2_application_does_not_depend_on_the_blocks_of_sweeps_per_pass(hip, n,
         assert np.linalg.norm(Q2.T @ Q2 - np.eye(n)) <= 64 * n * EPS
 
 
+@pytest.mark.parametrize("n", [777, 2100])
+def test_position_kernel_under_shaken_timing(hip, n):
+    """Pseudo-random pauses of single positions (EK_SB2ST_JITTER) change which neighbour waits for which: a mail line
+    read too early, emptied too late or overwritten before it was taken would change d, e or the reflectors."""
+    Bd = _random_band(n, 5 * n + 1)
+    Z0 = np.eye(n)[:, ::max(n // 16, 1)][:, :16].copy()
+    d0, e0, Z0r, f0 = hip.sb2st(Bd, Z0)
+    try:
+        for jit in ("1", "7", "12345"):
+            os.environ["EK_SB2ST_JITTER"] = jit
+            d1, e1, Z1, f1 = hip.sb2st(Bd, Z0)
+            assert f1 == 0 and np.array_equal(d0, d1) and np.array_equal(e0, e1) and np.array_equal(Z0r, Z1)
+    finally:
+        os.environ.pop("EK_SB2ST_JITTER", None)
+    assert f0 == 0
+
+
 def test_position_kernel_falls_back_when_its_workgroups_cannot_all_be_resident(hip):
     """The position-owned kernel needs every workgroup on the chip at once; its census gives up after a bounded
     wait and the sweep kernel behind it redoes the stage from the repacked band (same bits).  A census of zero

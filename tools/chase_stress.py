@@ -52,6 +52,16 @@ for n in [int(a) for a in sys.argv[1:]] or [130, 777, 1500, 3001, 6000]:
         same = all(np.array_equal(a, b) for a, b in zip(ref, r))
         print("n=%5d workgroups=%-4s identical: %s" % (n, wgs or "auto", same), flush=True)
         ok &= same
+    # the position-owned kernel (the default) under shaken timing: pseudo-random pauses of single positions
+    os.environ.pop("EK_SB2ST_WGS", None)
+    for jit in (0, 1, 7, 12345, 0):
+        if jit: os.environ["EK_SB2ST_JITTER"] = str(jit)
+        else: os.environ.pop("EK_SB2ST_JITTER", None)
+        r = sb2st(Bd, 16)
+        same = all(np.array_equal(a, b) for a, b in zip(ref, r))
+        print("n=%5d positions in registers, jitter=%-6s identical to the sweep kernel: %s" % (n, jit or "off", same), flush=True)
+        ok &= same
+    os.environ.pop("EK_SB2ST_JITTER", None)
 os.environ.pop("EK_SB2ST_WGS", None)
 print("STRESS OK" if ok else "STRESS FAILED", flush=True)
 sys.exit(0 if ok else 1)
