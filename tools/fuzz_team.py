@@ -3,8 +3,8 @@
 
   python tools/fuzz_team.py [cases] [seed]
 
-Random orders (2..1600, biased to strip boundaries) and team sizes (1..16): PDSYTRD, PDPOTRF and
-PDSYGST on a 1 x P grid against the single-GPU stages; every rank of a team must end with the same
+Random orders (2..1600, biased to strip boundaries) and team sizes (1..16): PDSYTRD, PDPOTRF,
+PDSYGST and the dense -> band stage on a 1 x P grid against the single-GPU stages; every rank of a team must end with the same
 bits.  Prints one line per failure and a summary.
 """
 import os
@@ -56,6 +56,17 @@ for c in range(cases):
         msgs.append("sygst info %d/%d" % (info, info1))
     elif not np.abs(C[il] - C1[il]).max() <= 64 * n * EPS * np.abs(C1[il]).max():
         msgs.append("sygst diff %.2e" % np.abs(C[il] - C1[il]).max())
+    if n >= 3:     # the team form of the dense -> band stage: members identical, spectrum of the band = spectrum of A
+        Ab, V, tau1s, flag, mm = hip.sy2sb_team(A, P)
+        if flag & 0xff or mm:
+            msgs.append("sy2sb_team flag %d mismatch %d" % (flag, mm))
+        else:
+            Lb = np.tril(Ab) - np.tril(Ab, -65)
+            Bd = Lb + np.tril(Lb, -1).T
+            w0 = np.linalg.eigvalsh(A)
+            err = np.abs(w0 - np.linalg.eigvalsh(Bd)).max()
+            if not err <= 8 * n * EPS * np.abs(w0).max() or np.abs(np.tril(Ab, -65)).max() != 0.0:
+                msgs.append("sy2sb_team spectrum %.2e" % err)
     if msgs:
         bad += 1
         print("FAIL n=%d P=%d: %s" % (n, P, "; ".join(msgs)), flush=True)
