@@ -13,11 +13,12 @@ timed region, because the solve overwrites A and B as the reference does).
 For N > 1 the driver launches one rank per GPU with torch.distributed.run.  By default
 (`--distribution auto`) the ranks first solve one problem each (replicas: no data-path collective;
 the safe measurement, kept in the line as "replicas"), then ONE problem on the 1 x N process grid
-with the library's RCCL communicator attached -- Cholesky factor, reduction and tridiagonalisation
-distributed over the ranks (one exchange per Householder column), eigenvector stages sharded by
-columns -- once with the per-column exchange as an ncclAllReduce and once with peer windows, each to
-the full contract (W warm-up solves, exactly K solves between barriers, max over ranks, parity
-checked on every rank).  The faster distributed mode that passed becomes the headline
+with the library's RCCL communicator attached -- Cholesky factor, reduction and the dense -> band stage of
+the tridiagonalisation distributed over the ranks (per panel one broadcast and one all-reduce), band ->
+tridiagonal replicated, eigenvector stages sharded by columns -- to the full contract (W warm-up solves,
+exactly K solves between barriers, max over ranks, parity checked on every rank; `--grid-probe-modes all`
+adds the older one-stage PDSYTRD with its per-column exchange as an ncclAllReduce and through peer
+windows).  The (fastest) distributed mode that passed becomes the headline
 ("scaling": "strong", value = n_vec * K / time: the eigenpairs of the one problem all ranks worked
 on); if neither passes (or an exchange hangs: a watchdog abandons it) the replicas line is the
 headline ("scaling": "weak").  `--distribution replicas | columns | grid` force one mode.
@@ -314,9 +315,10 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
     """ONE problem on the 1 x world grid with the library's communicator attached (Cholesky factor and
     reduction from three ranks on, tridiagonalisation always: distributed; eigenvector stages
     column-sharded), measured to the same contract as the headline (W warm-up solves, then exactly K
-    solves between barriers, max over ranks) once per exchange mode:
-      "collective"   : one ncclAllReduce per Householder column,
-      "peer_windows" : contributions stored straight into the peers' HBM, one command-processor wait.
+    solves between barriers, max over ranks) in the library's one distributed form ("two_stage": dense -> band over the
+    team, per panel one broadcast and one all-reduce) and, with --grid-probe-modes all, also in the older one-stage forms
+      "one_stage_collective"   : one ncclAllReduce per Householder column,
+      "one_stage_peer_windows" : contributions stored straight into the peers' HBM, one command-processor wait.
     Runs after the replicas region; a watchdog abandons it (os._exit after printing the line that
     exists by then) if an exchange never returns: a pool box has a single GPU, so this path could
     only be rehearsed there (team rehearsal, RCCL with one rank, processes sharing the GPU)."""
@@ -511,8 +513,8 @@ def main():
                          "'replicas' = one independent problem per rank (weak scaling) as the headline; "
                          "'columns' = ONE problem on a 1 x N process grid in replicated-input mode "
                          "(ek_hip_solve_device_grid: reduction replicated, eigenvector columns sharded; strong scaling); "
-                         "'grid' = the same with the library's RCCL communicator attached: the tridiagonalisation is "
-                         "distributed over the N ranks as well (one all-reduce per Householder column over xGMI)")
+                         "'grid' = the same with the library's RCCL communicator attached: the dense -> band stage of the "
+                         "tridiagonalisation is distributed over the N ranks as well (per panel one broadcast and one all-reduce)")
     ap.add_argument("--virtual-grid", type=int, default=0,
                     help="with --distribution columns on ONE GPU: play rank --virtual-rank of a 1 x P grid "
                          "(the mode has no collective, so a rank's time does not depend on the others)")

@@ -153,9 +153,12 @@ int ek_hip_solve_device_grid(int problem, int n, int n_vec,
  * (MPI_Bcast in a Fortran/MPI host, torch.distributed in the tests) and every rank calls
  * ek_hip_comm_init with its rank in row-major grid order (myrow*npcol + mycol, processes.f90:23).
  * While a communicator is attached, ek_hip_solve_device_grid / ek_hip_solve_replicated /
- * ek_hip_solve on a grid of exactly that many ranks distribute PDSYTRD over the ranks (1 x P
- * column-block-cyclic, 128-wide blocks, one ncclAllReduce of <= 2n+1 doubles per Householder
- * column issued on the library's stream) on top of the column sharding of the eigenvector stages.
+ * ek_hip_solve on a grid of exactly that many ranks distribute PDSYTRD over the ranks as a 1 x P team of
+ * 128-wide column strips (strip S on rank S mod P, whatever the shape of the caller's grid) on top of the
+ * column sharding of the eigenvector stages: from order 512 on the dense -> band stage with one broadcast of
+ * a panel's reflectors and one ncclAllReduce of A22 V per panel of 64 columns (the band -> tridiagonal stage
+ * then runs replicated after one all-gather of the band); below, the one-stage form with one ncclAllReduce of
+ * <= 2n+1 doubles per Householder column.  All exchanges are issued on the library's stream.
  * With a communicator attached ek_hip_solve also takes the reference's own data contract (block-
  * cyclic pieces of A and B in; pieces of Z, of the reflectors and of L out) on that grid WITHOUT the
  * host hook: only the local pieces cross PCIe, the full matrices are assembled in HBM by one
