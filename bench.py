@@ -30,7 +30,7 @@ the ranks there are).
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline"        : the dominant kernel, timed live with HIP events on its launch stream in the
                       timed region: with the two-stage tridiagonalisation (orders >= 512) the
-                      MFMA-bound application of the bulge-chasing reflectors (q2_apply_nb_kernel<3>),
+                      MFMA-bound application of the bulge-chasing reflectors (q2_apply_nb_kernel<4>),
                       else the HBM-bound symv of the one-stage reduction; "traffic" from the committed PMC
                       record only while the kernel's source file is the one it was measured with;
   "roofline_stages" : per stage of the path, algorithmic flops / device seconds
@@ -201,7 +201,7 @@ def host_path_step(lib, solver, problem, n, n_vec):
 def run_other_config(lib, torch, dev, name, steps, warmup):
     """One more BASELINE configuration on this GPU after the headline region: `steps` timed solves (each between
     synchronisations, inputs regenerated outside the timed part), parity of the last output through the reference's
-    acceptance quantities, and the fraction of the fp64 matrix peak its largest kernel (q2_apply_kernel) reached."""
+    acceptance quantities, and the fraction of the fp64 matrix peak its largest kernel (q2_apply_nb_kernel) reached."""
     n, prob, nv = CONFIGS[name]
     problem = 1 if prob == "gep" else 0
     n_vec = nv if 0 < nv < n else n
@@ -249,7 +249,7 @@ def run_other_config(lib, torch, dev, name, steps, warmup):
     if kp_l[0] > 0 and kp_s[0] > 0:
         dur = kp_s[0] / kp_l[0]
         fl = 2.0 * n * n * n_vec
-        res["dominant_kernel"] = {"kernel": "q2_apply_kernel", "avg_launch_us": 1e6 * dur, "achieved": fl / dur / 1e12,
+        res["dominant_kernel"] = {"kernel": "q2_apply_nb_kernel", "avg_launch_us": 1e6 * dur, "achieved": fl / dur / 1e12,
                                   "unit": "TFLOP/s", "frac": fl / dur / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                                   "chase_avg_launch_us": 1e6 * kp_s[1] / max(kp_l[1], 1)}
     w = dw.cpu().numpy()
@@ -268,7 +268,7 @@ def run_other_config(lib, torch, dev, name, steps, warmup):
 
 
 def q2_traffic_record(n, ncols):
-    """HBM bytes per q2_apply_kernel launch from the committed PMC measurement -- only while the kernel's source is
+    """HBM bytes per q2_apply_nb_kernel launch from the committed PMC measurement -- only while the kernel's source is
     the file the measurement was taken from (the record carries its sha256); a stale record is not reported."""
     import hashlib
     tpath = os.path.join(ROOT, "profiles", "r03_q2_apply_traffic.json")
@@ -723,8 +723,9 @@ def main():
             ach = fl / dur / 1e12
             traffic, tsrc = q2_traffic_record(n, k)
             out["roofline"] = {
-                "kernel": "q2_apply_nb_kernel<3> (Z <- Q2 Z: reflectors of the band->tridiagonal stage, compact-WY blocks of 32 "
-                          "sweeps applied three blocks per pass, window of Z resident in MFMA accumulator registers)",
+                "kernel": "q2_apply_nb_kernel<%d> (Z <- Q2 Z: reflectors of the band->tridiagonal stage, compact-WY blocks of 32 "
+                          "sweeps applied %s blocks per pass, window of Z resident in MFMA accumulator registers)"
+                          % ((4, "four") if n >= 8192 else (3, "three")),
                 "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                 "launches": int(kp_l[0]), "avg_launch_us": 1e6 * dur, "algorithmic_flops_per_launch": fl,

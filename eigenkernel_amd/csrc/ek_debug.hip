@@ -362,7 +362,7 @@ int ek_hip_debug_sb2st(int n, const double *A, int lda, double *d, double *e, do
 int ek_hip_debug_set_two_stage(int min_order) { g_two_stage_min = min_order; return 0; }   // -1: default
 
 // HIP-event brackets around the kernels of the two-stage path bench.py reports a roofline for
-// (0 q2_apply_kernel, 1 chase_kernel, 2 symm_lower_kernel of every 8th panel); _get after the solves.
+// (0 q2_apply_nb_kernel, 1 chase kernel, 2 symm_lower_kernel of every 8th panel); _get after the solves.
 int ek_hip_profile_kernels(int enable) {
   int rc = ensure_init(); if (rc) return rc;
   std::lock_guard<std::mutex> lk(g_mu);

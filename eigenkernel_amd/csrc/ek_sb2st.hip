@@ -748,7 +748,8 @@ __global__ void repack_band_kernel(int n, const double *__restrict__ AB0, double
 constexpr int QG = 32;                 // sweeps per compact-WY block
 constexpr int QR = QG + SB;            // rows of a block's window (95 used, 96 with padding)
 constexpr int QVLD = QG + 1;           // LDS leading dimension of the V image (row-major)
-constexpr int QREC = 2 * QR * QVLD;    // doubles per group record: the LDS images of V and of -(V T) (96 x 33, row-major)
+constexpr int QREC = 2 * QR * QG;      // doubles per group record: V and -(V T), 96 x 32 row-major each (the LDS images
+                                       // have the leading dimension QVLD: the padding is added on the way in)
 
 struct Q2Geom {
   int n, nsweeps, nS, kmax;            // kmax: groups of block 0 (the most any block has)
@@ -791,9 +792,8 @@ __global__ __launch_bounds__(256) void q2_tfactor_kernel(Q2Geom g, const double 
     const int rr = idx % QR, i = idx / QR;
     const double v = q2_v_entry(g, V2, ldv2, S, k, rr, i);
     sV[rr * QVLD + i] = v;
-    rec[rr * QVLD + i] = v;
+    rec[rr * QG + i] = v;
   }
-  for (int rr = t; rr < QR; rr += 256) { rec[rr * QVLD + QG] = 0.0; rec[QR * QVLD + rr * QVLD + QG] = 0.0; }   // padding column
   for (int idx = t; idx < QG * QVLD; idx += 256) sT[idx] = 0.0;
   if (t < QG) {
     const int s = q2_first_sweep(S) + t;
@@ -842,31 +842,34 @@ __global__ __launch_bounds__(256) void q2_tfactor_kernel(Q2Geom g, const double 
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rec[QR * QVLD + (16 * ti + l4 + 4 * r) * QVLD + 16 * tj + l15] = -acc[r];
+    for (int r = 0; r < 4; ++r) rec[QR * QG + (16 * ti + l4 + 4 * r) * QG + 16 * tj + l15] = -acc[r];
   }
 }
 
 // ------------------------------------------------------------------------ Q2: application
-// Z <- Q2 Z as a two-dimensional pipeline of PASSES (pair of blocks of sweeps, slab): a pass applies the
-// blocks of sweeps S+1 and S (S even) to one slab of 64 columns, walking down the rows in chunks of 64
-// starting at row 32 S.  In step k the window [chunk k | chunk k+1] (128 rows) sits in registers; group
-// (S+1, k) acts on its rows 32 .. 127, then group (S, k) on its rows 0 .. 95, after which chunk k is
-// final for both blocks and leaves.  Z is streamed once per PAIR of blocks: the stream of Z, not the
-// arithmetic, is what bounds this kernel (HBM traffic n^3/8 bytes instead of n^3/4 for all columns).
-// The pass of the pair above works 64 rows further down, so its chunk j-1 is our chunk j: passes of one
-// slab follow each other a few chunks apart, few columns (the *_select arms) still fill the chip, and many
-// columns run two passes per CU (two waves per SIMD is what the fp64 matrix pipe needs,
-// profiles/r02_mfma_peak.txt).  Persistent workgroups take passes from a ticket counter in dependency
-// order (S descending), so a workgroup only waits for passes whose
-// owners are running; a finished chunk is handed over through memory with agent-scope (sc1) stores,
-// a drain, a barrier and one progress word per pass, like the sweeps of chase_kernel.
+// Z <- Q2 Z as a two-dimensional pipeline of PASSES (bundle of NBLK blocks of sweeps, slab): a pass applies the
+// blocks of sweeps S + NBLK - 1, ..., S (S = NBLK q) to one slab of 64 columns, walking down the rows in chunks of
+// 64 starting at row 32 S.  In step k a window of 2 NBLK + 4 row tiles (16 rows each) sits in registers; block b of
+// the bundle acts on window rows 32 b .. 32 b + 95: the groups (S + NBLK - 1, k), ..., (S, k) in that order, after
+// which the first 64 rows of the window are final for the whole bundle and leave, and 64 new rows come in.  Z is
+// streamed once per BUNDLE (n^3 / (8 NBLK) bytes each way for all columns; one block per pass was bound by that
+// stream), and the fetch, the two LDS transposes and the store of a chunk are shared by NBLK groups.  The pass of the
+// bundle above starts 32 NBLK rows further down, so the rows a step takes in are that pass's chunk k + 1: passes of
+// one slab follow each other a few chunks apart, few columns (the *_select arms) still fill the chip, and many columns
+// run two passes per CU (two waves per SIMD is what the fp64 matrix pipe needs, profiles/r02_mfma_peak.txt).
+// Persistent workgroups take passes from a ticket counter in dependency order (bundles descending), so a workgroup
+// only waits for passes whose owners are running; a finished chunk is handed over through memory with agent-scope
+// (sc1) stores, a drain, a barrier and one progress word per pass, like the sweeps of chase_kernel.
 //
 // Inside a pass every wave streams its own 16 columns and keeps its window of Z in REGISTERS: the
 // accumulator layout of v_mfma_f64_16x16x4 (D(i,j) in lane (j = lane & 15, i = lane / 16 + 4 reg)) is
 // also the layout of its second operand for the k-step over rows 4 reg .. 4 reg + 3, so the same
 // registers serve as the operand of W1 = V^T Zw and as the accumulator of Zw += (-V T) W1, and W1
 // goes from the first product into the second without leaving the registers.  Only the factors
-// [V | -V T] of a group pass through LDS.
+// [V | -V T] of a group pass through LDS.  The order of the groups on any element of Z is the same for every NBLK,
+// so 2, 3 and 4 blocks per pass give the same bits (and the same as round 2's pair kernel: tools/q2_anchor.py).
+// Registers: window 8 (2 NBLK + 4), record halves in flight 48, chunk in flight 32, W1 16: 234 of 256 at NBLK = 3,
+// 256 (one spilled) at 4.
 constexpr int QNC = 64;
 constexpr int QSTLD = 34;              // per-wave transposing buffer: 16 columns x 32 rows (+2), column-major
 constexpr int QOPSZ = 2 * QR * QVLD;   // doubles of the operand buffer: V image, then -V T image (row-major, QVLD)
@@ -876,8 +879,8 @@ struct Q2ApplyArgs {
   Q2Geom g;
   const double *Rec;
   double *Z; int ldz; int ncols;
-  int nslab, npass, npair;   // npair = ceil(nS / 2) pairs of blocks of sweeps (2 q, 2 q + 1); pair q = 0 is the lowest
-  unsigned *prog;        // [npass] chunks stored by pass (pair, slab) at index (npair-1-pair) * nslab + slab
+  int nslab, npass, npair;   // npair = ceil(nS / NBLK) bundles of blocks of sweeps (NBLK q ..); bundle q = 0 is the lowest
+  unsigned *prog;        // [npass] chunks stored by pass (bundle, slab) at index (npair-1-bundle) * nslab + slab
   unsigned *ctl;         // [2] ticket, [1] abort (shared with the chase)
   int extra;             // chunks a pass keeps behind its predecessor beyond the two it must
 };
@@ -888,212 +891,6 @@ __device__ __forceinline__ void st_sc1_x2(double *p, double a, double b) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs p) {
-  extern __shared__ __attribute__((aligned(16))) double q2smem[];
-  double *sOp = q2smem;
-  __shared__ int s_pass, s_ok;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
-  double *st = q2smem + QOPSZ + wave * 16 * QSTLD;      // this wave's transposing buffer
-  const int n = p.g.n;
-  const double *sV = sOp, *sVT = sOp + QR * QVLD;
-  while (true) {
-    __syncthreads();
-    if (t == 0) s_pass = (int)atomicAdd(&p.ctl[2], 1u);
-    __syncthreads();
-    const int pass = s_pass;
-    if (pass >= p.npass) break;
-    const int pair = p.npair - 1 - pass / p.nslab, slab = pass % p.nslab;
-    const int S = 2 * pair;                              // lower block of the pair; the upper one may not exist
-    const bool has_hi = S + 1 < p.g.nS;
-    const int KS = q2_groups_of_block(n, S);
-    const int KSH = has_hi ? q2_groups_of_block(n, S + 1) : 0;     // KS or KS - 1
-    const int colw = slab * QNC + 16 * wave;
-    const unsigned *pprog = (pair + 1 < p.npair) ? p.prog + (size_t)(pass - p.nslab) : nullptr;   // the pair above, same slab
-    unsigned *myprog = p.prog + pass;
-    if (KS <= 0) { if (t == 0) __hip_atomic_store(myprog, kQ2Done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
-    const int o0 = S * QG;                               // first row of chunk 0 (even)
-    // the pair above works 64 rows further down: its chunk j - 1 is our chunk j, which is therefore final
-    // once it has stored j chunks; waiting for `need` stored chunks, bounded
-    auto wait_for = [&](unsigned need) -> bool {         // thread 0 only
-      if (!pprog) return true;
-      unsigned spins = 0;
-      while (__hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(2);
-        if ((++spins & 63u) == 0u &&
-            (spins > kSpinLimit || __hip_atomic_load(&p.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
-          return false;
-      }
-      return true;
-    };
-    double4_t za[4], zb[4];
-    static_assert(QREC % 2 == 0, "records travel as 16-byte pairs");
-    constexpr int NPAIR = QREC / 2, NOP = (NPAIR + 255) / 256;   // 13 pairs of a record per thread
-    double zreg[16];
-    d2_t oreg[NOP];
-    auto fetch_ops = [&](int Sb, int k) {                // the record is the LDS image itself: a linear copy
-      const d2_t *rec = reinterpret_cast<const d2_t *>(p.Rec + ((size_t)p.g.offS[Sb] + k) * QREC);
-#pragma unroll
-      for (int q = 0; q < NOP; ++q) oreg[q] = (q < NOP - 1 || t + 256 * q < NPAIR) ? rec[t + 256 * q] : (d2_t){0.0, 0.0};
-    };
-    auto put_ops = [&]() {
-      d2_t *dst = reinterpret_cast<d2_t *>(sOp);
-#pragma unroll
-      for (int q = 0; q < NOP; ++q)
-        if (q < NOP - 1 || t + 256 * q < NPAIR) dst[t + 256 * q] = oreg[q];
-    };
-    // chunk j -> zreg: lane = row of the chunk, 16 columns (sc1: another pass may have written them)
-    const bool cols_in = colw + 16 <= p.ncols;
-    auto fetch_chunk = [&](int j) {
-      const int row = o0 + SB * j + lane;
-      const double *src = p.Z + (size_t)row + (size_t)colw * p.ldz;
-      if (cols_in && o0 + SB * j + SB <= n) {            // interior chunk: no predicates
-#pragma unroll
-        for (int c = 0; c < 16; ++c) zreg[c] = ld_sc1(src + (size_t)c * p.ldz);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-          zreg[c] = (row < n && colw + c < p.ncols) ? ld_sc1(src + (size_t)c * p.ldz) : 0.0;
-      }
-    };
-    // zreg (row per lane) -> accumulator layout, through the per-wave buffer in two halves of 32 rows
-    auto chunk_to_tiles = [&](double4_t (&z)[4]) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if ((lane >> 5) == h) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) st[c * QSTLD + (lane & 31)] = zreg[c];
-        }
-        wave_sync();
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) z[2 * h + tt][r] = st[l15 * QSTLD + 16 * tt + l4 + 4 * r];
-        wave_sync();
-      }
-    };
-    // accumulator layout -> memory as aligned row pairs (16-byte write-through stores)
-    auto tiles_to_global = [&](int j, const double4_t (&z)[4]) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) st[l15 * QSTLD + 16 * tt + l4 + 4 * r] = z[2 * h + tt][r];
-        wave_sync();
-        {
-          const int pr = lane & 15, cg = lane >> 4;      // row pair of this half, 4 columns per lane
-          const int row = o0 + SB * j + 32 * h + 2 * pr;
-          double *dst0 = p.Z + (size_t)row + (size_t)(colw + 4 * cg) * p.ldz;
-          if (cols_in && o0 + SB * j + SB <= n) {        // interior chunk: no predicates
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int c = 4 * cg + q;
-              st_sc1_x2(dst0 + (size_t)q * p.ldz, st[c * QSTLD + 2 * pr], st[c * QSTLD + 2 * pr + 1]);
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int c = 4 * cg + q;
-              if (colw + c < p.ncols) {
-                const double a = st[c * QSTLD + 2 * pr], b = st[c * QSTLD + 2 * pr + 1];
-                if (row + 1 < n) st_sc1_x2(dst0 + (size_t)q * p.ldz, a, b);
-                else if (row < n) st_sc1(dst0 + (size_t)q * p.ldz, a);
-              }
-            }
-          }
-        }
-        wave_sync();
-      }
-    };
-    // one group on the window [za | zb]: row tiles OFF .. OFF + 5 of its eight (16 rows each)
-    auto apply_group = [&](auto off_c) {
-      constexpr int OFF = decltype(off_c)::value;
-      double4_t w1[2];
-      w1[0] = (double4_t){0.0, 0.0, 0.0, 0.0}; w1[1] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int tile = 0; tile < 6; ++tile)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // the image is a parallelogram: reflector i lives in rows i .. i + 63, so rows 80.. hold
-          // nothing of reflectors 0..15 and rows 0..15 nothing of reflectors 16..31
-          const double y = (tile + OFF < 4) ? za[(tile + OFF) & 3][r] : zb[(tile + OFF) & 3][r];
-          const double *vrow = sV + (16 * tile + 4 * r + l4) * QVLD + l15;
-          if (tile < 5) w1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[0], y, w1[0], 0, 0, 0);
-          if (tile > 0) w1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[16], y, w1[1], 0, 0, 0);
-        }
-#pragma unroll
-      for (int tile = 0; tile < 6; ++tile) {
-        double4_t acc = (tile + OFF < 4) ? za[(tile + OFF) & 3] : zb[(tile + OFF) & 3];
-        const double *xrow = sVT + (16 * tile + l15) * QVLD + l4;
-#pragma unroll
-        for (int kk = (tile == 5 ? 16 : 0); kk < QG; kk += 4)      // rows 80.. of V T: columns 16.. only
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xrow[kk], w1[kk >> 4][(kk & 15) >> 2], acc, 0, 0, 0);
-        if (tile + OFF < 4) za[(tile + OFF) & 3] = acc; else zb[(tile + OFF) & 3] = acc;
-      }
-    };
-    // ---- prologue: chunk 1 is chunk 0 of the pair above (+ slack)
-    if (t == 0) s_ok = wait_for((unsigned)(1 + p.extra)) ? 1 : 0;
-    __syncthreads();
-    if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    fetch_chunk(0); chunk_to_tiles(za);
-    fetch_chunk(1); chunk_to_tiles(zb);
-    if (KSH > 0) fetch_ops(S + 1, 0); else fetch_ops(S, 0);
-    unsigned early = 0;                                   // thread 0: an early look at the predecessor's progress
-    for (int k = 0; k < KS; ++k) {
-      // gate of this step: chunk k+2 is fetched below, it is chunk k+1 of the pair above.  The word
-      // was read while the previous group computed; only if that was too early does the thread poll.
-      if (t == 0) {
-        const unsigned need = (unsigned)(k + 2 + p.extra);
-        s_ok = (!pprog || early >= need || wait_for(need)) ? 1 : 0;
-      }
-      __syncthreads();
-      if (!s_ok) { if (t == 0) __hip_atomic_store(&p.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-      // every wave has passed the drain in front of its stores of chunk k-1, so chunks <= k-2 are in memory
-      if (t == 0 && k > 1) __hip_atomic_store(myprog, (unsigned)(k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool hi = k < KSH;
-      if (hi) {
-        // group (S+1, k) on rows 32 .. 127 of the window, the record of (S, k) in flight meanwhile
-        put_ops();
-        __syncthreads();
-        if (t == 0 && pprog) early = __hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fetch_ops(S, k);
-        if (k + 1 < KS) fetch_chunk(k + 2);
-        apply_group(std::integral_constant<int, 2>());
-        __syncthreads();                                  // all waves have read the images of (S+1, k)
-      }
-      // group (S, k) on rows 0 .. 95
-      put_ops();
-      __syncthreads();
-      if (!hi && t == 0 && pprog) early = __hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (k + 1 < KS) {
-        if (k + 1 < KSH) fetch_ops(S + 1, k + 1); else fetch_ops(S, k + 1);
-        if (!hi) fetch_chunk(k + 2);
-      }
-      apply_group(std::integral_constant<int, 0>());
-      // (the stores of the previous chunk, issued a whole step ago, have long completed: this wait
-      // only makes that certain before the progress word of the next step tells the follower)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      tiles_to_global(k, za);                            // chunk k is final for both blocks of sweeps
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) za[tt] = zb[tt];
-      if (k + 1 < KS) chunk_to_tiles(zb);                // chunk k+2
-      else tiles_to_global(k + 1, za);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) __hip_atomic_store(myprog, kQ2Done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// ------------------------------------------------------------------------ Q2: NBLK blocks of sweeps per pass
-// The same pipeline with a BUNDLE of NBLK blocks of sweeps (NBLK q .. NBLK q + NBLK - 1) per pass: the window grows
-// to 2 NBLK + 4 row tiles (block b of the bundle acts on window rows 32 b .. 32 b + 95), a step applies the groups
-// (S + NBLK - 1, k), ..., (S, k) and then stores the first 64 rows of the window and takes in 64 new ones -- which
-// are chunk k + 1 of the bundle ABOVE (it starts 32 NBLK rows further down), so the hand-off between passes is the one
-// of the pair kernel.  Z is streamed once per NBLK blocks (n^3 / (8 NBLK) bytes each way for all columns) and the
-// fetch, the two LDS transposes and the store of a chunk are shared by NBLK groups instead of two.  Same groups, same
-// order on every element as in q2_apply_kernel: the same bits.  NBLK = 3: 10 tiles = 80 registers of window; four do
-// not fit beside the record prefetch.
 #ifndef Q2_PF
 #define Q2_PF 2
 #endif
@@ -1111,13 +908,17 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
     __syncthreads();
     if (t == 0) s_pass = (int)atomicAdd(&p.ctl[2], 1u);
     __syncthreads();
-    const int pass = s_pass;
+    const int pass = __builtin_amdgcn_readfirstlane(s_pass);
     if (pass >= p.npass) break;
     const int bundle = p.npair - 1 - pass / p.nslab, slab = pass % p.nslab;      // (npair: number of bundles)
     const int S = NBLK * bundle;                         // lowest block of the bundle
     int KSb[NBLK];
+    unsigned offb[NBLK];                                 // first record of each block of the bundle
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b) KSb[b] = (S + b < p.g.nS) ? q2_groups_of_block(n, S + b) : 0;
+    for (int b = 0; b < NBLK; ++b) {
+      KSb[b] = (S + b < p.g.nS) ? q2_groups_of_block(n, S + b) : 0;
+      offb[b] = (S + b < p.g.nS) ? p.g.offS[S + b] : 0u;
+    }
     const int KS = KSb[0];
     const int colw = slab * QNC + 16 * wave;
     const unsigned *pprog = (bundle + 1 < p.npair) ? p.prog + (size_t)(pass - p.nslab) : nullptr;   // the bundle above, same slab
@@ -1136,20 +937,32 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
       return true;
     };
     double4_t w[WT];
-    constexpr int NPAIR = QREC / 2, NOP = (NPAIR + 255) / 256;   // 13 pairs of a record per thread
+    // A record travels global -> registers -> LDS in two halves of 6 x 16 bytes per thread (pair j = t + 256 q of a
+    // half is row j / 16, columns 2 (j % 16), +1 of the 96 x 32 matrix), each half written into its LDS image WHILE the
+    // matrix instructions of the other product run: the image of -(V T) of group g during g's first product (which
+    // reads V only), the image of V of group g + 1 during g's second product (which reads -(V T) only).  Written in one
+    // piece in front of a group (round 2) the 50 KB cost 16 of the kernel's 206 ms at N = 16384 (timing-only build).
+    static_assert(QR * QG == 6 * 256 * 2, "a half record is six 16-byte pairs per thread");
+    constexpr int HALF = QR * QG / 2;                     // pairs per half
     double zreg[16];
-    d2_t oreg[NOP];
-    auto fetch_ops = [&](int Sb, int k) {                // the record is the LDS image itself: a linear copy
-      const d2_t *rec = reinterpret_cast<const d2_t *>(p.Rec + ((size_t)p.g.offS[Sb] + k) * QREC);
+    d2_t oreg[12];                                        // [0..5]: V of the next group, [6..11]: -(V T) of this / the next one
+    const int obase = (t >> 4) * QVLD + 2 * (t & 15);
+    auto rec_of = [&](int b, int k) -> const d2_t * {     // block b of the bundle, group k (no memory access: offb)
+      unsigned o = offb[0];
 #pragma unroll
-      for (int q = 0; q < NOP; ++q) oreg[q] = (q < NOP - 1 || t + 256 * q < NPAIR) ? rec[t + 256 * q] : (d2_t){0.0, 0.0};
+      for (int q = 1; q < NBLK; ++q) if (b == q) o = offb[q];
+      return reinterpret_cast<const d2_t *>(p.Rec + ((size_t)o + k) * QREC) + t;
     };
-    auto put_ops = [&]() {
-      d2_t *dst = reinterpret_cast<d2_t *>(sOp);
+    auto fetch_v = [&](const d2_t *rec) {
 #pragma unroll
-      for (int q = 0; q < NOP; ++q)
-        if (q < NOP - 1 || t + 256 * q < NPAIR) dst[t + 256 * q] = oreg[q];
+      for (int q = 0; q < 6; ++q) oreg[q] = rec[256 * q];
     };
+    auto fetch_t = [&](const d2_t *rec) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) oreg[6 + q] = rec[HALF + 256 * q];
+    };
+    auto put_v = [&](int q) { double *d = sOp + obase + q * 16 * QVLD; d[0] = oreg[q][0]; d[1] = oreg[q][1]; };
+    auto put_t = [&](int q) { double *d = sOp + QR * QVLD + obase + q * 16 * QVLD; d[0] = oreg[6 + q][0]; d[1] = oreg[6 + q][1]; };
     const bool cols_in = colw + 16 <= p.ncols;
     // 64 rows from global row `row0` on -> zreg: lane = row, 16 columns (sc1: another pass may have written them)
     auto fetch_rows = [&](int row0) {
@@ -1208,7 +1021,8 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
     // steps AHEAD of their use (PF): left to itself the compiler reads an operand pair, waits for it, and issues the two
     // instructions that need it -- an LDS round trip every 128 cycles of the matrix pipe.  In the second product the
     // accumulation chains of two tiles alternate (a chain on one accumulator issues only every other slot).
-    auto apply_group = [&](auto off_c) {
+    // nrec: the record of the group after this one (its own if it is the last); row_next >= 0: the 64 rows of Z to fetch
+    auto apply_group = [&](auto off_c, const d2_t *nrec, int row_next) {
       constexpr int OFF = decltype(off_c)::value;
       constexpr int PF = Q2_PF;                            // steps of look-ahead
       double4_t w1[2];
@@ -1224,12 +1038,19 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
 #pragma unroll
         for (int sidx = 0; sidx < 24; ++sidx) {
           if (sidx + PF < 24) ld1(sidx + PF, (sidx + PF) % (PF + 1));
+          if (sidx < 12 && (sidx & 1) == 0) put_t(sidx >> 1);       // this group's -(V T) image (nobody reads it before B1)
+          if (sidx == 12) {                                         // (behind the writes: their wait must not cover these)
+            fetch_v(nrec);
+            if (row_next >= 0) fetch_rows(row_next);
+          }
           const int tile = sidx >> 2, r = sidx & 3;
           const double y = w[tile + OFF][r];
           if (tile < 5) w1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[sidx % (PF + 1)][0], y, w1[0], 0, 0, 0);
           if (tile > 0) w1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[sidx % (PF + 1)][1], y, w1[1], 0, 0, 0);
         }
       }
+      __syncthreads();                                     // B1: -(V T) complete; everybody has finished reading V
+      fetch_t(nrec);
       {
         // tiles in pairs (0,1), (2,3), (4,5): step q of a pair = k-step kk = 4 (q / 2) of tile 2 pr + (q & 1); tile 5 has
         // only the k-steps 16.. (rows 80.. of V T: columns 16.. only), its first four slots are skipped
@@ -1245,6 +1066,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
 #pragma unroll
         for (int q = 0; q < 48; ++q) {
           if (q + PF < 48) ld2(q + PF, (q + PF) % (PF + 1));
+          if (q >= 24 && (q & 3) == 0) put_v((q - 24) >> 2);       // the next group's V image
           if (seq_ok(q)) {
             const int tile = seq_tile(q), kk = seq_kk(q);
             w[tile + OFF] = __builtin_amdgcn_mfma_f64_16x16x4f64(px[q % (PF + 1)], w1[kk >> 4][(kk & 15) >> 2], w[tile + OFF], 0, 0, 0);
@@ -1259,12 +1081,13 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
       for (int q = 1; q < NBLK; ++q) if (k < KSb[q]) b = q;
       return b;
     };
-    auto prefetch_next = [&](int k, int b) {             // the record of the group after (b, k)
+    auto next_group = [&](int k, int b) -> const d2_t * {      // record of the group after (b, k); its own if it is the last
       int nb = -1, nk = k;
 #pragma unroll
       for (int q = NBLK - 1; q >= 0; --q) if (q < b && nb < 0 && k < KSb[q]) nb = q;
       if (nb < 0) { nk = k + 1; if (nk < KS) nb = first_block(nk); }
-      if (nb >= 0) fetch_ops(S + nb, nk);
+      if (nb < 0) { nb = b; nk = k; }
+      return rec_of(nb, nk);
     };
     // ---- prologue: the window at step 0; its rows from 32 NBLK on are chunk 0 of the bundle above (+ slack)
     if (t == 0) s_ok = wait_for((unsigned)(1 + p.extra)) ? 1 : 0;
@@ -1280,7 +1103,10 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
       fetch_rows(o0 + 64 * (WT / 4));
       half_to_tiles(0, w[WT - 2], w[WT - 1]);
     }
-    fetch_ops(S + first_block(0), 0);
+    fetch_v(rec_of(first_block(0), 0));
+    fetch_t(rec_of(first_block(0), 0));
+#pragma unroll
+    for (int q = 0; q < 6; ++q) put_v(q);                 // (visible after the barrier at the top of step 0)
     unsigned early = 0;                                   // thread 0: an early look at the predecessor's progress
     for (int k = 0; k < KS; ++k) {
       // gate of this step: the 64 rows fetched below are chunk k + 1 of the bundle above
@@ -1296,13 +1122,11 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
       auto do_group = [&](auto b_c) {
         constexpr int B = decltype(b_c)::value;
         if (k >= KSb[B]) return;                         // (uniform)
-        put_ops();
-        __syncthreads();
+        // (here: the V image of this group is in LDS and visible, its -(V T) half is on its way into registers)
         if (B == bfirst && t == 0 && pprog) early = __hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prefetch_next(k, B);
-        if (B == bfirst && k + 1 < KS) fetch_rows(o0 + 64 * (k + 1) + 16 * (WT - 4));
-        apply_group(std::integral_constant<int, 2 * B>());
-        if (B > 0) __syncthreads();                      // all waves have read the images of this group
+        apply_group(std::integral_constant<int, 2 * B>(), next_group(k, B),
+                    (B == bfirst && k + 1 < KS) ? o0 + 64 * (k + 1) + 16 * (WT - 4) : -1);
+        if (B > 0) __syncthreads();                      // B2: the next V image complete; everybody has finished reading -(V T)
       };
       if constexpr (NBLK >= 4) do_group(std::integral_constant<int, 3>());
       if constexpr (NBLK >= 3) do_group(std::integral_constant<int, 2>());
@@ -1485,16 +1309,16 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   constexpr size_t lds = (size_t)(QOPSZ + 4 * 16 * QSTLD) * sizeof(double);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void *)q2_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)q2_apply_nb_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)q2_apply_nb_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)q2_apply_nb_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  // blocks of sweeps per pass: 3 (q2_apply_nb_kernel<3>); EK_Q2_NBLK=2 the pair kernel of round 2, 22 the general
-  // kernel with pairs (all three give the same bits)
-  int nblk = 3;
-  if (const char *ev = getenv("EK_Q2_NBLK")) nblk = atoi(ev);
-  const int per = (nblk == 3) ? 3 : 2;
+  // blocks of sweeps per pass: 4 from order 8192 on, 3 below (N = 16384: 0.194 / 0.199 / 0.212 s with 4 / 3 / 2,
+  // N = 4096: 4.9 / 4.7 / 4.9 ms); EK_Q2_NBLK = 2, 3, 4 forces one (all give the same bits)
+  int nblk = (n >= 8192) ? 4 : 3;
+  if (const char *ev = getenv("EK_Q2_NBLK")) { const int v = atoi(ev); if (v >= 2 && v <= 4) nblk = v; }
+  const int per = nblk;
   const int nslab = ceil_div(ncols, QNC), npair = ceil_div(L.nS, per), npass = npair * nslab;
   (void)hipMemsetAsync(qprog, 0, (size_t)npass * 4, s);
   (void)hipMemsetAsync(ctl + 2, 0, 4, s);
@@ -1509,8 +1333,8 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   if (nwg > npass) nwg = npass;
   kprof_begin(s, kProfQ2Apply);
   if (nblk == 3) hipLaunchKernelGGL(q2_apply_nb_kernel<3>, dim3(nwg), dim3(256), lds, s, a);
-  else if (nblk == 22) hipLaunchKernelGGL(q2_apply_nb_kernel<2>, dim3(nwg), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(q2_apply_kernel, dim3(nwg), dim3(256), lds, s, a);
+  else if (nblk == 4) hipLaunchKernelGGL(q2_apply_nb_kernel<4>, dim3(nwg), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(q2_apply_nb_kernel<2>, dim3(nwg), dim3(256), lds, s, a);
   kprof_end(s, kProfQ2Apply);
   if (d_flag) hipLaunchKernelGGL(forward_abort_kernel, dim3(1), dim3(1), 0, s, ctl, d_flag);
 }

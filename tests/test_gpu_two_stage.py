@@ -176,23 +176,23 @@ def test_both_bulge_chasing_kernels_give_the_same_bits(hip, n):
 
 @pytest.mark.parametrize("n,ncols", [(3, 3), (66, 66), (130, 17), (200, 200), (321, 64), (777, 100), (1000, 1000), (1500, 333)])
 def test_q2_application_does_not_depend_on_the_blocks_of_sweeps_per_pass(hip, n, ncols):
-    """Z <- Q2 Z streams Z once per bundle of blocks of 32 sweeps: three per pass (the default), two (the round-2
-    kernel, EK_Q2_NBLK=2, and the general kernel with pairs, 22).  Same groups in the same order on every element:
-    the results must be the same bits, and Q2 orthogonal."""
+    """Z <- Q2 Z streams Z once per bundle of blocks of 32 sweeps: three per pass (the default) or two (EK_Q2_NBLK=2, as
+    in round 2).  Same groups in the same order on every element: the results must be the same bits, and Q2
+    orthogonal.  (tools/q2_anchor.py compares two BUILDS of the library the same way: the round-2 pair kernel, retired
+    in round 3, gave these bits too.)"""
     Bd = _random_band(n, 7 * n + 3)
     rng = np.random.default_rng(n)
     Z0 = rng.standard_normal((n, ncols))
     res = {}
     try:
-        for nblk in ("2", "22", "3"):
+        for nblk in ("2", "3", "4"):
             os.environ["EK_Q2_NBLK"] = nblk
             d, e, Z, f = hip.sb2st(Bd, Z0)
             assert f == 0
             res[nblk] = (d, e, Z)
     finally:
         os.environ.pop("EK_Q2_NBLK", None)
-    for nblk in ("22", "3"):
-        assert np.array_equal(res["2"][2], res[nblk][2]), nblk
+    assert np.array_equal(res["2"][2], res["3"][2]) and np.array_equal(res["2"][2], res["4"][2])
     if ncols == n:
         _, _, Q2, _ = hip.sb2st(Bd, np.eye(n))
         assert np.linalg.norm(Q2.T @ Q2 - np.eye(n)) <= 64 * n * EPS

@@ -13,7 +13,7 @@ sec = (ctypes.c_double * 4)()
 flag = ctypes.c_int(0)
 for n in [int(a) for a in sys.argv[1:]] or [4096, 16384]:
     for ncols in (n, min(n, 1024)):
-        for nblk in ("2", "22", "3"):
+        for nblk in (os.environ.get("Q2_TIMING_NBLK", "2,3,4").split(",")):
             os.environ["EK_Q2_NBLK"] = nblk
             lib.ek_hip_debug_two_stage_timing(n, ncols, 1, sec, ctypes.byref(flag))
             rc = lib.ek_hip_debug_two_stage_timing(n, ncols, 3, sec, ctypes.byref(flag))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 profile artefacts: the default bench line (headline + other_configs + cpu baseline), rocprofv3 kernel
-# summary of the headline command, PMC passes (MFMA instruction / busy counters; HBM traffic of q2_apply_kernel).
+# summary of the headline command, PMC passes (MFMA instruction / busy counters; HBM traffic of q2_apply_nb_kernel).
 # usage (on the GPU box): bash tools/r03_profile.sh <tag> ; then locally: python tools/make_traffic_record.py <tag>
 export TMPDIR=/tmp
 TAG=${1:-v1}
