@@ -498,6 +498,7 @@ struct PosArgs {
   unsigned census_spins;
   const int *skip;       // device: non-zero = the band is not valid (the first stage raised its flag): do nothing
   unsigned jitter;       // test aid (EK_SB2ST_JITTER): pseudo-random pauses of single positions, to shake the timing
+  long long *trace; int trace_k;   // EK_SB2ST_TRACE=<position>: wall-clock stamps (10 ns) of that position's first 2048 sweeps
 };
 
 template <int CTRL>
@@ -585,6 +586,13 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
     const bool lead = s > 0 && k + 1 < Kprev;              // position k+1 had a task in sweep s-1: its late numbers come by mail
     // every store of the previous task (mail, emptied lines) has completed before this task sends anything
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef EK_POS_TRACE      // diagnostic build only: the stamps cost 15 % of the stage even when no position is traced
+    const bool tr = p.trace && k == p.trace_k && s < 2048 && lane == 0;
+    auto stamp = [&](int slot) { if (tr) p.trace[16 * s + slot] = (long long)wall_clock64(); };
+#else
+    auto stamp = [](int) {};
+#endif
+    if (wave == 0) stamp(0);
     if (p.jitter) {                                        // (uniform per workgroup and sweep)
       const unsigned h = ((unsigned)s * 2654435761u) ^ ((unsigned)k * 40503u * p.jitter);
       if (((h >> 9) & 15u) == 0u) for (unsigned q = 0; q < ((h >> 3) & 63u); ++q) __builtin_amdgcn_s_sleep(64);
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
         const double x = (s == 0) ? ((lane < L) ? AB[(size_t)(1 + lane)] : 0.0) : xnext;
         const Reflector r = reflector_of(x, lane);
         s_v[0][lane] = r.v;
-        if (lane == 0) { s_tau[0] = r.tau; p.tau2[(size_t)s * p.ldt] = r.tau; st_sc1(AB + (size_t)1 + (size_t)s * LDAB, r.beta); }
+        if (lane == 0) { s_tau[0] = r.tau; p.tau2[(size_t)s * p.ldt] = r.tau; AB[(size_t)1 + (size_t)s * LDAB] = r.beta; }   // (e(s): read after the kernel)
         if (lane < L) p.V2[(size_t)(i0 + lane) + (size_t)s * p.ldv2] = r.v;
       } else {
         double a, b;
@@ -604,6 +612,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
         s_v[0][lane] = (lane == 0) ? 1.0 : a;
         if (lane == 0) s_tau[0] = a;
       }
+      stamp(1);
     }
     // ---- the entering column: the late numbers of position k+1's task of the previous sweep
     if (wave == NW - 1 && s > 0) {
@@ -616,6 +625,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
         const double col = (lane < 63) ? up : beta;
         bk[CW - 1] = (lane < L1 && SB - 1 < L) ? col : 0.0;
         if (lane == 63 && SB - 1 < L) dd[CW - 1] = corner;
+        stamp(2);
       } else if (L == SB) {
         // the one sweep after position k+1 has retired (or never existed): the corner is A(n-1, n-1) in the band array
         int ok = 1;
@@ -635,6 +645,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
     }
     __syncthreads();                                                         // #1
     if (!s_ok) return;
+    if (wave == 0) stamp(3);
     const double tau = s_tau[0];
     const double v_r = s_v[0][lane];
     double vc[CW];
@@ -647,6 +658,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
       if (wave == 0) s_b0[lane] = bk[0];
     }
     __syncthreads();                                                         // #2
+    if (wave == 0) stamp(7);
     // ---- the reflector of position k+1: position k+1 is waiting for it.  Made by wave RW from column 0 of B_k (which
     // wave 0 has put into LDS) while wave 0 updates column 0 of D_k, the late numbers position k-1 is waiting for.
     if (wave == RW) {
@@ -659,6 +671,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
         const Reflector r = reflector_of(col0, lane);
         double *line = p.fwd + ((size_t)(k + 1) * 4 + (s & 3)) * PMAILW;
         st_sc1(line + lane, (lane == 0) ? r.tau : r.v);
+        stamp(4);
         s_v[1][lane] = r.v;
         if (lane == 0) { s_tau[1] = r.tau; p.tau2[(size_t)(k + 1) + (size_t)s * p.ldt] = r.tau; }
         if (lane < L1) p.V2[(size_t)(i0 + SB + lane) + (size_t)s * p.ldv2] = r.v;
@@ -677,8 +690,9 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
     if (wave == 0) {
       // column 0 of D_k leaves the position: the late numbers of position k-1, or (position 0) d and the next column
       dd[0] = task_rank2(dd[0], v_r, lane_value(w_r, 0), w_r, vc[0]);
-      if (k > 0) st_sc1(p.bwd + ((size_t)(k - 1) * 4 + (s & 3)) * PMAILW + lane, dd[0]);
-      else if (lane == 0) st_sc1(AB + (size_t)(s + 1) * LDAB, dd[0]);
+      if (k > 0) { st_sc1(p.bwd + ((size_t)(k - 1) * 4 + (s & 3)) * PMAILW + lane, dd[0]); stamp(5); }
+      else if (lane == 0) AB[(size_t)(s + 1) * LDAB] = dd[0];              // d(s+1): read after the kernel -- a plain store: the
+                                                                            // wait at the top of the next sweep would sit out an sc1 store's way to memory
     }
 #pragma unroll
     for (int j = 0; j < CW; ++j)
@@ -693,10 +707,13 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
 #pragma unroll
       for (int j = 0; j < CW; ++j) bp[j] = (L1 > 0) ? task_right(bk[j], q_r, vc[j]) : 0.0;
     }
+    if (wave == 0) stamp(8);
     if (k + 1 < K) {
       __syncthreads();                                                       // #3: the new reflector is in LDS
+      if (wave == 0) stamp(9);
       task_left<CW>(bp, s_v[1][lane], s_tau[1], s_t[wave], lane, wave == 0);
     }
+    if (wave == 0) stamp(6);
     if (s == s_last) break;
     // ---- the blocks of the next sweep: one row and one column further down the band
     if (lane == 0) {
@@ -705,6 +722,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
     }
     s_x[wave][lane] = dd[0]; s_y[wave][lane] = bp[0];
     __syncthreads();                                                         // #4
+    if (wave == 0) stamp(10);
     if (k == 0 && wave == 0) {
       const double up = dpp_shift<0x130>(dd[0]);
       xnext = (lane < 63) ? up : s_b00;
@@ -721,6 +739,7 @@ __global__ __launch_bounds__(512) void chase_pos_kernel(PosArgs p) {
       bk[j] = (lane == 63) ? 0.0 : bu;
     }
     if (wave == NW - 1) dd[CW - 1] = (lane < 63) ? s_row[lane + 1] : 0.0;    // the corner and B's last column: next sweep's mail
+    if (wave == 0) stamp(11);
   }
   // ---- retirement: the last task had L = 2; what is left of D_k is A(n-1, n-1) (position 0: also e(n-2))
   if (wave == 0) {
@@ -1251,9 +1270,35 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
       unsigned census = 1u << 16;                            // x ~0.3 us: what a workgroup waits for the others to arrive
       if (const char *ev = getenv("EK_SB2ST_CENSUS_SPINS")) census = (unsigned)atoi(ev);
       PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * PMAILW, retired, ctl, per, census, d_flag,
-                getenv("EK_SB2ST_JITTER") ? (unsigned)atoi(getenv("EK_SB2ST_JITTER")) : 0u};
+                getenv("EK_SB2ST_JITTER") ? (unsigned)atoi(getenv("EK_SB2ST_JITTER")) : 0u, nullptr, -1};
+      static long long *trace_buf = nullptr;
+      if (const char *ev = getenv("EK_SB2ST_TRACE")) {
+        if (!trace_buf) (void)hipMalloc((void **)&trace_buf, 2048 * 16 * sizeof(long long));
+        (void)hipMemsetAsync(trace_buf, 0, 2048 * 16 * sizeof(long long), s);
+        a.trace = trace_buf; a.trace_k = atoi(ev);
+      }
       hipLaunchKernelGGL(chase_pos_kernel, dim3(per > 0 ? per * 8 : K0), dim3(512), 0, s, a);
       hipLaunchKernelGGL(repack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, AB0, AB, ctl);
+      if (a.trace) {                                         // diagnostic: average gaps between the stamps, sweeps 256 .. 2047
+        static long long h[2048 * 16];
+        (void)hipMemcpyAsync(h, a.trace, sizeof(h), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        double acc[16] = {0}; int cnt = 0;
+        for (int q = 256; q + 1 < 2048 && q + 1 <= L.nsweeps - 64 * (a.trace_k + 2); ++q) {
+          const long long *r = h + 16 * q, *r1 = h + 16 * (q + 1);
+          if (!r[0] || !r1[0]) continue;
+          acc[0] += (double)(r1[0] - r[0]);                 // period
+          for (int j = 1; j < 16; ++j) acc[j] += r[j] ? (double)(r[j] - r[0]) : 0.0;
+          ++cnt;
+        }
+        if (cnt)
+          fprintf(stderr, "[sb2st trace] position %d, %d sweeps: period %.0f ns; from the top of a sweep: forward mail taken %.0f, "
+                  "backward mail taken %.0f, barrier #1 passed %.0f, #2 passed %.0f, backward sent %.0f, forward sent %.0f, "
+                  "D and B H done %.0f, #3 passed %.0f, H B done %.0f, #4 passed %.0f, shifted %.0f ns\n",
+                  a.trace_k, cnt, 10 * acc[0] / cnt, 10 * acc[1] / cnt, 10 * acc[2] / cnt, 10 * acc[3] / cnt, 10 * acc[7] / cnt,
+                  10 * acc[5] / cnt, 10 * acc[4] / cnt, 10 * acc[8] / cnt, 10 * acc[9] / cnt, 10 * acc[6] / cnt, 10 * acc[10] / cnt,
+                  10 * acc[11] / cnt);
+      }
     }
     hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(nmail, 256)), dim3(256), 0, s, mail, nmail);
     ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, mail, L.kmax + 1, nullptr, pos ? 1 : 0, d_flag};

@@ -6,7 +6,7 @@
 //     k-1, passes two more barriers (left application, shift).
 // The sweep rate of the chain is bounded by the cycle forward hop + backward hop + what lies between;
 // the printout is microseconds per sweep.  Every spin is bounded.
-// Build: hipcc -O3 --offload-arch=gfx950 -o chain_hop chain_hop.hip ; run: ./chain_hop [K] [sweeps] [xcdmap] [pad]
+// Build: hipcc -O3 --offload-arch=gfx950 -o chain_hop chain_hop.hip ; run: ./chain_hop [K] [sweeps] [xcdmap 0|1|2] [pad] [plain]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -19,9 +19,14 @@ __device__ __forceinline__ double ld_sc1(const double *p) {
   return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT));
 }
+__device__ int g_plain;   // 1: plain stores (the line stays in the XCD's L2: only right when writer and reader share an XCD)
 __device__ __forceinline__ void st_sc1(double *p, double v) {
-  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+  if (g_plain)
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool empty(double v) { return (unsigned long long)__double_as_longlong(v) == kEmpty; }
 
@@ -38,7 +43,8 @@ __global__ __launch_bounds__(512) void chain_kernel(int K, int sweeps, int xcdma
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // position of this workgroup: neighbours on one XCD (blocks b and b + 8 share one) or dealt round-robin
   int k = blockIdx.x;
-  if (xcdmap) { const int per = (K + 7) / 8; k = (blockIdx.x & 7) * per + (blockIdx.x >> 3); }
+  if (xcdmap == 1) { const int per = (K + 7) / 8; k = (blockIdx.x & 7) * per + (blockIdx.x >> 3); }
+  if (xcdmap == 2) { if (blockIdx.x & 7) return; k = blockIdx.x >> 3; }   // every position on ONE XCD
   if (k >= K) return;
   if (t == 0) s_ok = 1;
   __syncthreads();
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(512) void chain_kernel(int K, int sweeps, int xcdma
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // #4
   }
-  out[(size_t)blockIdx.x * 512 + t] = acc;
+  out[(size_t)k * 512 + t] = acc;
 }
 
 __global__ void dpp_probe(double *x) {   // what wave_shl:1 / wave_shr:1 do on this chip (lane i <- lane i +- 1?)
@@ -128,7 +134,9 @@ int main(int argc, char **argv) {
     printf("wave_shl:1 lanes 0,1,15,16,31,32,62,63 <- %g %g %g %g %g %g %g %g\n", h[0], h[1], h[15], h[16], h[31], h[32], h[62], h[63]);
     printf("wave_shr:1 lanes 0,1,15,16,31,32,62,63 <- %g %g %g %g %g %g %g %g\n", h[64], h[65], h[79], h[80], h[95], h[96], h[126], h[127]);
   }
-  const int grid = xcdmap ? ((K + 7) / 8) * 8 : K;
+  const int plain = argc > 5 ? atoi(argv[5]) : 0;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_plain), &plain, sizeof(int));
+  const int grid = xcdmap == 2 ? 8 * K : xcdmap ? ((K + 7) / 8) * 8 : K;
   for (int rep = 0; rep < 3; ++rep) {
     hipLaunchKernelGGL(init_kernel, dim3((count + 255) / 256), dim3(256), 0, 0, fwd, count);
     hipLaunchKernelGGL(init_kernel, dim3((count + 255) / 256), dim3(256), 0, 0, bwd, count);
@@ -140,7 +148,7 @@ int main(int argc, char **argv) {
     hipError_t e = hipDeviceSynchronize();
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     unsigned hf = 0; hipMemcpy(&hf, fail, 4, hipMemcpyDeviceToHost);
-    printf("K=%d sweeps=%d xcdmap=%d pad=%d: %.3f ms -> %.3f us per sweep (fail=%u err=%d)\n", K, sweeps, xcdmap, pad, ms,
+    printf("K=%d sweeps=%d xcdmap=%d pad=%d plain=%d: %.3f ms -> %.3f us per sweep (fail=%u err=%d)\n", K, sweeps, xcdmap, pad, plain, ms,
            1e3 * ms / (sweeps + K), hf, (int)e);
   }
   return 0;
