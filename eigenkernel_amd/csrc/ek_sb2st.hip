@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
     // piece in front of a group (round 2) the 50 KB cost 16 of the kernel's 206 ms at N = 16384 (timing-only build).
     static_assert(QR * QG == 6 * 256 * 2, "a half record is six 16-byte pairs per thread");
     constexpr int HALF = QR * QG / 2;                     // pairs per half
-    double4_t zt[4];                                      // the 64 rows on their way in, already as four tiles
+    double zreg[16];
     d2_t oreg[12];                                        // [0..5]: V of the next group, [6..11]: -(V T) of this / the next one
     const int obase = (t >> 4) * QVLD + 2 * (t & 15);
     auto rec_of = [&](int b, int k) -> const d2_t * {     // block b of the bundle, group k (no memory access: offb)
@@ -983,24 +983,29 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
     auto put_v = [&](int q) { double *d = sOp + obase + q * 16 * QVLD; d[0] = oreg[q][0]; d[1] = oreg[q][1]; };
     auto put_t = [&](int q) { double *d = sOp + QR * QVLD + obase + q * 16 * QVLD; d[0] = oreg[6 + q][0]; d[1] = oreg[6 + q][1]; };
     const bool cols_in = colw + 16 <= p.ncols;
-    // 64 rows from global row `row0` on -> zt, straight in the accumulator layout: element r of tile tt in lane (l15, l4) is
-    // row 16 tt + 4 r + l4 of column l15 (8-byte sc1 loads -- another pass may have written them; an instruction takes 16
-    // pieces of 32 bytes, one base address and immediates: no transposition through LDS on the way in)
+    // 64 rows from global row `row0` on -> zreg: lane = row, 16 columns (sc1: another pass may have written them)
     auto fetch_rows = [&](int row0) {
-      const int row = row0 + l4, col = colw + l15;
-      const double *src = p.Z + (size_t)row + (size_t)col * p.ldz;
+      const int row = row0 + lane;
+      const double *src = p.Z + (size_t)row + (size_t)colw * p.ldz;
       if (cols_in && row0 + SB <= n) {                   // interior: no predicates
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) zt[tt][r] = ld_sc1(src + 16 * tt + 4 * r);
+        for (int c = 0; c < 16; ++c) zreg[c] = ld_sc1(src + (size_t)c * p.ldz);
       } else {
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            zt[tt][r] = (row + 16 * tt + 4 * r < n && col < p.ncols) ? ld_sc1(src + 16 * tt + 4 * r) : 0.0;
+        for (int c = 0; c < 16; ++c)
+          zreg[c] = (row < n && colw + c < p.ncols) ? ld_sc1(src + (size_t)c * p.ldz) : 0.0;
       }
+    };
+    // half h (32 rows) of zreg -> two tiles in the accumulator layout, through the per-wave buffer
+    auto half_to_tiles = [&](int h, double4_t &ta, double4_t &tb) {
+      if ((lane >> 5) == h) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) st[c * QSTLD + (lane & 31)] = zreg[c];
+      }
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ta[r] = st[l15 * QSTLD + l4 + 4 * r]; tb[r] = st[l15 * QSTLD + 16 + l4 + 4 * r]; }
+      wave_sync();
     };
     // two tiles (32 rows from global row `row0`) -> memory as aligned row pairs (16-byte write-through stores)
     auto tiles_to_rows = [&](int row0, const double4_t &ta, const double4_t &tb) {
@@ -1110,12 +1115,12 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
 #pragma unroll
     for (int c = 0; c < WT / 4; ++c) {
       fetch_rows(o0 + 64 * c);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) w[4 * c + tt] = zt[tt];
+      half_to_tiles(0, w[4 * c], w[4 * c + 1]);
+      half_to_tiles(1, w[4 * c + 2], w[4 * c + 3]);
     }
     if (WT % 4) {                                        // NBLK odd: half a chunk more
       fetch_rows(o0 + 64 * (WT / 4));
-      w[WT - 2] = zt[0]; w[WT - 1] = zt[1];
+      half_to_tiles(0, w[WT - 2], w[WT - 1]);
     }
     fetch_v(rec_of(first_block(0), 0));
     fetch_t(rec_of(first_block(0), 0));
@@ -1154,8 +1159,8 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
 #pragma unroll
       for (int i = 0; i + 4 < WT; ++i) w[i] = w[i + 4];
       if (k + 1 < KS) {
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) w[WT - 4 + tt] = zt[tt];
+        half_to_tiles(0, w[WT - 4], w[WT - 3]);
+        half_to_tiles(1, w[WT - 2], w[WT - 1]);
       } else {
 #pragma unroll
         for (int i = 0; i + 4 < WT; i += 2) tiles_to_rows(o0 + 64 * (k + 1) + 16 * i, w[i], w[i + 1]);   // the rest of the window
