@@ -887,8 +887,7 @@ __global__ __launch_bounds__(256) void q2_tfactor_kernel(Q2Geom g, const double 
 // goes from the first product into the second without leaving the registers.  Only the factors
 // [V | -V T] of a group pass through LDS.  The order of the groups on any element of Z is the same for every NBLK,
 // so 2, 3 and 4 blocks per pass give the same bits (and the same as round 2's pair kernel: tools/q2_anchor.py).
-// Registers: window 8 (2 NBLK + 4), record halves in flight 48, chunk in flight 32, W1 16: 234 of 256 at NBLK = 3,
-// 256 (one spilled) at 4.
+// Registers: window 8 (2 NBLK + 4), record halves in flight 48, chunk in flight 32, W1 16: 256 at NBLK = 4.
 constexpr int QNC = 64;
 constexpr int QSTLD = 34;              // per-wave transposing buffer: 16 columns x 32 rows (+2), column-major
 constexpr int QOPSZ = 2 * QR * QVLD;   // doubles of the operand buffer: V image, then -V T image (row-major, QVLD)
@@ -911,7 +910,11 @@ __device__ __forceinline__ void st_sc1_x2(double *p, double a, double b) {
 }
 
 #ifndef Q2_PF
-#define Q2_PF 2
+#define Q2_PF 1        // LDS operands read this many steps ahead of their use (1, 2, 3 inside a solve: 188.6 / 190.8 / 188.6 ms;
+#endif                 // one step leaves four blocks per pass without a spilled register)
+#ifndef Q2_PUTV0
+#define Q2_PUTV0 24      // second product: slot of the first of the six writes of the next V image, and their spacing
+#define Q2_PUTVS 4
 #endif
 template <int NBLK>
 __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
@@ -1085,7 +1088,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
 #pragma unroll
         for (int q = 0; q < 48; ++q) {
           if (q + PF < 48) ld2(q + PF, (q + PF) % (PF + 1));
-          if (q >= 24 && (q & 3) == 0) put_v((q - 24) >> 2);       // the next group's V image
+          if (q >= Q2_PUTV0 && q < Q2_PUTV0 + 6 * Q2_PUTVS && (q - Q2_PUTV0) % Q2_PUTVS == 0) put_v((q - Q2_PUTV0) / Q2_PUTVS);   // the next group's V image
           if (seq_ok(q)) {
             const int tile = seq_tile(q), kk = seq_kk(q);
             w[tile + OFF] = __builtin_amdgcn_mfma_f64_16x16x4f64(px[q % (PF + 1)], w1[kk >> 4][(kk & 15) >> 2], w[tile + OFF], 0, 0, 0);
