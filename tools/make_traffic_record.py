@@ -23,6 +23,14 @@ def counter(path, kernel, name):
     raise SystemExit("no %s for %s in %s" % (name, kernel, path))
 
 
+NOTE = ("four blocks of sweeps per pass: WRITE_SIZE is Z stored once per bundle (n^3/32 bytes = 137 GB; 270 GB with pairs, 180 "
+        "with three).  FETCH_SIZE is not the reads of Z (137 GB as well: the 8-byte sc1 loads do not appear in it -- "
+        "MI355X_MICROARCH.md: access widths other than 16 B per lane are uncalibrated) but the records' way into L2: 12 x 16 B per "
+        "thread and group = 3.2 GB of records x 256 slabs = 0.82 TB requested, mostly Infinity-Cache hits, which the counter "
+        "includes.  hbm_bytes_per_launch is the guide's formula on these counters: an upper bound of the HBM traffic, not a "
+        "byte count; algorithmic_bytes_per_launch counts Z once each way per bundle and every record once.")
+
+
 def main():
     tag = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
@@ -41,7 +49,10 @@ def main():
                      "MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE taken as is (16-byte stores)",
            "fetch_size_kib": fetch / nf, "write_size_kib": write / nw,
            "hbm_bytes_per_launch": (2.0 * fetch / nf + write / nw) * 1024.0,
-           "algorithmic_bytes_per_launch": 2.0 * 8.0 * n ** 3 / 64.0}
+           # four blocks of 32 sweeps per pass: Z (on average its lower half) is read and written once per 128 sweeps,
+           # and every group record (2 x 96 x 32 doubles, n^2 / 4096 of them) comes from memory once
+           "algorithmic_bytes_per_launch": 2.0 * (n / 128.0) * (8.0 * n * n / 2.0) + (n * n / 4096.0) * 6144 * 8.0,
+           "note": NOTE}
     out = os.path.join(ROOT, "profiles", "r03_q2_apply_traffic.json")
     json.dump(rec, open(out, "w"), indent=1)
     print(out, rec["hbm_bytes_per_launch"] / 1e12, "TB per launch")
