@@ -172,6 +172,8 @@ def host_path_step(lib, solver, problem, n, n_vec):
     try:
         A = np.zeros((n, n), order="F"); B = np.zeros((n, n), order="F") if problem == 1 else None
         Z = np.zeros((n, n), order="F"); w = np.zeros(n)
+        Z.fill(0.0)      # mapped before the call, like A and B (np.zeros leaves the pages to the first write: 2 GB of
+        #                  page faults inside the timed call, 0.1 - 0.25 s depending on the box)
         if lib.ek_hip_malloc(ctypes.byref(tmp), n * n * 8) != 0:
             return {"error": "ek_hip_malloc"}
         for seed, M in ((1, A), (2, B)):
@@ -190,7 +192,7 @@ def host_path_step(lib, solver, problem, n, n_vec):
         if info != 0:
             return {"error": "ek_hip_solve info=%d" % info}
         return {"value": n_vec / sec, "unit": "eigenpairs/s", "seconds": sec, "host_device_copies_seconds": st[7],
-                "note": "one ek_hip_solve call on pageable host arrays (A, B in; Z, A, B, w out)"}
+                "note": "one ek_hip_solve call on pageable host arrays, all mapped before the call (A, B in; Z, A, B, w out)"}
     except Exception as exc:      # an optional extra never takes the line down
         return {"error": repr(exc)}
     finally:
