@@ -890,7 +890,15 @@ __global__ __launch_bounds__(256) void q2_tfactor_kernel(Q2Geom g, const double 
 // Registers: window 8 (2 NBLK + 4), record halves in flight 48, chunk in flight 32, W1 16: 256 at NBLK = 4.
 constexpr int QNC = 64;
 constexpr int QSTLD = 34;              // per-wave transposing buffer: 16 columns x 32 rows (+2), column-major
-constexpr int QOPSZ = 2 * QR * QVLD;   // doubles of the operand buffer: V image, then -V T image (row-major, QVLD)
+// LDS images of a record, laid out for the 64-bit reads of the two products (ds_read_b64: two groups of 32 lanes, 64
+// banks of 4 bytes -- MI355X_MICROARCH.md, LDS): the first product reads V by rows (lanes l15 = 16 consecutive columns,
+// l4 = four consecutive rows): leading dimension 32 with the two halves of every ODD row swapped, so the rows of a lane
+// group lie in opposite halves of the bank row; the second reads -(V T) by columns (lanes l15 = 16 rows, l4 = four
+// consecutive columns): leading dimension 34, 16 rows x 2 columns = 64 different banks.  With 33 for both (round 2:
+// right for 16-lane groups) every one of these reads took two LDS cycles per group: SQ_LDS_BANK_CONFLICT as large
+// as SQ_ACTIVE_INST_LDS.
+constexpr int QVS = QG, QTS = QG + 2;
+constexpr int QOPSZ = QR * QVS + QR * QTS;   // doubles of the operand buffer: V image, then -(V T) image
 constexpr unsigned kQ2Done = 0x7fffffffu;
 
 struct Q2ApplyArgs {
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
   double *st = q2smem + QOPSZ + wave * 16 * QSTLD;      // this wave's transposing buffer
   const int n = p.g.n;
-  const double *sV = sOp, *sVT = sOp + QR * QVLD;
+  const double *sV = sOp, *sVT = sOp + QR * QVS;
   while (true) {
     __syncthreads();
     if (t == 0) s_pass = (int)atomicAdd(&p.ctl[2], 1u);
@@ -968,7 +976,9 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
     constexpr int HALF = QR * QG / 2;                     // pairs per half
     double zreg[16];
     d2_t oreg[12];                                        // [0..5]: V of the next group, [6..11]: -(V T) of this / the next one
-    const int obase = (t >> 4) * QVLD + 2 * (t & 15);
+    const int obase_v = (t >> 4) * QVS + ((2 * (t & 15) + 16 * ((t >> 4) & 1)) & 31);   // (odd rows: halves swapped)
+    const int obase_t = (t >> 4) * QTS + 2 * (t & 15);
+    const int vsw = 16 * (l4 & 1);                        // first product: the column half this lane finds columns 0..15 of its row in
     auto rec_of = [&](int b, int k) -> const d2_t * {     // block b of the bundle, group k (no memory access: offb)
       unsigned o = offb[0];
 #pragma unroll
@@ -983,8 +993,8 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) oreg[6 + q] = rec[HALF + 256 * q];
     };
-    auto put_v = [&](int q) { double *d = sOp + obase + q * 16 * QVLD; d[0] = oreg[q][0]; d[1] = oreg[q][1]; };
-    auto put_t = [&](int q) { double *d = sOp + QR * QVLD + obase + q * 16 * QVLD; d[0] = oreg[6 + q][0]; d[1] = oreg[6 + q][1]; };
+    auto put_v = [&](int q) { *reinterpret_cast<d2_t *>(sOp + obase_v + q * 16 * QVS) = oreg[q]; };
+    auto put_t = [&](int q) { *reinterpret_cast<d2_t *>(sOp + QR * QVS + obase_t + q * 16 * QTS) = oreg[6 + q]; };
     const bool cols_in = colw + 16 <= p.ncols;
     // 64 rows from global row `row0` on -> zreg: lane = row, 16 columns (sc1: another pass may have written them)
     auto fetch_rows = [&](int row0) {
@@ -1052,8 +1062,8 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
       {
         double pa[PF + 1][2];
         auto ld1 = [&](int sidx, int slot) {
-          const double *vrow = sV + (16 * (sidx >> 2) + 4 * (sidx & 3) + l4) * QVLD + l15;
-          pa[slot][0] = vrow[0]; pa[slot][1] = vrow[16];
+          const double *vrow = sV + (16 * (sidx >> 2) + 4 * (sidx & 3) + l4) * QVS + l15;
+          pa[slot][0] = vrow[vsw]; pa[slot][1] = vrow[16 - vsw];
         };
 #pragma unroll
         for (int q = 0; q < PF; ++q) ld1(q, q);
@@ -1081,7 +1091,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
         auto seq_kk = [](int q) { return 4 * ((q & 15) >> 1); };
         auto seq_ok = [&](int q) { return !(seq_tile(q) == 5 && seq_kk(q) < 16); };
         auto ld2 = [&](int q, int slot) {
-          if (seq_ok(q)) px[slot] = sVT[(16 * seq_tile(q) + l15) * QVLD + l4 + seq_kk(q)];
+          if (seq_ok(q)) px[slot] = sVT[(16 * seq_tile(q) + l15) * QTS + l4 + seq_kk(q)];
         };
 #pragma unroll
         for (int q = 0; q < PF; ++q) ld2(q, q);
