@@ -198,6 +198,26 @@ def test_q2_application_does_not_depend_on_the_blocks_of_sweeps_per_pass(hip, n,
         assert np.linalg.norm(Q2.T @ Q2 - np.eye(n)) <= 64 * n * EPS
 
 
+def test_q2_application_keeps_the_bits_of_its_earlier_forms(hip):
+    """tests/golden/q2_anchor_digests.txt: SHA-256 of Z <- Q2 Z on fixed inputs (tools/q2_anchor.py), identical for round 2's
+    pair kernel and for every form of the kernel since (three and four blocks of sweeps per pass, the record written in
+    halves between the matrix instructions, the LDS images re-laid for the banking of 64-bit reads).  A change of these
+    digests means the arithmetic of the bulge chasing or of its back-transformation changed: legitimate only if
+    deliberate -- regenerate the file with the tool then."""
+    import hashlib
+    path = os.path.join(os.path.dirname(__file__), "golden", "q2_anchor_digests.txt")
+    for line in open(path):
+        n, ncols, flag, digest = line.split()
+        n, ncols = int(n), int(ncols)
+        M = np.random.RandomState(7 * n + 3).standard_normal((n, n))
+        M = np.tril(M) - np.tril(M, -(B + 1))
+        Bd = M + np.tril(M, -1).T
+        Z0 = np.random.RandomState(n).standard_normal((n, ncols))
+        d, e, Z, f = hip.sb2st(Bd, Z0)
+        assert f == int(flag)
+        assert hashlib.sha256(np.ascontiguousarray(Z).tobytes()).hexdigest()[:16] == digest, (n, ncols)
+
+
 @pytest.mark.parametrize("n", [777, 2100])
 def test_position_kernel_under_shaken_timing(hip, n):
     """Pseudo-random pauses of single positions (EK_SB2ST_JITTER) change which neighbour waits for which: a mail line
