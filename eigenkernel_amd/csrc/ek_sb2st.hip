@@ -1289,14 +1289,17 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
       if (const char *ev = getenv("EK_SB2ST_CENSUS_SPINS")) census = (unsigned)atoi(ev);
       PosArgs a{n, K0, AB, V2, ldv2, tau2, L.ldt, pmail, pmail + (size_t)4 * (L.kmax + 2) * PMAILW, retired, ctl, per, census, d_flag,
                 getenv("EK_SB2ST_JITTER") ? (unsigned)atoi(getenv("EK_SB2ST_JITTER")) : 0u, nullptr, -1};
+#ifdef EK_POS_TRACE
       static long long *trace_buf = nullptr;
       if (const char *ev = getenv("EK_SB2ST_TRACE")) {
         if (!trace_buf) (void)hipMalloc((void **)&trace_buf, 2048 * 16 * sizeof(long long));
         (void)hipMemsetAsync(trace_buf, 0, 2048 * 16 * sizeof(long long), s);
         a.trace = trace_buf; a.trace_k = atoi(ev);
       }
+#endif
       hipLaunchKernelGGL(chase_pos_kernel, dim3(per > 0 ? per * 8 : K0), dim3(512), 0, s, a);
       hipLaunchKernelGGL(repack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, AB0, AB, ctl);
+#ifdef EK_POS_TRACE
       if (a.trace) {                                         // diagnostic: average gaps between the stamps, sweeps 256 .. 2047
         static long long h[2048 * 16];
         (void)hipMemcpyAsync(h, a.trace, sizeof(h), hipMemcpyDeviceToHost, s);
@@ -1317,6 +1320,7 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
                   10 * acc[5] / cnt, 10 * acc[4] / cnt, 10 * acc[8] / cnt, 10 * acc[9] / cnt, 10 * acc[6] / cnt, 10 * acc[10] / cnt,
                   10 * acc[11] / cnt);
       }
+#endif
     }
     hipLaunchKernelGGL(mail_init_kernel, dim3(ceil_div(nmail, 256)), dim3(256), 0, s, mail, nmail);
     ChaseArgs c{n, L.nsweeps, AB, V2, ldv2, tau2, L.ldt, prog, ctl, mail, L.kmax + 1, nullptr, pos ? 1 : 0, d_flag};
