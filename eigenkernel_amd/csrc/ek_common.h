@@ -253,8 +253,11 @@ size_t stedc_work_bytes(int n);
 // D&C flops, then multiplies only those columns.  All n eigenvalues are always returned.
 struct StedcSelect { int nsel, nb, npcol, mycol; };
 // d_flops (optional, device): receives the flops of the merge products this solve executed (after deflation)
+// wscratch (optional): an n x n array with leading dimension ldz for the permuted bases of the merges; without it Z
+// itself serves (and must then be n x n even where only sel->nsel columns are wanted)
 void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z,
-           int ldz, void *work, int *d_info, const StedcSelect *sel = nullptr, double *d_flops = nullptr);
+           int ldz, void *work, int *d_info, const StedcSelect *sel = nullptr, double *d_flops = nullptr,
+           double *wscratch = nullptr);
 
 // ---------------------------------------------------------------- back-transformation (ek_ormtr.hip)
 size_t ormtr_work_bytes(int n, int ncols, int ncols_global = -1);   // ncols_global: columns of the whole Z (a grid cell holds ncols of them)

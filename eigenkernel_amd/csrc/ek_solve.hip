@@ -232,6 +232,11 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   const size_t wb_sytrd = dist ? sytrd_dist_work_bytes(n, g_comm.nranks) : sytrd_work_bytes(n),
                wb_stedc = stedc_work_bytes(n), wb_ormtr = ormtr_work_bytes(n, nc_loc, n_vec);
   const size_t mat = al((size_t)ld * ld * 8);
+  // the eigenvector work array holds the columns this call forms only (a grid cell's share, or the first n_vec of a
+  // *_select arm): the one work matrix of the path whose size falls with the number of ranks
+  // (the D&C takes the spent copy of the reduced matrix for its permuted bases then: two-stage orders only)
+  const int zcols = (nc_loc >= n || !(two_stage_min() > 0 && n >= two_stage_min() && n >= 3)) ? ld : round_up(nc_loc > 0 ? nc_loc : 1, 128);
+  const size_t zmat = al((size_t)ld * zcols * 8);
   size_t scratch = wb_sytrd;
   if (wb_stedc > scratch) scratch = wb_stedc;
   if (wb_ormtr > scratch) scratch = wb_ormtr;
@@ -255,7 +260,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   const size_t wb_sy2sb = two_stage ? al(dist ? sy2sb_dist_work_bytes(n, g_comm.nranks) : sy2sb_work_bytes(n)) : 0,
                wb_sb2st = two_stage ? al(sb2st_work_bytes(n)) : 0;
   const size_t wb_q1prep = two_stage ? al(ormtr_prep_bytes(n)) : 0;
-  const size_t ws_need = 4 * mat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
+  const size_t ws_need = 3 * mat + zmat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
                          4 * al((size_t)ld * 8) + sygst_scr + potrf_wb +
                          (two_stage ? 2 * mat + wb_sy2sb + wb_sb2st + wb_q1prep + al((size_t)ld * 8) : 0);
   rc = workspace(ws_need, &ws);
@@ -264,7 +269,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   Arena a(ws, g_ctx.ws_bytes);
   double *wA = a.get<double>((size_t)ld * ld);
   double *wB = a.get<double>((size_t)ld * ld);
-  double *wZ = a.get<double>((size_t)ld * ld);
+  double *wZ = a.get<double>((size_t)ld * zcols);
   double *wV = a.get<double>((size_t)ld * ld);
   double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
   double *twork = a.get<double>((size_t)128 * ld);
@@ -416,7 +421,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // forms only those (columns 0..nc_loc-1 of wZ) and the two remaining stages treat the
   // columns of Z independently
   const StedcSelect pick{nc_loc, cell ? cell->nb : (n > 0 ? n : 1), cell ? cell->npcol : 1, cell ? cell->mycol : 0};
-  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats);
+  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats, two_stage ? wA0 : nullptr);
   mark();                                                              // 5
   double *zc = wZ;
   // with a staging pipeline the LAST stage (the recovery; the back-transformation of a standard problem) runs in column

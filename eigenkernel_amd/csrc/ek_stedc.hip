@@ -682,7 +682,7 @@ __global__ void dc_flops_kernel(int nmerge, const int *__restrict__ gdims, doubl
 }  // namespace
 
 void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z, int ldz,
-           void *work, int *d_info, const StedcSelect *sel, double *d_flops) {
+           void *work, int *d_info, const StedcSelect *sel, double *d_flops, double *wscratch) {
   if (n <= 0) return;
   const WorkLayout L(n);
   char *base = (char *)work;
@@ -758,7 +758,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
   auto count_flops = [&]() {
     if (d_flops) hipLaunchKernelGGL(dc_flops_kernel, dim3(1), dim3(256), 0, s, (int)all.size(), b.gdims, d_flops);
   };
-  double *W = Z;   // the output array doubles as the permuted-basis scratch until the end
+  double *W = wscratch ? wscratch : Z;   // (the output array doubles as the permuted-basis scratch until the end)
   const bool selecting = sel && sel->nsel < n;
   bool sel_done = false;
   for (size_t lv = 0; lv < plan.levels.size(); ++lv) {
