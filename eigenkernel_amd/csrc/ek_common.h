@@ -80,7 +80,7 @@ void gather_block_cyclic(hipStream_t s, int mr, int nc, const double *src, int l
 void scatter_block_cyclic(hipStream_t s, int mr, int nc, const double *src, int lds, int nb, int pr,
                           int me_r, int pc, int me_c, double *dst, int ldd);
 
-void maxabs_lower(hipStream_t s, int n, const double *A, int lda, double *partial /* 256 */);
+void maxabs_lower(hipStream_t s, int n, const double *A, int lda, double *partial /* 512 */, int bw = 1 << 30);
 void scale_lower(hipStream_t s, int n, double alpha, double *A, int lda);
 void scale_vector(hipStream_t s, int n, double alpha, double *x);
 

@@ -248,7 +248,11 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   if (t == 0) {
     double dmax = 0.0;
     for (int w = 0; w < 4; ++w) dmax = (s_red[w] > dmax || s_red[w] != s_red[w]) ? s_red[w] : dmax;
-    if (!(dmax <= 0.25)) atomicOr(p.flag, 2);
+    // max |Q1^T Q1 - I| after the first pass is eps kappa^2 (up to a modest factor): CholeskyQR2 itself would still
+    // orthogonalise up to kappa ~ 1e7, but Q1 = A R1^-1 is formed with the EXPLICIT inverse, whose error is eps kappa(R1)
+    // relative to A -- a band of half width 65 (first panel: a random triangle, kappa ~ 1e7) came out with eigenvalues
+    // 1.5e-9 off.  1e-9 keeps kappa below ~1e3 (dense random panels sit at 1e-14 .. 1e-12); the rest goes to the rescue.
+    if (!(dmax <= 1e-9)) atomicOr(p.flag, 2);
   }
   if (prof) tc[nt++] = clock64();
   if (chol64_upper_wg(sA, s_inv) >= 0 && t == 0) atomicOr(p.flag, 1);        // sA = R2

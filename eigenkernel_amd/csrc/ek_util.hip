@@ -105,19 +105,26 @@ __global__ void synth_kernel(int n, unsigned long long seed, double inv, double 
 }
 
 // out[0] = max |A(i,j)| over the lower triangle (one workgroup, grid-stride; tiny vs the solve)
+// (partial[gridDim.x + blockIdx.x]: the same over the entries more than `bw` below the diagonal -- all zero for a matrix
+// that is already a band of that half width)
 __global__ __launch_bounds__(1024) void maxabs_lower_kernel(int n, const double *__restrict__ A, int lda,
-                                                            double *__restrict__ partial) {
+                                                            double *__restrict__ partial, int bw) {
   __shared__ double red[1024];
-  double m = 0.0;
+  double m = 0.0, mo = 0.0;
   for (int j = blockIdx.x; j < n; j += gridDim.x)
     for (int i = j + threadIdx.x; i < n; i += 1024) {
       const double v = fabs(A[(size_t)i + (size_t)j * lda]);
-      m = (v <= 1.7e308) ? fmax(m, v) : INFINITY;        // NaN and Inf both surface as Inf
+      const double w = (v <= 1.7e308) ? v : INFINITY;    // NaN and Inf both surface as Inf
+      m = fmax(m, w);
+      if (i - j > bw) mo = fmax(mo, w);
     }
-  red[threadIdx.x] = m;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+  for (int pass = 0; pass < 2; ++pass) {
+    red[threadIdx.x] = pass ? mo : m;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) partial[pass * gridDim.x + blockIdx.x] = red[0];
+    __syncthreads();
+  }
 }
 
 __global__ void scale_lower_kernel(int n, double alpha, double *A, int lda) {
@@ -194,9 +201,10 @@ void synth_matrix(hipStream_t s, int n, unsigned long long seed, double *M, int 
   hipLaunchKernelGGL(synth_kernel, grid2d(n, n), dim3(256), 0, s, n, seed, 1.0 / sqrt((double)n), M, ldm);
 }
 
-// partial: >= 256 doubles (device); the caller reduces the 256 partial maxima on the host
-void maxabs_lower(hipStream_t s, int n, const double *A, int lda, double *partial) {
-  hipLaunchKernelGGL(maxabs_lower_kernel, dim3(256), dim3(1024), 0, s, n, A, lda, partial);
+// partial: >= 512 doubles (device); the caller reduces the 256 partial maxima on the host ([256 ..): the maxima over
+// the entries more than `bw` below the diagonal)
+void maxabs_lower(hipStream_t s, int n, const double *A, int lda, double *partial, int bw) {
+  hipLaunchKernelGGL(maxabs_lower_kernel, dim3(256), dim3(1024), 0, s, n, A, lda, partial, bw);
 }
 void scale_lower(hipStream_t s, int n, double alpha, double *A, int lda) {
   if (n <= 0) return;

@@ -342,13 +342,17 @@ def test_panels_cholesky_qr_cannot_factor_are_rescued_inside_the_stage(hip, orac
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 64 * n * EPS
     assert np.linalg.norm(Q.T @ A @ Q - _band_of(Ab)) <= 32 * n * EPS * nrm
     w_or = np.linalg.eigvalsh(A)
-    ep, _ = hip.eigen_solver("hip", A)
-    assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * max(np.abs(w_or).max(), 1.0)
-    _check_pairs(A, None, ep.values, ep.Vectors)
     import ctypes
     st = (ctypes.c_double * 8)()
-    hip.load_library().ek_hip_debug_last_solve_stats(st, 8)
-    assert st[1] == 1.0                             # the solve stayed on the two-stage path
+    os.environ["EK_HIP_BAND_INPUT"] = "0"           # (a band on entry would skip the stage this test is about)
+    try:
+        ep, _ = hip.eigen_solver("hip", A)
+        hip.load_library().ek_hip_debug_last_solve_stats(st, 8)
+    finally:
+        os.environ.pop("EK_HIP_BAND_INPUT", None)
+    assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * max(np.abs(w_or).max(), 1.0)
+    _check_pairs(A, None, ep.values, ep.Vectors)
+    assert st[1] == 1.0 and st[3] == 0.0            # the solve stayed on the two-stage path, first stage included
 
 
 def test_reference_matrix_through_two_stages(hip, golden_dir, forced_two_stage):
@@ -364,6 +368,39 @@ def test_reference_matrix_through_two_stages(hip, golden_dir, forced_two_stage):
     st = (ctypes.c_double * 8)()
     hip.load_library().ek_hip_debug_last_solve_stats(st, 8)
     assert st[1] == 1.0
+
+
+@pytest.mark.parametrize("halfwidth,taken", [(0, True), (4, True), (64, True), (65, False), (100, False), (200, False)])
+def test_a_band_on_entry_skips_the_dense_to_band_stage(hip, halfwidth, taken):
+    """A standard problem whose matrix has nothing below its 64th subdiagonal is already what the first stage would
+    produce (the reference's sparse Hamiltonians are often banded): the solve goes straight to the bulge chasing and Q1 is
+    the identity.  One subdiagonal more and it is a dense matrix like any other -- whose first panels are random
+    TRIANGLES (condition ~1e7): CholeskyQR2 orthogonalises them, but forming Q1 with the explicit inverse of R1 lost
+    seven digits (eigenvalues 1.5e-9 off) until the stage's acceptance test was tightened to send them to the Householder
+    rescue.  Same pairs either way."""
+    import ctypes
+    n = 1500
+    rng = np.random.default_rng(11 + halfwidth)
+    M = np.tril(rng.standard_normal((n, n))); M = M - np.tril(M, -(halfwidth + 1))
+    A = M + np.tril(M, -1).T
+    w_or = np.linalg.eigvalsh(A)
+    st = (ctypes.c_double * 8)()
+    ep, _ = hip.eigen_solver("hip", A)
+    hip.load_library().ek_hip_debug_last_solve_stats(st, 8)
+    assert st[1] == 1.0 and (st[3] == 1.0) == taken
+    assert np.abs(ep.values - w_or).max() <= 4 * n * EPS * max(np.abs(w_or).max(), 1.0)
+    _check_pairs(A, None, ep.values, ep.Vectors)
+    eps, _ = hip.eigen_solver("hip_select", A, n_vec=100)
+    assert np.abs(eps.values[:100] - w_or[:100]).max() <= 4 * n * EPS * max(np.abs(w_or).max(), 1.0)
+    _check_pairs(A, None, eps.values, eps.Vectors, n_vec=100)
+    os.environ["EK_HIP_BAND_INPUT"] = "0"
+    try:
+        ep0, _ = hip.eigen_solver("hip", A)
+        hip.load_library().ek_hip_debug_last_solve_stats(st, 8)
+    finally:
+        os.environ.pop("EK_HIP_BAND_INPUT", None)
+    assert st[3] == 0.0
+    assert np.abs(ep0.values - ep.values).max() <= 4 * n * EPS * max(np.abs(w_or).max(), 1.0)
 
 
 @pytest.mark.parametrize("kind", ["banded", "sparse_pattern", "low_rank_plus_identity"])
