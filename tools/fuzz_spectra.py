@@ -73,5 +73,31 @@ for kb in (1e2, 1e5, 1e8, 1e11):
     bad += bool(flag)
     print("GEP cond(B) %.0e  dlam/(n eps cond |lam|) %8.2e  res %10.2f (LAPACK %10.2f)  orth %10.2f (LAPACK %10.2f)  (n eps)%s" %
           (kb, err, res, res0, orth, orth0, flag), flush=True)
+# the reference's family: sparse / banded Hamiltonian A with a banded, diagonally dominant overlap B
+def banded(hw, diag):
+    M = np.tril(rng.standard_normal((n, n))); M = M - np.tril(M, -(hw + 1)); M = M + np.tril(M, -1).T
+    return M + diag * np.eye(n)
+
+
+pairs = [("A band 5, B band 5", banded(5, 0.0), 0.05 * banded(5, 0.0) + np.eye(n)),
+         ("A band 40, B = I", banded(40, 0.0), np.eye(n)),
+         ("A band 3, B diagonal", banded(3, 0.0), np.diag(rng.uniform(0.5, 2.0, n))),
+         ("A = B", None, None), ("A = 0", np.zeros((n, n)), 0.1 * banded(8, 0.0) + 2 * np.eye(n)),
+         ("A dense, B band 64 decaying", (lambda G: G + G.T)(rng.standard_normal((n, n))),
+          np.exp(-np.abs(np.subtract.outer(np.arange(n), np.arange(n))) / 3.0) * (np.abs(np.subtract.outer(np.arange(n), np.arange(n))) <= 64))]
+for name, A2, B2 in pairs:
+    if A2 is None:
+        B2 = 0.1 * banded(8, 0.0) + 2 * np.eye(n); A2 = B2.copy()
+    w0, Z0 = sl.eigh(A2, B2)
+    ep, _ = solver.eigen_solver("general_hip", np.asfortranarray(A2), np.asfortranarray(B2))
+    sc = max(np.abs(w0).max(), 1e-300)
+    err = np.abs(ep.values - w0).max() / (n * EPS * max(sc, 1.0))
+    Z = ep.Vectors
+    R = A2 @ Z - (B2 @ Z) * ep.values
+    res = np.abs(R).max() / (n * EPS * max(np.abs(A2).max(), np.abs(B2).max() * sc, 1e-300))
+    orth = np.abs(Z.T @ B2 @ Z - np.eye(n)).max() / (n * EPS)
+    flag = "" if (err <= 8 and res <= 16 and orth <= 16) else "   <-- BAD"
+    bad += bool(flag)
+    print("GEP %-30s dlam %6.2f  res %6.2f  orth %6.2f  (n eps)%s" % (name, err, res, orth, flag), flush=True)
 print("BAD:", bad)
 sys.exit(1 if bad else 0)
