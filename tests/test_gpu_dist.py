@@ -119,6 +119,30 @@ def test_dense_to_band_team_rehearsal(hip, oracle, n, P):
     assert orth <= 64 * n * EPS and sim <= 32 * n * EPS and ev <= 4 * n * EPS
 
 
+@pytest.mark.parametrize("kind", ["band65", "band4", "parallel_columns", "zero_column"])
+@pytest.mark.parametrize("n,P", [(600, 3)])
+def test_dense_to_band_team_rescues_panels(hip, oracle, kind, n, P):
+    """Panels CholeskyQR2 cannot (or should not: condition beyond ~1e3) factor are factored by Householder reflections on
+    the strip's owner and broadcast like any other panel: same bits on every member, an orthogonal similarity to a band."""
+    rng = np.random.default_rng(n + P)
+    if kind.startswith("band"):
+        hw = int(kind[4:])
+        M = np.tril(rng.standard_normal((n, n))); M = M - np.tril(M, -(hw + 1)); A = M + np.tril(M, -1).T
+    else:
+        A = oracle.synth_matrix(n, 1)
+        if kind == "parallel_columns":
+            A[64:, 5] = A[64:, 4] * (1.0 + 1e-7); A[5, 64:] = A[64:, 5]
+            A[200:, 150] = A[200:, 149] + 1e-6 * rng.standard_normal(n - 200); A[150, 200:] = A[200:, 150]
+        else:
+            A[64:, 3] = 0.0; A[3, 64:] = 0.0
+    Ab, V, tau, flag, mism = hip.sy2sb_team(A, P)
+    assert flag & 0xff == 0 and mism == 0
+    assert flag >> 8 >= 1                            # at least one panel took the rescue
+    assert np.abs(np.tril(Ab, -65)).max() == 0.0
+    orth, sim, ev = _band_similarity(A, Ab, V, tau)
+    assert orth <= 64 * n * EPS and sim <= 32 * n * EPS and ev <= 4 * n * EPS
+
+
 def test_dense_to_band_team_reads_only_owned_strips(hip, oracle, monkeypatch):
     """Every member's copy of the matrix is NaN outside its own 128-wide strips: the team form must neither read nor
     need them (what the distributed reduction to standard form leaves behind)."""
