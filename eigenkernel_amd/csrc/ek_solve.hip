@@ -105,7 +105,8 @@ void extract_local(int m, int n, const double *M_full, int ldf, const int *desc,
 // is why the copies have threads of their own; a matrix is cut into column pieces so that two threads share it.
 struct HostPipe {
   struct Job { double *dev; int ldd; double *host; int ldh; int m, n; hipEvent_t after; int tag; bool to_host; };
-  static constexpr int kThreads = 2;         // per direction
+  static constexpr int kMaxThreads = 8;
+  int kThreads = 2;                          // per direction (EK_HIP_PIPE_THREADS)
   std::mutex mu;
   std::condition_variable cv;
   std::deque<Job> in_q, out_q;
@@ -114,13 +115,14 @@ struct HostPipe {
   bool closing = false;
   int err = 0;
   std::vector<std::thread> th;
-  hipStream_t cs[2 * kThreads] = {};
+  hipStream_t cs[2 * kMaxThreads] = {};
   int device = 0;
   int z_slab = 2048;
 
   int start(int dev) {
     device = dev;
-    for (auto &c : cs) EK_HIP_CHECK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    if (const char *e = getenv("EK_HIP_PIPE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxThreads) kThreads = v; }
+    for (int i = 0; i < 2 * kThreads; ++i) EK_HIP_CHECK(hipStreamCreateWithFlags(&cs[i], hipStreamNonBlocking));
     for (int i = 0; i < 2 * kThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i]); });
     return 0;
   }
