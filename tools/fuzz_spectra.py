@@ -54,6 +54,19 @@ for name, A in std:
     flag = "" if (err <= 4 and res <= 16 and orth <= 16) else "   <-- BAD"
     bad += bool(flag)
     print("SEP %-28s dlam %6.2f  res %6.2f  orth %6.2f  (n eps)%s" % (name, err, res, orth, flag), flush=True)
+# the *_select arms where the cut falls inside a cluster, at a multiplicity, at the ends
+for name, A in std[:5]:
+    A = np.asfortranarray(A); w0 = np.linalg.eigvalsh(A); sc = max(np.abs(w0).max(), 1e-300)
+    for nv in (1, 37, n // 2, n - 1):
+        ep, _ = solver.eigen_solver("hip_select", A, n_vec=nv)
+        Z = ep.Vectors[:, :nv]; w = ep.values[:nv]
+        err = np.abs(w - w0[:nv]).max() / (n * EPS * sc)
+        res = np.abs(A @ Z - Z * w).max() / (n * EPS * sc)
+        orth = np.abs(Z.T @ Z - np.eye(nv)).max() / (n * EPS)
+        flag = "" if (err <= 4 and res <= 16 and orth <= 16) else "   <-- BAD"
+        bad += bool(flag)
+        if flag: print("SEL %-28s n_vec %5d dlam %6.2f  res %6.2f  orth %6.2f  (n eps)%s" % (name, nv, err, res, orth, flag), flush=True)
+print("select arms on the first five spectra done", flush=True)
 A = (lambda G: G + G.T)(rng.standard_normal((n, n)))
 for kb in (1e2, 1e5, 1e8, 1e11):
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
