@@ -64,7 +64,8 @@ int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds);
  * executed (2 M N K over both GEMMs of every merge, with the dimensions deflation and the column selection left
  * on the device: what bench.py prices that stage with, the nominal 4 n^3 / 3 being an upper bound), out[1] = 1
  * if the tridiagonalisation ran in two stages, out[2] = panels of the dense -> band stage that CholeskyQR2 could not
- * factor and the Householder rescue did. */
+ * factor and the Householder rescue did, out[3] = 1 if the matrix was already a band of half width 64 on entry and
+ * the dense -> band stage (and Q1) were skipped. */
 int ek_hip_debug_last_solve_stats(double *out, int count);
 
 #ifdef __cplusplus
