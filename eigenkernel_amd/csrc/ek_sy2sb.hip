@@ -36,6 +36,9 @@ static_assert(SB == kBandW, "the panel width is the width of the 64x64 building 
 // launches, and 64-row chunks put twice as many workgroups on each of them as 128-row chunks did
 // (stage 1 at N = 4096: 19.7 -> 17.7 ms, N = 16384: 215.7 -> 210.0 ms, N = 32768: 1.387 -> 1.382 s)
 constexpr int CH = 64;
+#ifndef EK_CHOLQR_MAXDEV
+#define EK_CHOLQR_MAXDEV 0.25      // largest |Q1^T Q1 - I| after the first CholeskyQR pass that the second pass is trusted with
+#endif
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS operations have completed
@@ -56,6 +59,7 @@ struct PanelArgs {
   double *Apanel; int lda;  // the panel inside A, at (r0, c0)
   double *Vimg; int ldi;    // [W | V | W] image: V goes to columns 64..127
   const int *pflag;         // FINAL pass: non-zero = this panel goes to the rescue: leave it untouched
+  int *nz;                  // MODE 0: *nz = 1 + the last 64-row chunk of the panel that is not all zeros (atomic max)
 };
 
 // out slab (64 x 64, LDS, row-major) = in slab * M^T-image; see mm64 for the operand convention
@@ -75,6 +79,49 @@ __device__ __forceinline__ void slab_mul(const double *sS, const double *sMT, do
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) sO[(i0 + l4 + 4 * r) * LD + 16 * jt + l15] = acc[jt][r];
+}
+
+// out slab X (64 x 64) with X R = in slab, R upper triangular (sR[i * LD + j] = R(i, j), srd[j] = 1 / R(j, j)): row by
+// row a forward substitution -- backward stable whatever the condition of R, where the product with an explicitly formed
+// R^-1 leaves eps cond(R) (a panel of condition 1e7 lost seven digits that way).  Wave w owns rows 16 w .. 16 w + 15: the
+// 16 x 16 diagonal blocks by substitution (lane = row; R's entries are broadcast reads), the blocks to their right on
+// the matrix cores; nothing crosses a wave, so no workgroup barrier inside.  The in slab is overwritten.
+__device__ __forceinline__ void slab_solve_upper(double *sS, const double *sR, const double *srd, double *sO) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int i0 = 16 * wave;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (lane < 16) {
+      double a[16];
+      const double *row = sS + (i0 + lane) * LD + 16 * b;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = row[c];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double x = a[j] * srd[16 * b + j];
+        a[j] = x;
+        const double *rr = sR + (16 * b + j) * LD + 16 * b;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] = __builtin_fma(-x, rr[c], a[c]);
+      }
+      double *out = sO + (i0 + lane) * LD + 16 * b;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) out[c] = a[c];
+    }
+    wave_sync();
+#pragma unroll
+    for (int bp = b + 1; bp < 4; ++bp) {
+      double4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sS[(i0 + l4 + 4 * r) * LD + 16 * bp + l15];
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sO[(i0 + l15) * LD + 16 * b + kk + l4], sR[(16 * b + kk + l4) * LD + 16 * bp + l15], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sS[(i0 + l4 + 4 * r) * LD + 16 * bp + l15] = acc[r];
+    }
+    wave_sync();
+  }
 }
 
 // G(i, j) += sum_r X(r, i) Y(r, j) over the 64 rows of two LDS slabs; wave w owns rows 16 w .. of G
@@ -97,14 +144,18 @@ __device__ __forceinline__ void store_gram(const double4_t (&acc)[4], double *G)
     for (int r = 0; r < 4; ++r) G[(16 * jt + l15) + SB * (16 * wave + l4 + 4 * r)] = acc[jt][r];
 }
 
-// MODE 0: Gram of src.  MODE 1: dst = src M, Gram of dst.  MODE 2: final pass (V = src M below the
-// top block, L1 in it) with the writes of the reflectors.
+// MODE 0: Gram of src.  MODE 1: dst = src M^-1 for the upper triangular M = R1 (by substitution), Gram of dst.
+// MODE 2: final pass (V = src M below the top block, L1 in it) with the writes of the reflectors.
 template <int MODE>
 __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p) {
-  __shared__ double sS[IMG], sO[IMG], sMT[MODE ? IMG : 1];
+  __shared__ double sS[IMG], sO[IMG], sMT[MODE ? IMG : 1], s_rd[MODE == 1 ? SB : 1];
   const int t = threadIdx.x, r = t & 63, cg = t >> 6;
   if (MODE == 2 && p.pflag && *p.pflag) return;
-  if (MODE) {
+  if (MODE == 1) {                                   // sMT(i, j) = R1(i, j) as stored (column-major in memory), 1 / diagonal
+    for (int idx = t; idx < SB * SB; idx += 256) sMT[(idx & 63) * LD + (idx >> 6)] = p.M[idx];
+    if (t < SB) s_rd[t] = 1.0 / p.M[t + SB * t];
+  }
+  if (MODE == 2) {
     for (int idx = t; idx < SB * SB; idx += 256) {
       const int k = idx & 63, j = idx >> 6;
       sMT[j * LD + k] = p.M[k + SB * j];
@@ -118,14 +169,23 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p) {
     if (row0 >= p.m) break;
     const int row = row0 + r;
     __syncthreads();
+    bool any = false;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const int col = 16 * cg + c;
-      sS[r * LD + col] = (row < p.m) ? p.src[(size_t)row + (size_t)col * p.lds_] : 0.0;
+      const double v = (row < p.m) ? p.src[(size_t)row + (size_t)col * p.lds_] : 0.0;
+      sS[r * LD + col] = v;
+      any = any || v != 0.0;
     }
+    if (MODE == 0 && p.nz && __any(any) && (t & 63) == 0) atomicMax(p.nz, (int)blockIdx.x * (CH / SB) + slab + 1);
     __syncthreads();
     const double *sOut = sS;
-    if (MODE) {
+    if (MODE == 1) {
+      slab_solve_upper(sS, sMT, s_rd, sO);
+      __syncthreads();
+      sOut = sO;
+    }
+    if (MODE == 2) {
       slab_mul(sS, sMT, sO);
       __syncthreads();
       sOut = sO;
@@ -198,11 +258,11 @@ __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G,
   const int zero_panel = !s_nz;
   const int bad = chol64_upper_wg(sA, s_inv);
   if (t == 0) *pflag = zero_panel ? 4 : ((bad >= 0) ? 1 : 0);
-  triinv64_upper_wg(sA, sB, s_inv);
+  (void)Rinv; (void)sB;                                    // (no explicit inverse: the panel is divided by R1 by substitution)
+  __syncthreads();
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
     R[idx] = sA[i * LD + j];
-    Rinv[idx] = sB[i * LD + j];
   }
 }
 
@@ -248,11 +308,11 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   double dmax = 0.0;
   for (int w = 0; w < 4; ++w) dmax = (s_red[w] > dmax || s_red[w] != s_red[w]) ? s_red[w] : dmax;
   if (t == 0) {
-    // max |Q1^T Q1 - I| after the first pass is eps kappa^2 (up to a modest factor): CholeskyQR2 itself would still
-    // orthogonalise up to kappa ~ 1e7, but Q1 = A R1^-1 is formed with the EXPLICIT inverse, whose error is eps kappa(R1)
-    // relative to A -- a band of half width 65 (first panel: a random triangle, kappa ~ 1e7) came out with eigenvalues
-    // 1.5e-9 off.  1e-9 keeps kappa below ~1e3 (dense random panels sit at 1e-14 .. 1e-12); the rest goes to the rescue.
-    if (!(dmax <= 1e-9)) atomicOr(p.flag, 2);
+    // max |Q1^T Q1 - I| after the first pass is eps kappa^2 (up to a modest factor): up to 0.25 (kappa ~ 1e7) the
+    // second pass orthogonalises to rounding.  (Q1 = A R1^-1 is formed by SUBSTITUTION: with the explicit inverse of R1,
+    // as until the end of round 3, its error was eps kappa(R1) relative to A -- a band of half width 65, whose panels are
+    // random triangles of kappa ~ 1e7, came out with eigenvalues 1.5e-9 off.)  The rest goes to the rescue.
+    if (!(dmax <= EK_CHOLQR_MAXDEV)) atomicOr(p.flag, 2);
   }
   if (prof) tc[nt++] = clock64();
   if (dmax <= 1e-10) {                                                   // (uniform)
@@ -450,12 +510,17 @@ __device__ __forceinline__ void ht_reduce(double (&a)[K], double *s_part /* [HT 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(HT) void house_tall_kernel(int m, double *__restrict__ P, int ldp, double *__restrict__ tau_out,
-                                                        const int *pflag, int *d_flag) {
+// nz: 1 + the last 64-row chunk of the panel with a non-zero entry (panel_kernel<0>): the rows below are exactly zero and
+// stay zero under every reflector, so the walk stops there -- the panels of a matrix that is nearly a band (the
+// reference's sparse Hamiltonians) cost a few hundred rows each instead of the full height.
+__global__ __launch_bounds__(HT) void house_tall_kernel(int m_full, double *__restrict__ P, int ldp, double *__restrict__ tau_out,
+                                                        const int *pflag, int *d_flag, const int *nz) {
   __shared__ double s_part[(HT / 64) * HB * HB], s_out[HB * HB];
   __shared__ double s_T[HB * HB], s_X[HB * HB], s_tau[SB];
   if (!*pflag) return;
   const int t = threadIdx.x;
+  int m = m_full;
+  if (nz) { const int me = *nz * SB; if (me < m) m = (me > SB + 1) ? me : ((SB + 1 < m) ? SB + 1 : m); }
   if (t == 0) atomicAdd(d_flag, 256);                      // bits 8..: panels that took this path (informational)
   if (*pflag & 4) {                                        // the panel is exactly zero: R = 0, H = I
     if (t < SB) tau_out[t] = 0.0;
@@ -966,6 +1031,7 @@ struct ChainBufs {
   double *Qt, *Gpart2, *Gred2, *R1, *R1inv, *M2, *L1, *Rband;
   long long *prof;
   int *pflag;               // the flag of the panel in flight (device)
+  int *nzrows;              // [panel]: 1 + the last non-zero 64-row chunk of the panel (zeroed at the start of the stage)
 };
 
 void ensure_attrs() {
@@ -993,11 +1059,11 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
     return;
   }
   PanelArgs pa{};
-  pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = b.Gpart2;
+  pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = b.Gpart2; pa.nz = b.nzrows ? b.nzrows + c0 / SB : nullptr;
   hipLaunchKernelGGL(panel_kernel<0>, dim3(nch), dim3(256), 0, st, pa);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2);
   hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, b.Gred2, b.R1, b.R1inv, b.pflag);
-  pa.M = b.R1inv; pa.dst = b.Qt; pa.ldd = b.mpad;
+  pa.M = b.R1; pa.dst = b.Qt; pa.ldd = b.mpad;           // (Q1 = A R1^-1 by substitution against R1 itself)
   hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, st, pa);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2);
   HrArgs ha{b.Gred2, b.Qt, b.mpad, b.R1, b.M2, Tp, b.L1, b.Rband, tau1 + c0, b.pflag, b.prof};
@@ -1007,7 +1073,8 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
   pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vimg = Vimg; pf.ldi = ldi; pf.pflag = b.pflag;
   hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, st, pf);
   // the rescue of a panel CholeskyQR2 could not factor (the four kernels leave at once otherwise)
-  hipLaunchKernelGGL(house_tall_kernel, dim3(1), dim3(HT), 0, st, m, Ap, lda, tau1 + c0, b.pflag, d_flag);
+  hipLaunchKernelGGL(house_tall_kernel, dim3(1), dim3(HT), 0, st, m, Ap, lda, tau1 + c0, b.pflag, d_flag,
+                     b.nzrows ? b.nzrows + c0 / SB : nullptr);
   TallFinishArgs tf{m, Ap, lda, Vp, ldv, Vimg, ldi, b.Gpart2, b.pflag};
   hipLaunchKernelGGL(tall_finish_kernel, dim3(nch), dim3(256), 0, st, tf);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2, b.pflag);
@@ -1076,8 +1143,10 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   static int la_min = -1;
   if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 5120; }
 
+  int *nzrows = (int *)(sm + 13 * 4096);               // one word per panel (room for 8192)
+  (void)hipMemsetAsync(nzrows, 0, (size_t)ceil_div(n, SB) * sizeof(int), s);
   const ChainBufs cb{n, L.mpad, Qt, Gpart2, Gred2, R1, R1inv, M2, L1, Rband, prof ? (long long *)(sm + 10 * 4096) : nullptr,
-                     (int *)(sm + 12 * 4096)};
+                     (int *)(sm + 12 * 4096), nzrows};
   auto panel_chain = [&](hipStream_t st, int c0, double *Vimg, double *Tp) {
     ek::panel_chain(st, cb, A, lda, Vall, ldv, tau1, d_flag, c0, Vimg, Tp);
   };
@@ -1173,7 +1242,8 @@ void sy2sb_lower_dist(hipStream_t s, int n, int nmem, const Sy2sbMember *mem, co
     m.msg = (double *)(w + L.off_msg); m.offs = (long long *)(w + L.off_offs); m.dims = (int *)(w + L.off_dims);
     double *sm = m.sm;
     m.cb = ChainBufs{n, L.mpad, m.Qt, (double *)(w + L.off_gpart2), sm + 11 * 4096, sm + 4096, sm + 2 * 4096, sm + 3 * 4096,
-                     sm + 5 * 4096, sm + 6 * 4096, nullptr, (int *)(sm + 12 * 4096)};
+                     sm + 5 * 4096, sm + 6 * 4096, nullptr, (int *)(sm + 12 * 4096), (int *)(sm + 13 * 4096)};
+    (void)hipMemsetAsync(sm + 13 * 4096, 0, (size_t)ceil_div(n, SB) * sizeof(int), s);
     msgs[q] = m.msg; ys[q] = m.Y;
     hipLaunchKernelGGL(strip_table_kernel, dim3(L.npanels), dim3(round_up(L.maxb, 64)), 0, s, n, mem[q].lda, P, mem[q].rank,
                        L.maxb, m.offs, m.dims);

@@ -376,8 +376,7 @@ def test_a_band_on_entry_skips_the_dense_to_band_stage(hip, halfwidth, taken):
     produce (the reference's sparse Hamiltonians are often banded): the solve goes straight to the bulge chasing and Q1 is
     the identity.  One subdiagonal more and it is a dense matrix like any other -- whose first panels are random
     TRIANGLES (condition ~1e7): CholeskyQR2 orthogonalises them, but forming Q1 with the explicit inverse of R1 lost
-    seven digits (eigenvalues 1.5e-9 off) until the stage's acceptance test was tightened to send them to the Householder
-    rescue.  Same pairs either way."""
+    seven digits (eigenvalues 1.5e-9 off); Q1 = A R1^-1 is formed by substitution since.  Same pairs either way."""
     import ctypes
     n = 1500
     rng = np.random.default_rng(11 + halfwidth)

@@ -26,6 +26,13 @@ def make(kind):
             A[np.arange(d, n), np.arange(0, n - d)] = v
             A[np.arange(0, n - d), np.arange(d, n)] = v
         return A
+    if kind == "band65":      # one subdiagonal more than the band: every panel a random triangle (condition ~1e7): all rescued
+        A = np.zeros((n, n), order="F")
+        for d in range(66):
+            v = rng.standard_normal(n - d)
+            A[np.arange(d, n), np.arange(0, n - d)] = v
+            A[np.arange(0, n - d), np.arange(d, n)] = v
+        return A
     if kind == "diagonal":
         return np.asfortranarray(np.diag(rng.uniform(1, 2, n)))
     if kind == "low_rank_plus_identity":
@@ -44,7 +51,7 @@ def make(kind):
 lib = hip.load_library()
 st = (ctypes.c_double * 8)()
 base = None
-for kind in ("dense", "sparse_pattern", "banded", "diagonal", "low_rank_plus_identity"):
+for kind in ("dense", "sparse_pattern", "banded", "band65", "diagonal", "low_rank_plus_identity"):
     A = make(kind)
     for rep in range(2):
         t0 = time.time()
