@@ -192,37 +192,44 @@ SytrdExchange team_exchange(int nteam, int n) {
   return x;
 }
 
+// One small all-reduce of a status word over the attached communicator.  A sticky exchange error recorded earlier in
+// the call (g_comm.err: the stages' exchanges set it and go on) is neither erased nor kept private: it travels in the
+// word's high part, so every rank learns that SOME rank's exchange failed, and the local record survives the vote.
+constexpr double kVoteErr = 1048576.0;       // (> kMaxTeam: the low part counts the ranks that raised `local`)
+static bool comm_vote(int local, double *sum) {
+  const SytrdExchange x = team_exchange(0);
+  const int prev = g_comm.err;
+  double st = (local ? 1.0 : 0.0) + (prev ? kVoteErr : 0.0);
+  bool ok = hipMemcpy(g_ctx.d_status, &st, sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  double *bufs[1] = {g_ctx.d_status};
+  g_comm.err = 0;
+  x.allreduce(g_ctx.stream, 1, bufs, 1, x.user);
+  ok = ok && hipStreamSynchronize(g_ctx.stream) == hipSuccess && !g_comm.err;
+  ok = ok && hipMemcpy(&st, g_ctx.d_status, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  if (prev) g_comm.err = prev;               // (else: whatever the vote's own exchange recorded stays)
+  *sum = st;
+  return ok;
+}
+
+// 1 if `local` is non-zero on ANY rank of the team (the same answer on all of them), else 0; -996 on every rank if the
+// vote itself or an earlier exchange of the call failed on any of them
+int comm_any(int local) {
+  if (!g_comm.on || g_comm.nranks <= 1) return g_comm.err ? -996 : (local ? 1 : 0);
+  double st = 0.0;
+  if (!comm_vote(local, &st) || st >= kVoteErr) return -996;
+  return st != 0.0 ? 1 : 0;
+}
+
 // A rank-local failure (allocation, staging copy) in front of a collective part of a call must not leave
 // the other ranks waiting in that collective: every rank contributes its status to one small all-reduce
 // over the attached communicator and all of them leave together -- the failing rank with its own code,
 // the others with -993.  Returns 0 when every rank is fine.  (The word lives in memory allocated at
 // initialisation, so the agreement itself needs nothing that could fail locally.)
-// 1 if `local` is non-zero on ANY rank of the team (the same answer on all of them), else 0; < 0: the exchange failed
-int comm_any(int local) {
-  if (!g_comm.on || g_comm.nranks <= 1) return local ? 1 : 0;
-  const SytrdExchange x = team_exchange(0);
-  double st = local ? 1.0 : 0.0;
-  bool ok = hipMemcpy(g_ctx.d_status, &st, sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-  double *bufs[1] = {g_ctx.d_status};
-  g_comm.err = 0;
-  x.allreduce(g_ctx.stream, 1, bufs, 1, x.user);
-  ok = ok && hipStreamSynchronize(g_ctx.stream) == hipSuccess && !g_comm.err;
-  ok = ok && hipMemcpy(&st, g_ctx.d_status, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
-  if (!ok) return -996;
-  return st != 0.0 ? 1 : 0;
-}
-
 int comm_agree(int local_rc) {
   if (!g_comm.on || g_comm.nranks <= 1) return local_rc;
-  const SytrdExchange x = team_exchange(0);
-  double st = local_rc ? 1.0 : 0.0;
-  bool ok = hipMemcpy(g_ctx.d_status, &st, sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-  double *bufs[1] = {g_ctx.d_status};
-  g_comm.err = 0;
-  x.allreduce(g_ctx.stream, 1, bufs, 1, x.user);
-  ok = ok && hipStreamSynchronize(g_ctx.stream) == hipSuccess && !g_comm.err;
-  ok = ok && hipMemcpy(&st, g_ctx.d_status, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
-  if (!ok) return local_rc ? local_rc : -996;
+  double st = 0.0;
+  if (!comm_vote(local_rc, &st)) return local_rc ? local_rc : -996;
+  if (st >= kVoteErr) return local_rc ? local_rc : -996;
   if (st != 0.0) return local_rc ? local_rc : -993;
   return 0;
 }

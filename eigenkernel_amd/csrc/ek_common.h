@@ -227,9 +227,16 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
 // identical on every member, the band stays in the members' own strips (see ek_sy2sb.hip).
 struct Sy2sbMember { double *A; int lda; double *Vall; int ldv; double *tau1; int *d_flag; void *work; int rank; };
 size_t sy2sb_dist_work_bytes(int n, int nranks);
-void sy2sb_lower_dist(hipStream_t s, int n, int nmem, const Sy2sbMember *mem, const SytrdExchange &x);
+// s2: second stream (look-ahead: the chain and the broadcast of panel p + 1 beside the rest of update p; nullptr: none)
+void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2sbMember *mem, const SytrdExchange &x);
+void sy2sb_dist_set_lookahead(int min_rows);         // rows from which the team form looks ahead (0: never, -1: default)
+void sy2sb_dist_profile(bool on);                    // per-panel HIP events (tools/team_timing.py)
+void sy2sb_dist_profile_collect(double *seconds, int P);   // [0] chains, [1] rest-of-update sections, [2] their cost to a rank of P with look-ahead; after a sync
 
-size_t sb2st_work_bytes(int n);
+// with_records = false: without the compact-WY records of the bulge chasing's reflectors (sb2st_record_bytes(n), the one
+// large part): the caller then lends sb2st_apply_q2 an array for them that only has to live while Q2 is applied
+size_t sb2st_work_bytes(int n, bool with_records = true);
+size_t sb2st_record_bytes(int n);
 // Band (lower band of A, half bandwidth kBandW) -> d(n), e(n-1) by bulge chasing.  V2 (n x n, ldv2,
 // zero on entry) receives the reflectors (column s = those of sweep s, stacked); *d_flag |= 4 if the
 // persistent kernel had to be abandoned.  work: >= sb2st_work_bytes(n), shared with sb2st_apply_q2.
@@ -238,14 +245,17 @@ size_t sb2st_work_bytes(int n);
 constexpr int kBandLd = 2 * kBandW;
 double *sb2st_band(void *work, int n);
 void pack_band(hipStream_t s, int n, const double *A, int lda, double *AB /* kBandLd x n */);
+// chase_mode: 0 = default (positions in registers where the chip holds them all), 1 = sweeps through memory only (what
+// the whole-path call repeats the stage with after an abandoned wait)
 void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, double *e, double *V2, int ldv2,
-                 int *d_flag, void *work, bool band_packed = false);
+                 int *d_flag, void *work, bool band_packed = false, int chase_mode = 0);
 // Z(:, 0:ncols) <- Q2 Z (Z 16-byte aligned, ldz even); *d_flag |= 4 if the pipeline had to be abandoned
 void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2, double *Z, int ldz, int *d_flag,
-                    void *work);
+                    void *work, double *records = nullptr);
 
 // ---------------------------------------------------------------- tridiagonal D&C (ek_stedc.hip)
-size_t stedc_work_bytes(int n);
+size_t stedc_work_bytes(int n, int nsel = -1);     // nsel: eigenvector columns wanted (-1: all); <= n - n/2: compact bases
+bool stedc_compact(int n, int nsel);               // whether stedc keeps its bases compact for that selection (no wscratch, Z n x nsel)
 // d(n), e(n-1) -> eigenvalues ascending in w(n), eigenvectors in Z (n x n, ldz).
 // With a selection only the eigenvectors of ranks r(l) = ((l / nb) * npcol + mycol) * nb + l % nb,
 // l = 0..nsel-1, are formed (the block-cyclic share of a process column; nb >= n, npcol = 1 gives

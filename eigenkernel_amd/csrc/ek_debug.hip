@@ -290,7 +290,7 @@ int ek_hip_debug_sy2sb_team(int n, double *A, int lda, double *V, int ldv, doubl
   }
   const SytrdExchange x = team_exchange(nteam, 0);
   g_comm.err = 0;
-  sy2sb_lower_dist(s, n, nmem, mem, x);
+  sy2sb_lower_dist(s, g_ctx.stream2, n, nmem, mem, x);
   for (int m = 0; m < nmem; ++m) pack_band(s, n, mem[m].A, ld, ABs[m]);
   gather_band_strips(s, n, nmem, mem[0].rank, ABs, x);
   EK_HIP_CHECK(hipGetLastError());
@@ -521,7 +521,12 @@ int ek_hip_debug_sytrd_team(int n, int nteam, int reps, double *seconds) {
 
 // Tuning hook: the team form of the dense -> band stage on the synthetic matrix; *seconds = the whole team back to back
 // on this GPU when nteam >= 1 (divide by nteam for a rank's compute: the wire is not in it)
-int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds) {
+// lookahead_min: rows from which the team form looks ahead (0: never: every section of a panel back to back; -1: default).
+// parts (optional, 4 doubles): [0] whole stage, [1] all panel chains, [2] all "rest of the trailing update" sections,
+// [3] first chain + sum over the panels of max(chain p + 1, update p / P), of the LAST repetition, from HIP events around
+// them -- with lookahead_min = 0 these are the serial pieces from which tools/team_timing.py models a rank's critical
+// path (the chain runs on ONE rank while the others wait for its broadcast; the update is shared)
+int ek_hip_debug_sy2sb_team_profile(int n, int nteam, int reps, int lookahead_min, double *seconds, double *parts) {
   if (n < 3) return -1;
   if (nteam < 0 || nteam > kMaxTeam) return -2;
   int rc = ensure_init(); if (rc) return rc;
@@ -549,7 +554,9 @@ int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds) 
   EK_HIP_CHECK(hipEventCreate(&e0)); EK_HIP_CHECK(hipEventCreate(&e1));
   double tot = 0.0;
   g_comm.err = 0;
+  sy2sb_dist_set_lookahead(lookahead_min);
   for (int r = 0; r < reps; ++r) {
+    if (parts) sy2sb_dist_profile(true);
     EK_HIP_CHECK(hipMemsetAsync(d_flags, 0, kMaxTeam * sizeof(int), s));
     for (int m = 0; m < nmem; ++m) {
       EK_HIP_CHECK(hipMemsetAsync(mem[m].A, 0, (size_t)ld * ld * 8, s));
@@ -558,15 +565,21 @@ int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds) 
       synth_matrix(s, n, 1, mem[m].A, ld);
     }
     EK_HIP_CHECK(hipEventRecord(e0, s));
-    sy2sb_lower_dist(s, n, nmem, mem, x);
+    sy2sb_lower_dist(s, g_ctx.stream2, n, nmem, mem, x);
     EK_HIP_CHECK(hipEventRecord(e1, s));
     EK_HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0.f; EK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     tot += ms * 1e-3;
+    if (parts) { parts[0] = ms * 1e-3; sy2sb_dist_profile_collect(parts + 1, P); sy2sb_dist_profile(false); }
   }
+  sy2sb_dist_set_lookahead(-1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (seconds) *seconds = tot / (reps > 0 ? reps : 1);
   return g_comm.err ? -996 : 0;
+}
+
+int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds) {
+  return ek_hip_debug_sy2sb_team_profile(n, nteam, reps, -1, seconds, nullptr);
 }
 
 // Tuning hook: Cholesky + reduction to standard form of the synthetic pair, distributed form;

@@ -1200,7 +1200,7 @@ struct Layout {
   int nsweeps, nS, kmax, ldt;
   size_t off_ab0, off_ab, off_tau, off_prog, off_mail, off_pmail, off_retired, off_ctl, off_T, off_qprog, off_offs, total;
   size_t nrec;
-  explicit Layout(int n) {
+  explicit Layout(int n, bool with_records = true) {
     nsweeps = n > 2 ? n - 2 : 0;
     nS = ceil_div((nsweeps > 0 ? nsweeps : 1) + 1, QG);   // block S = sweeps 32 S - 1 .. 32 S + 30
     kmax = q2_groups_of_block(n, 0); if (kmax < 1) kmax = 1;
@@ -1216,7 +1216,7 @@ struct Layout {
     off_ctl = o; o += 256;
     nrec = 0;
     for (int S = 0; S < nS; ++S) nrec += (size_t)q2_groups_of_block(n, S);
-    off_T = o; o += al256((nrec + 1) * QREC * 8);
+    off_T = o; o += with_records ? al256((nrec + 1) * QREC * 8) : 0;     // (without: the caller lends the records' array)
     off_qprog = o; o += al256((size_t)nS * ceil_div(n, QNC) * 4);
     off_offs = o; o += al256((size_t)(nS + 1) * 4);
     total = o;
@@ -1242,21 +1242,22 @@ int pos_capacity() {
 
 }  // namespace
 
-size_t sb2st_work_bytes(int n) { return Layout(n).total; }
+size_t sb2st_work_bytes(int n, bool with_records) { return Layout(n, with_records).total; }
+size_t sb2st_record_bytes(int n) { return al256((Layout(n).nrec + 1) * QREC * 8); }
 
 // Band (lower band of A, half bandwidth 64) -> d, e; the reflectors go to V2 (n x n, ldv2, zero on
 // entry; column s = the reflectors of sweep s stacked) and into the workspace (tau).  *d_flag |= 4
 // if the persistent kernel had to be abandoned (a bounded spin ran out).
-double *sb2st_band(void *work, int n) { return (double *)((char *)work + Layout(n).off_ab0); }
+double *sb2st_band(void *work, int n) { return (double *)((char *)work + Layout(n, false).off_ab0); }   // (in front of the records in both layouts)
 void pack_band(hipStream_t s, int n, const double *A, int lda, double *AB) {
   if (n <= 0) return;
   hipLaunchKernelGGL(pack_band_kernel, dim3(n), dim3(LDAB), 0, s, n, A, lda, AB);
 }
 
 void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, double *e, double *V2, int ldv2,
-                 int *d_flag, void *work, bool band_packed) {
+                 int *d_flag, void *work, bool band_packed, int chase_mode) {
   if (n <= 0) return;
-  const Layout L(n);
+  const Layout L(n, false);     // (nothing here touches the records or what lies behind them)
   char *w = (char *)work;
   double *AB0 = (double *)(w + L.off_ab0);
   double *AB = (double *)(w + L.off_ab), *tau2 = (double *)(w + L.off_tau);
@@ -1273,7 +1274,10 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
     // which kernel: 1 = sweeps through memory (chase_kernel), 2 = positions in registers (chase_pos_kernel, with
     // chase_kernel behind it in case its workgroups cannot all become resident); default 2 where the chip holds K0
     int mode = 2;
-    if (const char *ev = getenv("EK_SB2ST_CHASE")) mode = atoi(ev);
+    static int env_mode = -1;
+    if (env_mode < 0) { const char *ev = getenv("EK_SB2ST_CHASE"); env_mode = ev ? atoi(ev) : 0; }
+    if (env_mode > 0) mode = env_mode;
+    if (chase_mode > 0) mode = chase_mode;
     const int K0 = (n - 3) / SB + 1;
     const bool pos = mode == 2 && K0 <= pos_capacity() && !getenv("EK_SB2ST_WGS") && !getenv("EK_SB2ST_PROF");
     kprof_begin(s, kProfChase);
@@ -1357,12 +1361,12 @@ void sb2st_lower(hipStream_t s, int n, const double *A, int lda, double *d, doub
 
 // Z(:, 0:ncols) <- Q2 Z with the reflectors left by sb2st_lower (same V2, same workspace)
 void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2, double *Z, int ldz, int *d_flag,
-                    void *work) {
+                    void *work, double *records) {
   if (n <= 2 || ncols <= 0) return;
-  const Layout L(n);
+  const Layout L(n, records == nullptr);
   char *w = (char *)work;
   const double *tau2 = (const double *)(w + L.off_tau);
-  double *Rec = (double *)(w + L.off_T);
+  double *Rec = records ? records : (double *)(w + L.off_T);
   unsigned *ctl = (unsigned *)(w + L.off_ctl), *qprog = (unsigned *)(w + L.off_qprog);
   unsigned *offS = (unsigned *)(w + L.off_offs);
   hipLaunchKernelGGL(q2_offsets_kernel, dim3(1), dim3(64), 0, s, n, L.nS, offS);

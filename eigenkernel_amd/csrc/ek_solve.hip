@@ -4,6 +4,7 @@
 #include "ek_api_internal.h"
 
 #include <condition_variable>
+#include <sched.h>
 #include <deque>
 #include <thread>
 
@@ -101,12 +102,52 @@ void extract_local(int m, int n, const double *M_full, int ldf, const int *desc,
 //   in : B, then A (B is needed first: the Cholesky factorisation runs while A is still on its way);
 //   out: L as soon as it is final (it leaves during the reduction), the reflectors / band of A after the
 //        tridiagonalisation, Z in column slabs as the last stage finishes them, w last.
-// A copy of pageable host memory keeps its calling thread busy (the runtime stages it through pinned buffers), which
-// is why the copies have threads of their own; a matrix is cut into column pieces so that two threads share it.
+// The caller's arrays are pageable.  Handed to the runtime as they are, a copy is staged through the runtime's own
+// bounce buffers by the calling thread at a rate that depends on the box's host side (27 - 36 GB/s with two threads per
+// direction on one pool box, a third of that exposed time on another: round 3).  Round 4: the library owns a ring of
+// PINNED bounce buffers (allocated once per process), a worker packs a chunk of columns into its slot with the CPU
+// (memcpy) and hands the slot to the DMA engine (and the reverse on the way out), two slots per worker so that its
+// memcpy and its DMA overlap; the number of workers per direction follows the cores the process may run on.
+struct PinRing {
+  static constexpr size_t kSlot = (size_t)8 << 20;       // bytes per slot
+  static constexpr int kMaxWorkers = 16;
+  char *base = nullptr;
+  int nslots = 0;
+  hipEvent_t ev[2 * kMaxWorkers] = {};
+  // (called under g_mu; the ring lives until the process ends: pinning 16 MiB per worker costs more than a solve's copies
+  // may lose)
+  bool ensure(int workers) {
+    const int want = 2 * workers;
+    if (base && nslots >= want) return true;
+    release();
+    if (hipHostMalloc((void **)&base, kSlot * want, hipHostMallocDefault) != hipSuccess) { base = nullptr; (void)hipGetLastError(); return false; }
+    for (int i = 0; i < want; ++i)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { release(); return false; }
+    nslots = want;
+    return true;
+  }
+  void release() {
+    for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (base) (void)hipHostFree(base);
+    base = nullptr; nslots = 0;
+  }
+  char *slot(int i) const { return base + kSlot * (size_t)i; }
+};
+PinRing g_pin;
+
+int usable_cores() {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) return c; }
+  const unsigned h = std::thread::hardware_concurrency();
+  return h > 0 ? (int)h : 1;
+}
+
 struct HostPipe {
   struct Job { double *dev; int ldd; double *host; int ldh; int m, n; hipEvent_t after; int tag; bool to_host; };
   static constexpr int kMaxThreads = 8;
-  int kThreads = 2;                          // per direction (EK_HIP_PIPE_THREADS)
+  int kThreads = 2;                          // per direction (EK_HIP_PIPE_THREADS; default by the cores the process has)
+  bool pinned = false;                       // the copies go through the pinned ring (EK_HIP_PIPE_PINNED=0: as round 3)
   std::mutex mu;
   std::condition_variable cv;
   std::deque<Job> in_q, out_q;
@@ -118,15 +159,90 @@ struct HostPipe {
   hipStream_t cs[2 * kMaxThreads] = {};
   int device = 0;
   int z_slab = 2048;
+  // EK_HIP_PIPE_TRACE=1: what every copy job and every wait of the main thread took (stderr, at the end of the call)
+  bool trace = false;
+  std::chrono::steady_clock::time_point t_origin;
+  struct TraceRec { double t0, t1; double bytes; int kind; };      // kind 0 = in, 1 = out, 2 = wait_in, 3 = finish
+  std::vector<TraceRec> trace_log;
+  double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_origin).count(); }
+  void report() {
+    if (!trace) return;
+    double busy[2] = {0, 0}, bytes[2] = {0, 0}, first[2] = {1e30, 1e30}, last[2] = {0, 0};
+    for (const auto &r : trace_log) {
+      if (r.kind < 2) {
+        busy[r.kind] += r.t1 - r.t0; bytes[r.kind] += r.bytes;
+        if (r.t0 < first[r.kind]) first[r.kind] = r.t0;
+        if (r.t1 > last[r.kind]) last[r.kind] = r.t1;
+      } else {
+        fprintf(stderr, "[pipe] main thread waited %.4f s (%s) at t = %.4f\n", r.t1 - r.t0, r.kind == 2 ? "input" : "drain", r.t0);
+      }
+    }
+    for (int k = 0; k < 2; ++k)
+      if (bytes[k] > 0)
+        fprintf(stderr, "[pipe] %s: %.2f GB between t = %.4f and %.4f s (%.1f GB/s over the span), %d threads busy %.3f s in all (%.1f GB/s per busy thread), %s\n",
+                k ? "out" : "in", bytes[k] / 1e9, first[k], last[k], bytes[k] / 1e9 / (last[k] - first[k]), kThreads, busy[k],
+                bytes[k] / 1e9 / busy[k], pinned ? "pinned ring" : "pageable");
+  }
 
   int start(int dev) {
     device = dev;
-    if (const char *e = getenv("EK_HIP_PIPE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxThreads) kThreads = v; }
+    t_origin = std::chrono::steady_clock::now();
+    { static int tr = -1; if (tr < 0) { const char *e = getenv("EK_HIP_PIPE_TRACE"); tr = (e && atoi(e) != 0) ? 1 : 0; } trace = tr != 0; }
+    static int env_threads = -2, env_pinned = -1;
+    if (env_threads == -2) { const char *e = getenv("EK_HIP_PIPE_THREADS"); env_threads = e ? atoi(e) : -1; }
+    if (env_pinned < 0) { const char *e = getenv("EK_HIP_PIPE_PINNED"); env_pinned = (e && atoi(e) == 0) ? 0 : 1; }
+    const int cores = usable_cores();
+    kThreads = cores >= 16 ? 6 : cores >= 8 ? 4 : 2;      // (both directions are rarely busy at once)
+    if (env_threads >= 1 && env_threads <= kMaxThreads) kThreads = env_threads;
+    pinned = env_pinned != 0 && g_pin.ensure(2 * kThreads);
     for (int i = 0; i < 2 * kThreads; ++i) EK_HIP_CHECK(hipStreamCreateWithFlags(&cs[i], hipStreamNonBlocking));
-    for (int i = 0; i < 2 * kThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i]); });
+    for (int i = 0; i < 2 * kThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i], i); });
     return 0;
   }
-  void run(bool input, hipStream_t c) {
+  // one job through the worker's two pinned slots (m rows of 8 bytes, n columns; a chunk = as many columns as fit a slot)
+  hipError_t copy_pinned(const Job &j, hipStream_t c, int worker) {
+    const size_t col_bytes = (size_t)j.m * 8;
+    if (col_bytes > PinRing::kSlot) return hipErrorInvalidValue;      // (orders beyond a million)
+    const int cpc = (int)(PinRing::kSlot / col_bytes);
+    const int nchunk = ceil_div(j.n, cpc);
+    char *slot[2] = {g_pin.slot(2 * worker), g_pin.slot(2 * worker + 1)};
+    hipEvent_t ev[2] = {g_pin.ev[2 * worker], g_pin.ev[2 * worker + 1]};
+    hipError_t e = hipSuccess;
+    auto cols = [&](int q) { const int c0 = q * cpc; return (j.n - c0 < cpc) ? j.n - c0 : cpc; };
+    if (!j.to_host) {
+      for (int q = 0; q < nchunk && e == hipSuccess; ++q) {
+        const int k = q & 1, c0 = q * cpc, nc = cols(q);
+        if (q >= 2) e = hipEventSynchronize(ev[k]);                   // the slot's previous DMA has read it
+        if (e != hipSuccess) break;
+        const double *src = j.host + (size_t)c0 * j.ldh;
+        if (j.ldh == j.m) memcpy(slot[k], src, col_bytes * nc);
+        else for (int cc = 0; cc < nc; ++cc) memcpy(slot[k] + col_bytes * cc, src + (size_t)cc * j.ldh, col_bytes);
+        e = hipMemcpy2DAsync(j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, slot[k], col_bytes, col_bytes, nc, hipMemcpyHostToDevice, c);
+        if (e == hipSuccess) e = hipEventRecord(ev[k], c);
+      }
+      const hipError_t e2 = hipStreamSynchronize(c);
+      return e != hipSuccess ? e : e2;
+    }
+    auto fetch = [&](int q) {
+      const int k = q & 1, c0 = q * cpc, nc = cols(q);
+      hipError_t f = hipMemcpy2DAsync(slot[k], col_bytes, j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, col_bytes, nc, hipMemcpyDeviceToHost, c);
+      if (f == hipSuccess) f = hipEventRecord(ev[k], c);
+      return f;
+    };
+    e = fetch(0);
+    for (int q = 0; q < nchunk && e == hipSuccess; ++q) {
+      const int k = q & 1, c0 = q * cpc, nc = cols(q);
+      if (q + 1 < nchunk) e = fetch(q + 1);                           // (its slot was emptied by this thread one round ago)
+      if (e == hipSuccess) e = hipEventSynchronize(ev[k]);
+      if (e != hipSuccess) break;
+      double *dst = j.host + (size_t)c0 * j.ldh;
+      if (j.ldh == j.m) memcpy(dst, slot[k], col_bytes * nc);
+      else for (int cc = 0; cc < nc; ++cc) memcpy(dst + (size_t)cc * j.ldh, slot[k] + col_bytes * cc, col_bytes);
+    }
+    const hipError_t e2 = hipStreamSynchronize(c);
+    return e != hipSuccess ? e : e2;
+  }
+  void run(bool input, hipStream_t c, int worker) {
     (void)hipSetDevice(device);
     std::deque<Job> &q = input ? in_q : out_q;
     while (true) {
@@ -139,24 +255,30 @@ struct HostPipe {
       }
       hipError_t e = hipSuccess;
       if (j.after) e = hipEventSynchronize(j.after);
+      const double tj0 = trace ? now() : 0.0;
       if (e == hipSuccess && j.m > 0 && j.n > 0) {
-        if (j.to_host)
-          e = hipMemcpy2DAsync(j.host, (size_t)j.ldh * 8, j.dev, (size_t)j.ldd * 8, (size_t)j.m * 8, j.n, hipMemcpyDeviceToHost, c);
-        else
-          e = hipMemcpy2DAsync(j.dev, (size_t)j.ldd * 8, j.host, (size_t)j.ldh * 8, (size_t)j.m * 8, j.n, hipMemcpyHostToDevice, c);
-        if (e == hipSuccess) e = hipStreamSynchronize(c);
+        if (pinned && (size_t)j.m * 8 <= PinRing::kSlot) e = copy_pinned(j, c, worker);
+        else {
+          if (j.to_host)
+            e = hipMemcpy2DAsync(j.host, (size_t)j.ldh * 8, j.dev, (size_t)j.ldd * 8, (size_t)j.m * 8, j.n, hipMemcpyDeviceToHost, c);
+          else
+            e = hipMemcpy2DAsync(j.dev, (size_t)j.ldd * 8, j.host, (size_t)j.ldh * 8, (size_t)j.m * 8, j.n, hipMemcpyHostToDevice, c);
+          if (e == hipSuccess) e = hipStreamSynchronize(c);
+        }
       }
       {
         std::lock_guard<std::mutex> lk(mu);
         if (e != hipSuccess && !err) err = -1000 - (int)e;
+        if (trace) trace_log.push_back(TraceRec{tj0, now(), (double)j.m * j.n * 8.0, input ? 0 : 1});
         if (input) --pending_in[j.tag]; else --pending_out;
       }
       cv.notify_all();
     }
   }
-  // host array (m x n, ldh) <-> device image (ldd), cut into column pieces for the threads
+  // host array (m x n, ldh) <-> device image (ldd), cut into column pieces for the threads (in column order: the
+  // first columns of a matrix arrive first)
   void push(bool to_host, double *dev, int ldd, double *host, int ldh, int m, int n, hipEvent_t after, int tag) {
-    const int pieces = (n >= 256) ? 2 * kThreads : 1;
+    const int pieces = (n >= 256) ? 4 * kThreads : 1;
     {
       std::lock_guard<std::mutex> lk(mu);
       for (int p = 0; p < pieces; ++p) {
@@ -168,15 +290,19 @@ struct HostPipe {
     cv.notify_all();
   }
   int wait_in(int tag) {
+    const double t0 = trace ? now() : 0.0;
     std::unique_lock<std::mutex> lk(mu);
     cv.wait(lk, [&]() { return pending_in[tag] == 0; });
+    if (trace) trace_log.push_back(TraceRec{t0, now(), 0.0, 2});
     return err;
   }
   int finish() {                              // all copies done; threads joined; streams released
     {
+      const double t0 = trace ? now() : 0.0;
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&]() { return pending_out == 0 && pending_in[0] == 0 && pending_in[1] == 0; });
       closing = true;
+      if (trace) trace_log.push_back(TraceRec{t0, now(), 0.0, 3});
     }
     cv.notify_all();
     for (auto &t : th) t.join();
@@ -184,6 +310,7 @@ struct HostPipe {
     for (auto &c : cs) if (c) { (void)hipStreamDestroy(c); c = nullptr; }
     for (auto &e : evs) (void)hipEventDestroy(e);
     evs.clear();
+    report();
     return err;
   }
   ~HostPipe() { if (!th.empty()) (void)finish(); }
@@ -212,6 +339,64 @@ struct StageTimer {      // events are released when the timer goes out of scope
   ~StageTimer() { destroy(); }
 };
 
+// Workspace of one whole-path call, laid out by LIFETIME (round 4).  Until round 3 every work array had its own place
+// for the whole call (9.5 matrices + scratch at N = 16384, whatever the team size).  What a stage needs lives in one of
+//   persistent : L (wB) and the first stage's reflectors (wV) -- operators every rank applies in full to its own
+//                eigenvector columns at the end --, the eigenvector columns this call forms (wZ: n x n on one GPU, a grid
+//                cell's share n x n/P on a team), the small vectors, the band and the bulge chasing's mail;
+//   X0 (one matrix): the matrix A from the stage-in to the end of dense -> band, THEN the bulge chasing's reflectors V2
+//                (what the call leaves in A goes back to the caller in between);
+//   X1         : the scratch of the reduction to standard form and of the Cholesky factorisation, THEN the divide &
+//                conquer's bases (compact for a cell's share: 1.5 n^2 + n n/P; 2 n^2 for the full spectrum on one GPU),
+//                THEN the compact-WY records of Q2 (1.55 n^2, made from V2 after the D&C), THEN the scratch of Q1.
+// The copy of the reduced matrix for a fall-back to the one-stage reduction is gone: a bulge chasing that abandons a
+// bounded wait is repeated from the band it started from (a few MB) instead.
+struct PathPlan {
+  int ld, nblk, zcols;
+  bool two_stage, potrf_rl, compact_dc;
+  size_t mat, zmat, x0, x1, sygst_dbl, potrf_wb, wb_sytrd, wb_stedc, wb_ormtr, wb_sy2sb, wb_sb2st, wb_rec, wb_q1prep,
+         trsm_work, total;
+};
+PathPlan plan_path(int problem, int n, int n_vec, int nc_loc, int nranks_dist /* 0: not distributed */) {
+  PathPlan p{};
+  const bool dist = nranks_dist > 0;
+  p.ld = pad_ld(n); p.nblk = ceil_div(n, kDiagNB);
+  const int ts_min = two_stage_min();
+  p.two_stage = ts_min > 0 && n >= ts_min && n >= 3;
+  p.mat = al((size_t)p.ld * p.ld * 8);
+  // the eigenvector work array holds the columns this call forms only (a grid cell's share, or the first n_vec of a
+  // *_select arm) where the D&C can keep its bases compact; else it is n x n and doubles as the D&C's scratch
+  p.compact_dc = stedc_compact(n, nc_loc);
+  p.zcols = p.compact_dc ? round_up(nc_loc > 0 ? nc_loc : 1, 128) : p.ld;
+  p.zmat = al((size_t)p.ld * p.zcols * 8);
+  p.wb_sytrd = (p.two_stage) ? 0 : (dist ? sytrd_dist_work_bytes(n, nranks_dist) : sytrd_work_bytes(n));
+  p.wb_stedc = stedc_work_bytes(n, nc_loc);
+  p.wb_ormtr = ormtr_work_bytes(n, nc_loc, n_vec);
+  p.trsm_work = al((size_t)128 * p.ld * 8);
+  p.sygst_dbl = (problem == 1) ? sygst_scratch_doubles(n) : 0;
+  if (problem == 1 && dist) {
+    const size_t dd = sygst_dist_scratch_doubles(n, p.ld, nranks_dist);
+    if (dd > p.sygst_dbl) p.sygst_dbl = dd;
+  }
+  // right-looking Cholesky with look-ahead from this order on (below it the recursion is as fast)
+  p.potrf_rl = problem == 1 && n >= kPotrfRlMin;
+  p.potrf_wb = (problem == 1 && dist) ? al(potrf_dist_work_bytes(n, p.ld, nranks_dist)) : 0;
+  if (p.potrf_rl && al(potrf_rl_work_bytes(n, p.ld)) > p.potrf_wb) p.potrf_wb = al(potrf_rl_work_bytes(n, p.ld));
+  p.wb_sy2sb = p.two_stage ? al(dist ? sy2sb_dist_work_bytes(n, nranks_dist) : sy2sb_work_bytes(n)) : 0;
+  p.wb_sb2st = p.two_stage ? al(sb2st_work_bytes(n, /*with_records=*/false)) : 0;
+  p.wb_rec = p.two_stage ? al(sb2st_record_bytes(n)) : 0;
+  p.wb_q1prep = p.two_stage ? al(ormtr_prep_bytes(n)) : 0;
+  p.x0 = p.mat;
+  const size_t phase_a = al(p.sygst_dbl * 8) + p.potrf_wb + al(p.wb_sytrd) + 512;   // [reduction | Cholesky | one-stage scratch]
+  p.x1 = phase_a;
+  if (al(p.wb_stedc) > p.x1) p.x1 = al(p.wb_stedc);
+  if (p.wb_rec > p.x1) p.x1 = p.wb_rec;
+  if (al(p.wb_ormtr) > p.x1) p.x1 = al(p.wb_ormtr);
+  p.total = 2 * p.mat + p.zmat + p.x0 + p.x1 + al((size_t)p.nblk * kDiagNB * kDiagNB * 8) + p.trsm_work +
+            5 * al((size_t)p.ld * 8) + p.wb_sy2sb + p.wb_sb2st + p.wb_q1prep + 4096;
+  return p;
+}
+
 // Runs the path on user device arrays dA, dB, dZ (column-major, any ld >= n) by way of padded
 // internal work arrays (ld multiple of 128, zero padding), so the kernels see aligned tiles.
 //
@@ -223,70 +408,46 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
                         double *dw, double *dZ, int ldz, double *stage_seconds, int n_stages,
                         const GridCell *cell = nullptr, HostPipe *pipe = nullptr) {
   hipStream_t s = g_ctx.stream;
-  const int ld = pad_ld(n), nblk = ceil_div(n, kDiagNB);
   const int nc_loc = cell ? numroc0(n_vec, cell->nb, cell->mycol, cell->npcol) : n_vec;
   const int nr_loc = cell ? numroc0(n, cell->nb, cell->myrow, cell->nprow) : n;
-  // A communicator attached by the host (ek_hip_comm_init) whose size is the grid's: the
-  // tridiagonalisation is distributed over the ranks (one RCCL all-reduce per column); the other
-  // stages are as in the replicated-input mode.
+  // A communicator attached by the host (ek_hip_comm_init) whose size is the grid's: the Cholesky factorisation, the
+  // reduction and the dense -> band stage of the tridiagonalisation are distributed over the ranks (1 x P team, per panel
+  // one broadcast and one all-reduce; below the two-stage orders the one-stage form with its per-column exchange); the
+  // other stages are as in the replicated-input mode.
   const bool dist = cell && g_comm.on && g_comm.nranks == cell->nprow * cell->npcol;
   if (dist && g_comm.rank != cell->myrow * cell->npcol + cell->mycol) return -994;
-  const size_t wb_sytrd = dist ? sytrd_dist_work_bytes(n, g_comm.nranks) : sytrd_work_bytes(n),
-               wb_stedc = stedc_work_bytes(n), wb_ormtr = ormtr_work_bytes(n, nc_loc, n_vec);
-  const size_t mat = al((size_t)ld * ld * 8);
-  // the eigenvector work array holds the columns this call forms only (a grid cell's share, or the first n_vec of a
-  // *_select arm): the one work matrix of the path whose size falls with the number of ranks
-  // (the D&C takes the spent copy of the reduced matrix for its permuted bases then: two-stage orders only)
-  const int zcols = (nc_loc >= n || !(two_stage_min() > 0 && n >= two_stage_min() && n >= 3)) ? ld : round_up(nc_loc > 0 ? nc_loc : 1, 128);
-  const size_t zmat = al((size_t)ld * zcols * 8);
-  size_t scratch = wb_sytrd;
-  if (wb_stedc > scratch) scratch = wb_stedc;
-  if (wb_ormtr > scratch) scratch = wb_ormtr;
-  const size_t trsm_work = al((size_t)128 * ld * 8);
-  void *ws;
-  size_t sygst_dbl = (problem == 1) ? sygst_scratch_doubles(n) : 0;
-  if (problem == 1 && dist) {
-    const size_t dd = sygst_dist_scratch_doubles(n, ld, g_comm.nranks);
-    if (dd > sygst_dbl) sygst_dbl = dd;
-  }
-  const size_t sygst_scr = al(sygst_dbl * 8);
-  // right-looking Cholesky with look-ahead from this order on (below it the recursion is as fast)
-  const bool potrf_rl = problem == 1 && n >= kPotrfRlMin;
-  size_t potrf_wb = (problem == 1 && dist) ? al(potrf_dist_work_bytes(n, ld, g_comm.nranks)) : 0;
-  if (potrf_rl && al(potrf_rl_work_bytes(n, ld)) > potrf_wb) potrf_wb = al(potrf_rl_work_bytes(n, ld));
+  const PathPlan pl = plan_path(problem, n, n_vec, nc_loc, dist ? g_comm.nranks : 0);
+  const int ld = pl.ld, nblk = pl.nblk, zcols = pl.zcols;
+  const bool two_stage = pl.two_stage, potrf_rl = pl.potrf_rl;
+  const size_t wb_sytrd = pl.wb_sytrd;
   int rc = 0;
-  // two-stage tridiagonalisation: one more matrix for the reflectors of the bulge chasing, a copy of
-  // the reduced matrix for the (rare) fall-back to the one-stage path, and the stages' own scratch
-  const int ts_min = two_stage_min();
-  const bool two_stage = ts_min > 0 && n >= ts_min && n >= 3;
-  const size_t wb_sy2sb = two_stage ? al(dist ? sy2sb_dist_work_bytes(n, g_comm.nranks) : sy2sb_work_bytes(n)) : 0,
-               wb_sb2st = two_stage ? al(sb2st_work_bytes(n)) : 0;
-  const size_t wb_q1prep = two_stage ? al(ormtr_prep_bytes(n)) : 0;
-  const size_t ws_need = 3 * mat + zmat + al((size_t)nblk * kDiagNB * kDiagNB * 8) + trsm_work + al(scratch) +
-                         4 * al((size_t)ld * 8) + sygst_scr + potrf_wb +
-                         (two_stage ? 2 * mat + wb_sy2sb + wb_sb2st + wb_q1prep + al((size_t)ld * 8) : 0);
-  rc = workspace(ws_need, &ws);
+  void *ws;
+  g_comm.err = 0;                        // (sticky from here to the end of the call: the votes below keep it)
+  rc = workspace(pl.total, &ws);
   if (dist) rc = comm_agree(rc);         // a rank that cannot get its workspace takes the team out with it (-993)
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
-  double *wA = a.get<double>((size_t)ld * ld);
   double *wB = a.get<double>((size_t)ld * ld);
-  double *wZ = a.get<double>((size_t)ld * zcols);
   double *wV = a.get<double>((size_t)ld * ld);
+  double *wZ = a.get<double>((size_t)ld * zcols);
+  double *x0 = a.get<double>((size_t)ld * ld);
+  char *x1 = a.get<char>(pl.x1);
   double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
   double *twork = a.get<double>((size_t)128 * ld);
-  char *work = a.get<char>(scratch);
   double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
-  double *sscr = (problem == 1) ? a.get<double>(sygst_dbl) : nullptr;
-  char *pwork = potrf_wb ? a.get<char>(potrf_wb) : nullptr;
-  double *wV2 = two_stage ? a.get<double>((size_t)ld * ld) : nullptr;
-  double *wA0 = two_stage ? a.get<double>((size_t)ld * ld) : nullptr;
-  char *work_sy2sb = two_stage ? a.get<char>(wb_sy2sb) : nullptr;
-  char *work_sb2st = two_stage ? a.get<char>(wb_sb2st) : nullptr;
-  char *q1prep = two_stage ? a.get<char>(wb_q1prep) : nullptr;
-  double *dt1 = two_stage ? a.get<double>(ld) : nullptr;
-  // where the tridiagonalisation keeps x, the panel and its partial sums (probed once per workspace)
-  void *sytrd_work = two_stage ? (void *)work : choose_sytrd_scratch(n, ld, wA, work, dd, wb_sytrd);
+  double *dt1 = a.get<double>(ld);
+  char *work_sy2sb = two_stage ? a.get<char>(pl.wb_sy2sb) : nullptr;
+  char *work_sb2st = two_stage ? a.get<char>(pl.wb_sb2st) : nullptr;
+  char *q1prep = two_stage ? a.get<char>(pl.wb_q1prep) : nullptr;
+  double *wA = x0;                       // X0, first life: the matrix
+  double *wV2 = x0;                      // X0, second life: the reflectors of the bulge chasing
+  double *sscr = (problem == 1) ? (double *)x1 : nullptr;                       // X1, phase A
+  char *pwork = pl.potrf_wb ? x1 + al(pl.sygst_dbl * 8) : nullptr;
+  char *work = x1;                       // X1 as the scratch of the D&C / of the back-transformation
+  double *q2rec = (double *)x1;          // X1 as the records of Q2
+  // where the one-stage tridiagonalisation keeps x, the panel and its partial sums (probed once per workspace)
+  char *sytrd_arena = x1 + al(pl.sygst_dbl * 8) + pl.potrf_wb + 256;
+  void *sytrd_work = two_stage ? nullptr : choose_sytrd_scratch(n, ld, wA, sytrd_arena, dd, wb_sytrd);
 
   StageTimer tm;
   const bool timing = stage_seconds && n_stages > 0;
@@ -337,7 +498,6 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   if (!pipe) { rc = stage_in_A(); if (rc) { tm.destroy(); return rc; } }
   rc = stage_in_B(); if (rc) { tm.destroy(); return rc; }
   mark();                                                              // 1
-  g_comm.err = 0;
   if (problem == 1) {
     // right-looking sweep with one panel broadcast per strip: pays from three ranks on
     if (dist && g_comm.nranks >= dist_min_ranks()) {
@@ -369,66 +529,70 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   mark();                                                              // 3
   bool two_stage_done = false;
   double rescued_panels = 0.0;
+  // what the call leaves in A -- PDSYTRD's reflectors; after a two-stage reduction the band and the first stage's R factors
+  //  -- goes back to the caller as soon as it is final: its place (X0) is needed again
+  auto a_out = [&]() {
+    copy_matrix(s, n, n, wA, ld, dA, lda);
+    if (pipe) pipe->push(true, dA, lda, pipe->hA, pipe->ldha, n, n, pipe->mark(s), 0);
+  };
   if (dist && !two_stage) {
     const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
     sytrd_lower_dist(s, n, 1, &me, team_exchange(0, n));
+    a_out();
   } else if (two_stage) {
-    // dense -> band -> tridiagonal.  The panel factorisation of the first stage is CholeskyQR2 with a
-    // device-side check; a matrix it cannot handle (rank-deficient or very ill-conditioned panels,
-    // e.g. an input that is already banded) takes the one-stage path from a copy instead.
-    EK_HIP_CHECK(hipMemcpyAsync(wA0, wA, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
-    EK_HIP_CHECK(hipMemsetAsync(wV2, 0, (size_t)ld * ld * 8, s));
+    // dense -> band -> tridiagonal.  The panel factorisation of the first stage is CholeskyQR2 with a device-side check;
+    // a panel it cannot handle (rank deficient, cond > 1e7: e.g. an input that is nearly banded) is factored by
+    // Householder reflections inside the stage (per-panel rescue, ek_sy2sb.hip): the stage never gives up.
     EK_HIP_CHECK(hipMemsetAsync(dt1, 0, (size_t)ld * 8, s));
+    double *AB0 = sb2st_band(work_sb2st, n);
     if (dist) {
       // On a team the first stage is distributed over the 128-wide column strips (strip S on rank S mod P: where
       // the distributed reduction to standard form left the matrix, so nothing is gathered in front of it): per panel
-      // one broadcast of [V | T | tau] and one all-reduce of Y (ek_sy2sb.hip).  Then ONE all-gather of the band
-      // (65 n doubles); the bulge chasing and the D&C below its top merge run replicated, bit-identical on all ranks.
+      // one broadcast of [V | T | tau] and one all-reduce of Y, the next panel's chain and broadcast on the second stream
+      // beside the rest of the update (ek_sy2sb.hip).  Then ONE all-gather of the band (65 n doubles); the bulge chasing
+      // and the D&C below its top merge run replicated, bit-identical on all ranks.
       const SytrdExchange x = team_exchange(0);
       const Sy2sbMember me{wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb, g_comm.rank};
-      sy2sb_lower_dist(s, n, 1, &me, x);
-      double *ABs[1] = {sb2st_band(work_sb2st, n)};
-      pack_band(s, n, wA, ld, ABs[0]);
+      sy2sb_lower_dist(s, g_ctx.stream2, n, 1, &me, x);
+      double *ABs[1] = {AB0};
+      pack_band(s, n, wA, ld, AB0);
       gather_band_strips(s, n, 1, g_comm.rank, ABs, x);
-      sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st, /*band_packed=*/true);
     } else {
       if (!band_input) sy2sb_lower(s, g_ctx.stream2, n, wA, ld, wV, ld, dt1, g_ctx.d_info + 2, work_sy2sb);
-      sb2st_lower(s, n, wA, ld, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st);
+      pack_band(s, n, wA, ld, AB0);
     }
-    // (the bulge chasing does nothing when the first stage has raised its flag: the band is not valid then)
-    int flag = 0;
-    EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
-    EK_HIP_CHECK(hipStreamSynchronize(s));
-    rescued_panels = (double)(flag >> 8);      // panels of the first stage that took the Householder rescue
-    flag &= 0xff;                              // the low byte says why the two-stage form gave up, if it did
-    // a team decides together: a flag that only one rank has raised (an abandoned wait depends on timing, not on the
-    // data) must not leave the ranks with eigenvectors of two different decompositions
-    if (dist) { flag = comm_any(flag); if (flag < 0) return flag; }
-    if (flag == 0) two_stage_done = true;
-    else {
-      EK_HIP_CHECK(hipMemcpyAsync(wA, wA0, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice, s));
-      EK_HIP_CHECK(hipMemsetAsync(wV, 0, (size_t)ld * ld * 8, s));
-      EK_HIP_CHECK(hipMemsetAsync(dd, 0, 3 * al((size_t)ld * 8), s));
-      if (dist) {     // (the copy holds the matrix in this rank's strips only: the one-stage form over the team)
-        const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
-        sytrd_lower_dist(s, n, 1, &me, team_exchange(0, n));
-      } else {
-        sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
-      }
+    a_out();                               // X0 changes hands: the matrix leaves, the reflectors of the chase move in
+    EK_HIP_CHECK(hipMemsetAsync(wV2, 0, (size_t)ld * ld * 8, s));
+    sb2st_lower(s, n, nullptr, 0, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st, /*band_packed=*/true);
+    // The low byte of the flag says that the bulge chasing abandoned a bounded wait (a matter of timing, not of the
+    // data; nothing has raised it yet).  The stage is then repeated from the band it started from -- kept beside the
+    // working copy -- with the older kernel alone, twice at most.  A team decides together: a flag that only one rank
+    // has raised must not leave the ranks with eigenvectors of two different decompositions.
+    for (int attempt = 0; ; ++attempt) {
+      int flag = 0;
+      EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+      EK_HIP_CHECK(hipStreamSynchronize(s));
+      rescued_panels = (double)(flag >> 8);      // panels of the first stage that took the Householder rescue
+      int low = flag & 0xff;
+      if (dist) { low = comm_any(low); if (low < 0) return low; }
+      if (low == 0) { two_stage_done = true; break; }
+      if (attempt == 2) return -992;
+      flag &= ~0xff;
+      EK_HIP_CHECK(hipMemcpyAsync(g_ctx.d_info + 2, &flag, sizeof(int), hipMemcpyHostToDevice, s));
+      EK_HIP_CHECK(hipStreamSynchronize(s));
+      EK_HIP_CHECK(hipMemsetAsync(wV2, 0, (size_t)ld * ld * 8, s));
+      sb2st_lower(s, n, nullptr, 0, dd, de, wV2, ld, g_ctx.d_info + 2, work_sb2st, /*band_packed=*/true, /*chase_mode=*/1);
     }
   } else {
     sytrd_lower(s, n, wA, ld, dd, de, dt, wV, ld, sytrd_work);
-  }
-  if (pipe) {                  // what the call leaves in A (reflectors / band) is final
-    copy_matrix(s, n, n, wA, ld, dA, lda);
-    pipe->push(true, dA, lda, pipe->hA, pipe->ldha, n, n, pipe->mark(s), 0);
+    a_out();
   }
   mark();                                                              // 4
   // eigenvector columns wanted: the first n_vec, or this grid cell's share of them; the D&C
   // forms only those (columns 0..nc_loc-1 of wZ) and the two remaining stages treat the
   // columns of Z independently
   const StedcSelect pick{nc_loc, cell ? cell->nb : (n > 0 ? n : 1), cell ? cell->npcol : 1, cell ? cell->mycol : 0};
-  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats, two_stage ? wA0 : nullptr);
+  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats);
   mark();                                                              // 5
   double *zc = wZ;
   // with a staging pipeline the LAST stage (the recovery; the back-transformation of a standard problem) runs in column
@@ -439,7 +603,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     pipe->push(true, dZ + (size_t)c0 * ldz, ldz, pipe->hZ + (size_t)c0 * pipe->ldhz, pipe->ldhz, n, nc, pipe->mark(s), 0);
   };
   if (two_stage_done) {
-    sb2st_apply_q2(s, n, nc_loc, wV2, ld, zc, ld, g_ctx.d_info + 2, work_sb2st);
+    // (the records of Q2 are made from V2 here, after the D&C whose scratch they take over)
+    sb2st_apply_q2(s, n, nc_loc, wV2, ld, zc, ld, g_ctx.d_info + 2, work_sb2st, q2rec);
     // (the T factors of the block reflectors do not depend on Z; forming them on the second stream beside the
     // bulge chasing was measured: the skinny GEMMs take CUs and issue slots from the latency-bound pipeline,
     // which loses 11 ms to gain 6)
@@ -479,7 +644,6 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   if (!pipe) {
     if (cell) gather_block_cyclic(s, nr_loc, nc_loc, zc, ld, cell->nb, cell->nprow, cell->myrow, 1, 0, dZ, ldz);
     else copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
-    copy_matrix(s, n, n, wA, ld, dA, lda);
     if (problem == 1) copy_matrix(s, n, n, wB, ld, dB, ldb);
   }
   mark();                                                              // 8
@@ -504,15 +668,17 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     for (int i = 0; i < n_stages && i < EK_HIP_N_STAGES; ++i) stage_seconds[i] = st[i];
     tm.destroy();
   }
-  if (dist && g_comm.err) {
-    fprintf(stderr, "[ek_hip] RCCL all-reduce failed: %s\n", comm_error_string());
-    return -996;
+  // the pipelined back-transformation was abandoned (a bounded wait ran out): on a team, for all ranks -- and an exchange
+  // that failed on ANY rank (its sticky record travels in the same vote) ends the call on all of them with -996
+  int bad = two_stage_done && info[2] != 0;
+  if (dist) {
+    bad = comm_any(bad);
+    if (bad < 0) {
+      if (g_comm.err) fprintf(stderr, "[ek_hip] exchange failed: %s\n", comm_error_string());
+      return -996;
+    }
   }
-  if (two_stage_done) {   // the pipelined back-transformation was abandoned (a bounded wait ran out): on a team, for all ranks
-    int bad = info[2] != 0;
-    if (dist) bad = comm_any(bad);
-    if (bad) return bad < 0 ? bad : -992;
-  }
+  if (bad) return -992;
   if (info[0] != 0) return info[0];          // Cholesky: leading minor not positive definite
   if (info[1] != 0) return 100000 + info[1];  // tridiagonal eigensolver did not converge
   return 0;
@@ -579,6 +745,22 @@ int ek_hip_solve_device(int problem, int n, int n_vec, double *dA, int lda, doub
   if (n == 0) return 0;
   std::lock_guard<std::mutex> lk(g_mu);
   return solve_device_locked(problem, n, n_vec, dA, lda, dB, ldb, dw, dZ, ldz, stage_seconds, n_stages);
+}
+
+// Pure host arithmetic (no GPU needed): bytes of workspace one whole-path call asks for -- on one GPU (nranks <= 1: all
+// n_vec eigenvector columns) or as rank 0 of a 1 x nranks team with a communicator attached (its share of the columns,
+// 64-wide blocks dealt round robin).  parts (optional, 6 entries): matrix bytes (one padded n x n array), persistent
+// operators (L, the first stage's reflectors), eigenvector columns, X0, X1, the rest.
+unsigned long long ek_hip_debug_workspace_bytes(int problem, int n, int n_vec, int nranks, unsigned long long *parts) {
+  if (n < 1 || n_vec < 0 || n_vec > n) return 0;
+  const int P = nranks > 1 ? nranks : 1;
+  const int nc_loc = P > 1 ? numroc0(n_vec, 64, 0, P) : n_vec;
+  const PathPlan p = plan_path(problem, n, n_vec, nc_loc, P > 1 ? P : 0);
+  if (parts) {
+    parts[0] = p.mat; parts[1] = 2 * p.mat; parts[2] = p.zmat; parts[3] = p.x0; parts[4] = p.x1;
+    parts[5] = p.total - (2 * p.mat + p.zmat + p.x0 + p.x1);
+  }
+  return p.total;
 }
 
 int ek_hip_set_allgatherv(ek_hip_allgatherv_fn fn, void *user) {
@@ -711,9 +893,9 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
     if (!rc) rc = mem.alloc(&pk, nn * 8);
     if (!rc) rc = mem.alloc(&uZ, (size_t)ldzl * (ncz > 0 ? ncz : 1) * 8);
     if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
+    g_comm.err = 0;
     rc = comm_agree(rc);                 // nobody enters the all-gathers below unless everybody can
     if (rc) return rc;
-    g_comm.err = 0;
     auto assemble = [&](const double *M_loc, const int *desc, double *full) -> int {
       const int nb = desc[4];
       size_t offs[kMaxTeam], counts[kMaxTeam];

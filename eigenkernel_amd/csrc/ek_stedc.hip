@@ -41,6 +41,10 @@ struct DcBufs {
   long long *goffs;              // per merge 2 x {A, B, C} element offsets of the two merge GEMMs
   int *gdims;                    // per merge 2 x {M, N, K}
   int ldw, ldq, lds;             // leading dimensions of W (the output array), Q, S
+  // Compact storage of the bases (selected columns <= half of them: a grid cell's share, a *_select arm): below the top
+  // merge every block lives inside one half of the matrix, so the blocks of the second half are stored hq / hw / hs
+  // columns to the left -- an n x (n - n/2) array holds a whole level.  INT_MAX: no shift (columns as numbered).
+  int hq = 0x7fffffff, hw = 0x7fffffff, hs = 0x7fffffff;
   int *rotp, *rotn;              // n: rotation list (sorted positions)
   double *rotc, *rots;           // n
   double *rho;                   // per merge
@@ -48,6 +52,10 @@ struct DcBufs {
   Merge *merges;
   double *orgnrm;                // 1
 };
+
+__device__ __forceinline__ size_t cq(const DcBufs &b, int c) { return (size_t)(c >= b.hq ? c - b.hq : c); }
+__device__ __forceinline__ size_t cw(const DcBufs &b, int c) { return (size_t)(c >= b.hw ? c - b.hw : c); }
+__device__ __forceinline__ size_t cs(const DcBufs &b, int c) { return (size_t)(c >= b.hs ? c - b.hs : c); }
 
 // ------------------------------------------------------------------ scaling / splits
 __global__ void dc_scale_kernel(int n, const double *__restrict__ din, const double *__restrict__ ein,
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const Leaf *__restrict__ le
   __syncthreads();
   if (lane < n) {
     b.d[lf.off + lane] = sd[lane];
-    for (int c = 0; c < n; ++c) Q[(size_t)(lf.off + lane) + (size_t)(lf.off + c) * ldq] = sZ[c][lane];
+    for (int c = 0; c < n; ++c) Q[(size_t)(lf.off + lane) + cq(b, lf.off + c) * ldq] = sZ[c][lane];
   }
 }
 
@@ -173,8 +181,8 @@ __global__ void dc_sort_kernel(int mbeg, DcBufs b, const double *__restrict__ Q,
   const double rho_in = b.e[mg.off + mg.n1 - 1];
   const double is2 = 0.70710678118654752440;
   double z;
-  if (t < mg.n1) z = Q[(size_t)(mg.off + mg.n1 - 1) + (size_t)(mg.off + t) * ldq] * is2;
-  else z = (rho_in < 0.0 ? -1.0 : 1.0) * Q[(size_t)(mg.off + mg.n1) + (size_t)(mg.off + t) * ldq] * is2;
+  if (t < mg.n1) z = Q[(size_t)(mg.off + mg.n1 - 1) + cq(b, mg.off + t) * ldq] * is2;
+  else z = (rho_in < 0.0 ? -1.0 : 1.0) * Q[(size_t)(mg.off + mg.n1) + cq(b, mg.off + t) * ldq] * is2;
   b.perm[mg.off + rank] = t;
   b.dsort[mg.off + rank] = dt;
   b.zsort[mg.off + rank] = z;
@@ -271,9 +279,10 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
         const long long o = off;
         long long *go = b.goffs + 6 * (size_t)mi;
         int *gd = b.gdims + 6 * (size_t)mi;
-        go[0] = o + o * b.ldw;                       go[1] = o + o * b.lds;        go[2] = o + o * b.ldq;
+        const long long ow = (long long)cw(b, off), os = (long long)cs(b, off), oq = (long long)cq(b, off);   // (block columns as stored)
+        go[0] = o + ow * b.ldw;                      go[1] = o + os * b.lds;       go[2] = o + oq * b.ldq;
         const int k1e = k1f & ~1;                    // even start of the second product (see below)
-        go[3] = o + mg.n1 + (o + k1e) * b.ldw;       go[4] = o + k1e + o * b.lds;  go[5] = o + mg.n1 + o * b.ldq;
+        go[3] = o + mg.n1 + (ow + k1e) * b.ldw;      go[4] = o + k1e + os * b.lds; go[5] = o + mg.n1 + oq * b.ldq;
         gd[0] = mg.n1;        gd[1] = kf; gd[2] = k1f;
         gd[3] = n - mg.n1;    gd[4] = kf; gd[5] = k3f + (k1f - k1e);
         b.k[mi] = kf; b.nrot[mi] = 0; b.rho[mi] = rho;
@@ -331,12 +340,13 @@ __global__ __launch_bounds__(256) void dc_deflate_kernel(int mbeg, DcBufs b) {
     const long long o = off;
     long long *go = b.goffs + 6 * (size_t)mi;
     int *gd = b.gdims + 6 * (size_t)mi;
-    go[0] = o + o * b.ldw;                       go[1] = o + o * b.lds;        go[2] = o + o * b.ldq;
+    const long long ow = (long long)cw(b, off), os = (long long)cs(b, off), oq = (long long)cq(b, off);       // (block columns as stored)
+    go[0] = o + ow * b.ldw;                      go[1] = o + os * b.lds;       go[2] = o + oq * b.ldq;
     // (the second product starts on an EVEN column of W / row of S: if k1 is odd it takes the last top-only
     // column along, whose bottom rows are zero -- the operands of both products then start on even offsets
     // whenever off and n1 are even, which is what the GEMM's 16-byte loads need)
     const int k1e = k1 & ~1;
-    go[3] = o + mg.n1 + (o + k1e) * b.ldw;       go[4] = o + k1e + o * b.lds;  go[5] = o + mg.n1 + o * b.ldq;
+    go[3] = o + mg.n1 + (ow + k1e) * b.ldw;      go[4] = o + k1e + os * b.lds; go[5] = o + mg.n1 + oq * b.ldq;
     gd[0] = mg.n1;        gd[1] = k; gd[2] = k12;
     gd[3] = n - mg.n1;    gd[4] = k; gd[5] = k23 + (k1 - k1e);
   }
@@ -352,7 +362,7 @@ __global__ void dc_permute_kernel(int mbeg, DcBufs b, const double *__restrict__
   const int off = mg.off;
   for (int t = blockIdx.y; t < mg.n; t += gridDim.y) {
     const int src = b.perm[off + t], dst = b.wcol[off + t];
-    W[(size_t)(off + r) + (size_t)(off + dst) * ldw] = Q[(size_t)(off + r) + (size_t)(off + src) * ldq];
+    W[(size_t)(off + r) + cw(b, off + dst) * ldw] = Q[(size_t)(off + r) + cq(b, off + src) * ldq];
   }
 }
 
@@ -362,7 +372,7 @@ __global__ void dc_rotate_kernel(int mbeg, DcBufs b, double *__restrict__ W, int
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= mg.n) return;
   const int off = mg.off, nrot = b.nrot[mi];
-  double *Wr = W + (size_t)(off + r) + (size_t)off * ldw;
+  double *Wr = W + (size_t)(off + r) + cw(b, off) * ldw;
   for (int q = 0; q < nrot; ++q) {
     const int cp = b.wcol[off + b.rotp[off + q]], cn = b.wcol[off + b.rotn[off + q]];
     const double c = b.rotc[off + q], s = b.rots[off + q];
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(256) void dc_vectors_kernel(int mbeg, DcBufs b, dou
   const int c = blockIdx.x, t = threadIdx.x;
   const int k = b.k[mi];
   if (c >= k) return;
-  double *col = S + (size_t)mg.off + (size_t)(mg.off + c) * lds;
+  double *col = S + (size_t)mg.off + cs(b, mg.off + c) * lds;
   const double *dl = b.dl + mg.off, *zh = b.zhat + mg.off;
   const int *grp = b.grp + mg.off;
   const double dK = dl[b.korig[mg.off + c]], tau = b.tauv[mg.off + c];
@@ -547,7 +557,7 @@ __global__ void dc_copy_deflated_kernel(int mbeg, DcBufs b, const double *__rest
   if (r >= mg.n) return;
   const int k = b.k[mi], off = mg.off;
   for (int c = k + blockIdx.y; c < mg.n; c += gridDim.y)
-    Q[(size_t)(off + r) + (size_t)(off + c) * ldq] = W[(size_t)(off + r) + (size_t)(off + c) * ldw];
+    Q[(size_t)(off + r) + cq(b, off + c) * ldq] = W[(size_t)(off + r) + cw(b, off + c) * ldw];
 }
 
 // ------------------------------------------------------------------ final ordering
@@ -644,14 +654,25 @@ struct Plan {
   }
 };
 
+// nsel: eigenvector columns the caller wants (-1 or n: all).  With at most half of them (a grid cell's share of a team of
+// two or more, a *_select arm) the bases are kept COMPACT: below the top merge every block lies inside one half of the
+// matrix, so a level fits n x h2 (h2 = n - n/2) with the second half's blocks stored n/2 columns to the left (DcBufs::hq,
+// hw, hs); the top merge needs the permuted basis at full width once, where the lower levels' W and S used to be, and
+// its S and result have nsel columns: 1.5 n^2 + n nsel doubles instead of the 3 n^2 of the full form with a separate
+// scratch for the permuted bases.
 struct WorkLayout {
-  size_t off_Q, off_S, off_vec, off_int, off_merge, off_leaf, off_offs, off_dims, total;
+  size_t off_Q, off_S, off_Ssel, off_vec, off_int, off_merge, off_leaf, off_offs, off_dims, total;
   int nmerge_cap, nleaf_cap;
-  explicit WorkLayout(int n) {
+  bool compact;
+  int h2;
+  explicit WorkLayout(int n, int nsel = -1) {
     nleaf_cap = n / (LEAF / 2) + 2; nmerge_cap = nleaf_cap;
+    h2 = n - n / 2;
+    compact = nsel >= 0 && nsel < n && nsel <= h2 && n > LEAF;
     size_t o = 0;
-    off_Q = o; o += al256((size_t)n * n * 8);
-    off_S = o; o += al256((size_t)n * n * 8);
+    off_Q = o; o += al256((size_t)n * (compact ? h2 : n) * 8);
+    off_S = o; o += al256((size_t)n * (compact ? 2 * h2 : n) * 8);      // compact: [W | S] of a lower level, W of the top merge
+    off_Ssel = o; o += compact ? al256((size_t)n * (nsel > 0 ? nsel : 1) * 8) : 0;
     off_vec = o; o += 12 * al256((size_t)(n + 8) * 8) + al256((size_t)nmerge_cap * 8) + 256;
     off_int = o; o += 8 * al256((size_t)(n + 8) * 4) + 2 * al256((size_t)nmerge_cap * 4);
     off_merge = o; o += al256((size_t)nmerge_cap * sizeof(Merge));
@@ -664,7 +685,8 @@ struct WorkLayout {
 
 }  // namespace
 
-size_t stedc_work_bytes(int n) { return WorkLayout(n > 0 ? n : 1).total; }
+size_t stedc_work_bytes(int n, int nsel) { return WorkLayout(n > 0 ? n : 1, nsel).total; }
+bool stedc_compact(int n, int nsel) { return WorkLayout(n > 0 ? n : 1, nsel).compact; }
 
 namespace {
 // flops of the eigenvector products this solve really ran: 2 M N K over the two GEMMs of every merge, with the
@@ -684,11 +706,16 @@ __global__ void dc_flops_kernel(int nmerge, const int *__restrict__ gdims, doubl
 void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z, int ldz,
            void *work, int *d_info, const StedcSelect *sel, double *d_flops, double *wscratch) {
   if (n <= 0) return;
-  const WorkLayout L(n);
+  const WorkLayout L(n, sel ? sel->nsel : -1);
   char *base = (char *)work;
   double *Q = (double *)(base + L.off_Q);      // current eigenvector basis (ld = n)
   double *S = (double *)(base + L.off_S);      // rank-one eigenvector matrices (ld = n)
   const int ldq = n, lds = n;
+  const bool compact = L.compact;
+  const int half = n / 2;                      // n1 of the top merge (Plan::height)
+  double *Wbig = S;                            // compact: the permuted bases live in the workspace (ld = n)
+  if (compact) S = Wbig + (size_t)n * L.h2;
+  const int ldw = compact ? n : ldz;
   DcBufs b;
   {
     char *p = base + L.off_vec;
@@ -706,7 +733,8 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     b.merges = (Merge *)(base + L.off_merge);
     b.goffs = (long long *)(base + L.off_offs);
     b.gdims = (int *)(base + L.off_dims);
-    b.ldw = ldz; b.ldq = ldq; b.lds = lds;
+    b.ldw = ldw; b.ldq = ldq; b.lds = lds;
+    if (compact) b.hq = b.hw = b.hs = half;
   }
   int *fperm = (int *)(base + L.off_int + 5 * al256((size_t)(n + 8) * 4));
   Leaf *d_leaves = nullptr;
@@ -751,27 +779,32 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
   if (!all.empty())
     hipLaunchKernelGGL(dc_split_kernel, dim3(ceil_div((int)all.size(), 256)), dim3(256), 0, s,
                        (int)all.size(), b);
-  (void)hipMemsetAsync(Q, 0, (size_t)n * n * 8, s);
+  (void)hipMemsetAsync(Q, 0, (size_t)n * (compact ? L.h2 : n) * 8, s);
   hipLaunchKernelGGL(dc_leaf_kernel, dim3((int)plan.leaves.size()), dim3(64), 0, s, d_leaves, b, Q, ldq,
                      d_info);
 
   auto count_flops = [&]() {
     if (d_flops) hipLaunchKernelGGL(dc_flops_kernel, dim3(1), dim3(256), 0, s, (int)all.size(), b.gdims, d_flops);
   };
-  double *W = wscratch ? wscratch : Z;   // (the output array doubles as the permuted-basis scratch until the end)
+  double *W = compact ? Wbig : (wscratch ? wscratch : Z);   // (full form: the output array doubles as the permuted-basis scratch until the end)
   const bool selecting = sel && sel->nsel < n;
   bool sel_done = false;
   for (size_t lv = 0; lv < plan.levels.size(); ++lv) {
     const int mbeg = lvl_beg[lv], cnt = lvl_beg[lv + 1] - mbeg;
     int maxn = 0;
-    bool even = ((ldz | ldq | lds) & 1) == 0;      // every merge of this height starts on even rows and columns
+    bool even = ((ldw | ldq | lds) & 1) == 0;      // every merge of this height starts on even rows and columns
     for (auto &m : plan.levels[lv]) { maxn = std::max(maxn, m.n); even = even && ((m.off | m.n1) & 1) == 0; }
     const int gx = ceil_div(maxn, 256);
+    const bool top = lv + 1 == plan.levels.size();
+    if (compact && top) {                 // the top merge: W at full width, S (n x nsel) in its own array; Q stays compact
+      b.hw = b.hs = 0x7fffffff;
+      S = (double *)(base + L.off_Ssel);
+    }
     hipLaunchKernelGGL(dc_sort_kernel, dim3(ceil_div(maxn * RP, 256), cnt), dim3(256), 0, s, mbeg, b, Q, ldq);
     hipLaunchKernelGGL(dc_deflate_kernel, dim3(cnt), dim3(256), 0, s, mbeg, b);
     const int gy = std::min(maxn, std::max(1, 4096 / std::max(1, gx * cnt)));
-    hipLaunchKernelGGL(dc_permute_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, Q, ldq, W, ldz);
-    hipLaunchKernelGGL(dc_rotate_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, W, ldz);
+    hipLaunchKernelGGL(dc_permute_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, Q, ldq, W, ldw);
+    hipLaunchKernelGGL(dc_rotate_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, W, ldw);
     hipLaunchKernelGGL(dc_secular_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
     hipLaunchKernelGGL(dc_zhat_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
     if (selecting && lv + 1 == plan.levels.size()) {
@@ -788,13 +821,13 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
       GemmDesc g{};
       g.M = (maxn + 1) / 2; g.N = sel->nsel; g.K = maxn; g.transA = false; g.transB = false;
       g.alpha = 1.0; g.beta = 0.0;
-      g.A = W; g.lda = ldz; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
+      g.A = W; g.lda = ldw; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
       g.C = Q; g.ldc = ldq; g.strideC = 0; g.batch = 2; g.lower_only = false;
       g.d_offs = b.goffs + 6 * (size_t)mbeg; g.d_dims = b.gdims + 6 * (size_t)mbeg; g.even_offs = even;
       gemm(s, g);
       const int gys = std::min(sel->nsel, std::max(1, 4096 / gx));
       hipLaunchKernelGGL(dc_copy_deflated_sel_kernel, dim3(gx, gys), dim3(256), 0, s, mbeg, b, sel->nsel, selcol,
-                         W, ldz, Q, ldq);
+                         W, ldw, Q, ldq);
       copy_matrix(s, n, sel->nsel, Q, ldq, Z, ldz);
       break;
     }
@@ -805,11 +838,11 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     GemmDesc g{};
     g.M = (maxn + 1) / 2; g.N = maxn; g.K = maxn; g.transA = false; g.transB = false;
     g.alpha = 1.0; g.beta = 0.0;
-    g.A = W; g.lda = ldz; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
+    g.A = W; g.lda = ldw; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
     g.C = Q; g.ldc = ldq; g.strideC = 0; g.batch = 2 * cnt; g.lower_only = false;
     g.d_offs = b.goffs + 6 * (size_t)mbeg; g.d_dims = b.gdims + 6 * (size_t)mbeg; g.even_offs = even;
     gemm(s, g);
-    hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldz, Q, ldq);
+    hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldw, Q, ldq);
   }
   count_flops();
   if (sel_done) return;

@@ -26,6 +26,7 @@
 #include "ek_block64.h"
 
 #include <cstdlib>
+#include <vector>
 
 namespace ek {
 namespace {
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(int npart, const doub
 // (*pflag: the flag of THIS panel, written here -- 0 or 1 -- and possibly raised by hr_kernel: a panel CholeskyQR2
 // cannot factor goes to the Householder rescue below)
 __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G, double *__restrict__ R,
-                                                   double *__restrict__ Rinv, int *pflag) {
+                                                   double *__restrict__ Rinv, int *pflag, const int *nz) {
   __shared__ double sA[IMG], sB[IMG];
   __shared__ double s_inv[kScratch];
   const int t = threadIdx.x;
@@ -249,11 +250,13 @@ __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G,
 #pragma unroll
   for (int k = 0; k < 16; ++k) { const int idx = t + 256 * k; sA[(idx >> 6) * LD + (idx & 63)] = gv[k]; }
   __syncthreads();
-  // (an all-zero panel -- an input that is already banded -- has a zero Gram matrix: flag 4, the rescue's short cut)
+  // (an all-zero panel -- an input that is already banded: flag 4, the rescue's short cut.  The test is the first
+  // pass's scan of the entries themselves (*nz = 1 + the last chunk with a non-zero entry), not the Gram diagonal: the
+  // squares of a column of entries below 1e-162 underflow to a zero diagonal, and such a panel is not zero)
   __shared__ int s_nz;
-  if (t == 0) s_nz = 0;
+  if (t == 0) s_nz = nz ? (*nz != 0) : 0;
   __syncthreads();
-  if (t < SB && sA[t * LD + t] != 0.0) atomicOr(&s_nz, 1);
+  if (!nz && t < SB && sA[t * LD + t] != 0.0) atomicOr(&s_nz, 1);
   __syncthreads();
   const int zero_panel = !s_nz;
   const int bad = chol64_upper_wg(sA, s_inv);
@@ -999,7 +1002,7 @@ struct Layout {
   size_t off_img, off_img2, off_qt, off_y, off_ypart, off_gpart, off_gpart2, off_small, total;
   // team form (P > 0): the panel message [V | T | tau], the table of the strip updates
   int maxb = 0, npanels = 0;
-  size_t off_msg = 0, off_offs = 0, off_dims = 0, msg_doubles = 0;
+  size_t off_msg = 0, off_offs = 0, off_dims = 0, off_offs2 = 0, off_dims2 = 0, msg_doubles = 0;
   explicit Layout(int n, int P = 0) {
     mpad = round_up(n > 0 ? n : 1, 128);
     nparts = mpad / CH + 1;
@@ -1020,6 +1023,8 @@ struct Layout {
       off_msg = o; o += al256(msg_doubles * 8);
       off_offs = o; o += al256((size_t)npanels * maxb * 3 * sizeof(long long));
       off_dims = o; o += al256((size_t)npanels * maxb * 3 * sizeof(int));
+      off_offs2 = o; o += al256((size_t)npanels * maxb * 3 * sizeof(long long));
+      off_dims2 = o; o += al256((size_t)npanels * maxb * 3 * sizeof(int));
     }
     total = o;
   }
@@ -1062,7 +1067,7 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
   pa.m = m; pa.src = Ap; pa.lds_ = lda; pa.Gpart = b.Gpart2; pa.nz = b.nzrows ? b.nzrows + c0 / SB : nullptr;
   hipLaunchKernelGGL(panel_kernel<0>, dim3(nch), dim3(256), 0, st, pa);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2);
-  hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, b.Gred2, b.R1, b.R1inv, b.pflag);
+  hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, b.Gred2, b.R1, b.R1inv, b.pflag, pa.nz);
   pa.M = b.R1; pa.dst = b.Qt; pa.ldd = b.mpad;           // (Q1 = A R1^-1 by substitution against R1 itself)
   hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, st, pa);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2);
@@ -1082,17 +1087,18 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
 }
 
 // team form: the strips a member updates after panel p (batched GEMM: one problem per owned strip that still has
-// columns at or beyond r0 = 64 (p + 1)).  Entry (panel, k): element offsets {A, B, C} and dims {M, N, K}; the
-// operands are the rows of the image [W | V | W] from the strip's first column on.
-__global__ void strip_table_kernel(int n, int lda, int P, int rank, int maxb, long long *offs, int *dims) {
+// columns at or beyond cs = 64 (p + 1) + skip).  Entry (panel, k): element offsets {A, B, C} and dims {M, N, K}; the
+// operands are the rows of the image [W | V | W] from the strip's first column on.  skip = 64: the table of the member
+// that owns the NEXT panel when the look-ahead has already updated that panel's 64 columns on their own.
+__global__ void strip_table_kernel(int n, int lda, int P, int rank, int maxb, long long *offs, int *dims, int skip) {
   const int panel = blockIdx.x, k = threadIdx.x;
   if (k >= maxb) return;
-  const int r0 = (panel + 1) * SB;
-  const int Sf = r0 / 128;
+  const int r0 = (panel + 1) * SB, cs = r0 + skip;
+  const int Sf = cs / 128;
   const int Sfl = Sf + ((rank - Sf) % P + P) % P;
   const int S = Sfl + k * P;
   long long c0 = (long long)S * 128;
-  if (c0 < r0) c0 = r0;
+  if (c0 < cs) c0 = cs;
   int M = 0, N = 0;
   if (c0 < n) {
     M = n - (int)c0;
@@ -1104,6 +1110,23 @@ __global__ void strip_table_kernel(int n, int lda, int P, int rank, int maxb, lo
   offs[3 * e] = c0 - r0; offs[3 * e + 1] = c0 - r0; offs[3 * e + 2] = c0 * ((long long)lda + 1);
   dims[3 * e] = M; dims[3 * e + 1] = N; dims[3 * e + 2] = 2 * SB;
 }
+
+// optional per-panel timing of the team form (tools/team_timing.py): HIP events around every panel chain and around
+// every "rest of the trailing update" section, on the streams they run on
+struct DistProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;      // pairs (begin, end)
+  std::vector<int> kind;           // per pair: 0 = panel chain (+ packing), 1 = rest of the update
+  hipEvent_t mark(hipStream_t st) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    (void)hipEventRecord(e, st);
+    ev.push_back(e);
+    return e;
+  }
+};
+DistProf g_dprof;
+int g_dist_la_min = -1;            // rows from which the team form looks ahead (0: never); -1: environment / default
 
 }  // namespace
 
@@ -1225,62 +1248,146 @@ size_t sy2sb_dist_work_bytes(int n, int nranks) { return Layout(n, nranks > 0 ? 
 // Two bandwidth-bound exchanges per panel, n/64 panels; a member reads and writes only columns it owns.  V, T,
 // tau, and therefore the reflectors for the back-transformation, end up complete and identical on every member;
 // the band stays distributed by strips (the caller gathers its 65 diagonals: 8 n^2 / 128 bytes... 65 n doubles).
-void sy2sb_lower_dist(hipStream_t s, int n, int nmem, const Sy2sbMember *mem, const SytrdExchange &x) {
+void sy2sb_dist_set_lookahead(int min_rows) { g_dist_la_min = min_rows; }
+void sy2sb_dist_profile(bool on) {
+  for (auto &e : g_dprof.ev) (void)hipEventDestroy(e);
+  g_dprof.ev.clear(); g_dprof.kind.clear();
+  g_dprof.on = on;
+}
+// after the streams have been synchronised: seconds[0] = all panel chains, seconds[1] = all "rest of the update" sections,
+// seconds[2] = the first chain + the sum over the panels of max(chain of panel p + 1, (update of panel p) / P): what the
+// two cost a rank of a real team of P when the chain (one rank, the others wait for its broadcast) runs beside the
+// update (every rank its 1 / P) -- meaningful for a rehearsal WITHOUT look-ahead, where the sections do not overlap on
+// the one GPU
+void sy2sb_dist_profile_collect(double *seconds, int P) {
+  seconds[0] = seconds[1] = seconds[2] = 0.0;
+  double last_update = -1.0;
+  for (size_t q = 0; q < g_dprof.kind.size(); ++q) {
+    float ms = 0.f;
+    if (!(g_dprof.ev[2 * q] && g_dprof.ev[2 * q + 1] && hipEventElapsedTime(&ms, g_dprof.ev[2 * q], g_dprof.ev[2 * q + 1]) == hipSuccess)) continue;
+    const double t = ms * 1e-3;
+    seconds[g_dprof.kind[q]] += t;
+    if (g_dprof.kind[q] == 1) {
+      if (last_update >= 0.0) seconds[2] += last_update / (P > 0 ? P : 1);    // (an update no chain followed)
+      last_update = t;
+    } else {
+      const double u = last_update >= 0.0 ? last_update / (P > 0 ? P : 1) : 0.0;
+      seconds[2] += (t > u) ? t : u;
+      last_update = -1.0;
+    }
+  }
+  if (last_update >= 0.0) seconds[2] += last_update / (P > 0 ? P : 1);
+  sy2sb_dist_profile(g_dprof.on);
+}
+
+// Look-ahead (round 4; the single-GPU form has had it since round 2): as soon as W of panel p exists, the member that
+// owns panel p + 1 updates that panel's 64 columns alone; then the chain of panel p + 1, the broadcast of its
+// [V | T | tau] and the unpacking on the other members run on the second stream s2 while every member applies the rest
+// of update p to its strips on s.  The images [W | V | W] and T are double-buffered for that.  On a real team the
+// owner's chain (about 0.25 ms, alone on its GPU) and the broadcast are then hidden behind the update of the other
+// strips as far as that lasts; the all-reduce of Y stays on s behind the SYMM it sums.  Same arithmetic on every
+// element as without (EK_SY2SB_DIST_LOOKAHEAD_MIN=0): same bits.
+void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2sbMember *mem, const SytrdExchange &x) {
   if (n <= 2 || nmem <= 0 || nmem > kMaxTeam) return;
   ensure_attrs();
+  static bool evs = false;
+  static hipEvent_t evA[2], evB[2];
+  if (!evs) {
+    for (int q = 0; q < 2; ++q) {
+      (void)hipEventCreateWithFlags(&evA[q], hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&evB[q], hipEventDisableTiming);
+    }
+    evs = true;
+  }
+  static int la_env = -2;
+  if (la_env == -2) { const char *e = getenv("EK_SY2SB_DIST_LOOKAHEAD_MIN"); la_env = e ? atoi(e) : -1; }
+  const int la_min = g_dist_la_min >= 0 ? g_dist_la_min : (la_env >= 0 ? la_env : 1024);
+  const bool la_on = s2 != nullptr && la_min > 0;
   const int P = x.nranks;
   const Layout L(n, P);
   const int ldi = L.mpad;
-  struct St { double *img, *Qt, *Y, *Ypart, *Gpart, *sm, *msg; long long *offs; int *dims; ChainBufs cb; };
+  struct St { double *img[2], *Tm[2], *Qt, *Y, *Ypart, *Gpart, *sm, *msg; long long *offs, *offs2; int *dims, *dims2; ChainBufs cb; };
   St st[kMaxTeam];
   double *msgs[kMaxTeam], *ys[kMaxTeam];
   for (int q = 0; q < nmem; ++q) {
     char *w = (char *)mem[q].work;
     St &m = st[q];
-    m.img = (double *)(w + L.off_img); m.Qt = (double *)(w + L.off_qt); m.Y = (double *)(w + L.off_y);
+    m.img[0] = (double *)(w + L.off_img); m.img[1] = (double *)(w + L.off_img2);
+    m.Qt = (double *)(w + L.off_qt); m.Y = (double *)(w + L.off_y);
     m.Ypart = (double *)(w + L.off_ypart); m.Gpart = (double *)(w + L.off_gpart); m.sm = (double *)(w + L.off_small);
     m.msg = (double *)(w + L.off_msg); m.offs = (long long *)(w + L.off_offs); m.dims = (int *)(w + L.off_dims);
+    m.offs2 = (long long *)(w + L.off_offs2); m.dims2 = (int *)(w + L.off_dims2);
     double *sm = m.sm;
+    m.Tm[0] = sm + 4 * 4096; m.Tm[1] = sm + 9 * 4096;
     m.cb = ChainBufs{n, L.mpad, m.Qt, (double *)(w + L.off_gpart2), sm + 11 * 4096, sm + 4096, sm + 2 * 4096, sm + 3 * 4096,
                      sm + 5 * 4096, sm + 6 * 4096, nullptr, (int *)(sm + 12 * 4096), (int *)(sm + 13 * 4096)};
     (void)hipMemsetAsync(sm + 13 * 4096, 0, (size_t)ceil_div(n, SB) * sizeof(int), s);
     msgs[q] = m.msg; ys[q] = m.Y;
     hipLaunchKernelGGL(strip_table_kernel, dim3(L.npanels), dim3(round_up(L.maxb, 64)), 0, s, n, mem[q].lda, P, mem[q].rank,
-                       L.maxb, m.offs, m.dims);
+                       L.maxb, m.offs, m.dims, 0);
+    if (la_on)
+      hipLaunchKernelGGL(strip_table_kernel, dim3(L.npanels), dim3(round_up(L.maxb, 64)), 0, s, n, mem[q].lda, P, mem[q].rank,
+                         L.maxb, m.offs2, m.dims2, SB);
   }
-  int p = 0;
-  for (int c0 = 0; ; c0 += SB, ++p) {
-    const int r0 = c0 + SB, m = n - r0;
-    if (m < 2) break;
+  const int NRB = ceil_div(n, 128);
+  // panel p on stream sp into image / T buffer `buf`: the owner factors it and packs [V | T | tau]; one broadcast; everybody
+  // else unpacks V into its image and into the reflector matrix, T, tau
+  auto issue_panel = [&](hipStream_t sp, int p, int buf) {
+    const int c0 = p * SB, r0 = c0 + SB, m = n - r0;
     const int owner = (c0 / 128) % P;
     const int ldy = round_up(m, 2);
     const size_t vcount = (size_t)ldy * SB;
-    // ---- the owner factors the panel and packs the message
     for (int q = 0; q < nmem; ++q) {
       if (mem[q].rank != owner) continue;
       St &M = st[q];
-      double *Tp = M.sm + 4 * 4096;
-      panel_chain(s, M.cb, mem[q].A, mem[q].lda, mem[q].Vall, mem[q].ldv, mem[q].tau1, mem[q].d_flag, c0, M.img, Tp);
+      hipEvent_t e0 = g_dprof.on ? g_dprof.mark(sp) : nullptr;
+      panel_chain(sp, M.cb, mem[q].A, mem[q].lda, mem[q].Vall, mem[q].ldv, mem[q].tau1, mem[q].d_flag, c0, M.img[buf], M.Tm[buf]);
       if (P > 1) {                      // (only the m rows of the panel travel: V is packed with leading dimension ldy)
-        copy_matrix(s, m, SB, M.img + (size_t)SB * ldi, ldi, M.msg, ldy);
-        (void)hipMemcpyAsync(M.msg + vcount, Tp, (size_t)SB * SB * 8, hipMemcpyDeviceToDevice, s);
-        (void)hipMemcpyAsync(M.msg + vcount + SB * SB, mem[q].tau1 + c0, (size_t)SB * 8, hipMemcpyDeviceToDevice, s);
+        copy_matrix(sp, m, SB, M.img[buf] + (size_t)SB * ldi, ldi, M.msg, ldy);
+        (void)hipMemcpyAsync(M.msg + vcount, M.Tm[buf], (size_t)SB * SB * 8, hipMemcpyDeviceToDevice, sp);
+        (void)hipMemcpyAsync(M.msg + vcount + SB * SB, mem[q].tau1 + c0, (size_t)SB * 8, hipMemcpyDeviceToDevice, sp);
       }
+      if (e0) { g_dprof.mark(sp); g_dprof.kind.push_back(0); }
     }
     if (P > 1) {
       size_t offs[kMaxTeam], counts[kMaxTeam];
       for (int r = 0; r < P; ++r) { offs[r] = 0; counts[r] = (r == owner) ? vcount + SB * SB + SB : 0; }
-      x.allgatherv(s, nmem, mem[0].rank, msgs, offs, counts, P, x.user);
+      x.allgatherv(sp, nmem, mem[0].rank, msgs, offs, counts, P, x.user);
     }
-    // ---- everybody else unpacks: V into its image and into the reflector matrix, T, tau
     for (int q = 0; q < nmem; ++q) {
       if (mem[q].rank == owner) continue;
       St &M = st[q];
-      copy_matrix(s, m, SB, M.msg, ldy, M.img + (size_t)SB * ldi, ldi);
-      (void)hipMemcpyAsync(M.sm + 4 * 4096, M.msg + vcount, (size_t)SB * SB * 8, hipMemcpyDeviceToDevice, s);
-      (void)hipMemcpyAsync(mem[q].tau1 + c0, M.msg + vcount + SB * SB, (size_t)SB * 8, hipMemcpyDeviceToDevice, s);
-      copy_matrix(s, m, SB, M.msg, ldy, mem[q].Vall + (size_t)r0 + (size_t)c0 * mem[q].ldv, mem[q].ldv);
+      copy_matrix(sp, m, SB, M.msg, ldy, M.img[buf] + (size_t)SB * ldi, ldi);
+      (void)hipMemcpyAsync(M.Tm[buf], M.msg + vcount, (size_t)SB * SB * 8, hipMemcpyDeviceToDevice, sp);
+      (void)hipMemcpyAsync(mem[q].tau1 + c0, M.msg + vcount + SB * SB, (size_t)SB * 8, hipMemcpyDeviceToDevice, sp);
+      copy_matrix(sp, m, SB, M.msg, ldy, mem[q].Vall + (size_t)r0 + (size_t)c0 * mem[q].ldv, mem[q].ldv);
     }
+  };
+  // A(:, own strips) -= [W | V] [V | W]^T rows of the strip: the member's strips from column r0 + skip on
+  auto update_strips = [&](int q, int p, int buf, int skip) {
+    St &M = st[q];
+    const int r0 = (p + 1) * SB, m = n - r0, cs = r0 + skip;
+    const int Sf = cs / 128, rank = mem[q].rank;
+    const int Sfl = Sf + ((rank - Sf) % P + P) % P;
+    if (Sfl >= NRB) return;
+    const int nb = ceil_div(NRB - Sfl, P);
+    GemmDesc g{};
+    g.M = m; g.N = 128; g.K = 2 * SB; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
+    g.A = M.img[buf]; g.lda = ldi; g.strideA = 0; g.B = M.img[buf] + (size_t)SB * ldi; g.ldb = ldi; g.strideB = 0;
+    g.C = mem[q].A; g.ldc = mem[q].lda; g.strideC = 0; g.batch = nb; g.lower_only = true;
+    g.d_offs = (skip ? M.offs2 : M.offs) + (size_t)p * L.maxb * 3; g.d_dims = (skip ? M.dims2 : M.dims) + (size_t)p * L.maxb * 3;
+    gemm(s, g);
+  };
+
+  issue_panel(s, 0, 0);
+  bool waited = true;        // whether stream s already follows the chain / broadcast of the current panel
+  int p = 0;
+  for (int c0 = 0; ; c0 += SB, ++p) {
+    const int r0 = c0 + SB, m = n - r0;
+    if (m < 2) break;
+    const int cur = p & 1;
+    if (!waited) (void)hipStreamWaitEvent(s, evB[cur], 0);
+    const int ldy = round_up(m, 2);
     // ---- Y = A22 V: every member its own entries, then the sum over the team
     const int nch = ceil_div(m, CH);
     const int T = ceil_div(m, 128);
@@ -1292,7 +1399,7 @@ void sy2sb_lower_dist(hipStream_t s, int n, int nmem, const Sy2sbMember *mem, co
     for (int q = 0; q < nmem; ++q) {
       St &M = st[q];
       double *A22 = mem[q].A + (size_t)r0 + (size_t)r0 * mem[q].lda;
-      const double *V = M.img + (size_t)SB * ldi;
+      const double *V = M.img[cur] + (size_t)SB * ldi;
       SymmArgs sy{m, A22, mem[q].lda, V, ldi, M.Ypart, L.mpad, (long long)L.mpad * SB, T, tps, P, mem[q].rank, r0};
       hipLaunchKernelGGL(symm_lower_kernel<true>, dim3(T, nsplit), dim3(256), 0, s, sy);
       YredArgs ya{m, nsplit, M.Ypart, L.mpad, (long long)L.mpad * SB, M.Y, V, ldi, M.Gpart};
@@ -1302,27 +1409,39 @@ void sy2sb_lower_dist(hipStream_t s, int n, int nmem, const Sy2sbMember *mem, co
     if (P > 1) x.allreduce(s, nmem, ys, (size_t)ldy * SB, x.user);
     for (int q = 0; q < nmem; ++q) {
       St &M = st[q];
-      const double *V = M.img + (size_t)SB * ldi;
+      const double *V = M.img[cur] + (size_t)SB * ldi;
       if (P > 1) {    // G = V^T Y of the summed Y
         YredArgs yb{m, 1, M.Y, ldy, 0, M.Y, V, ldi, M.Gpart};
         yb.ldyo = ldy;
         hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, yb);
       }
       hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s, nch, M.Gpart, M.sm);
-      WArgs wa{m, M.Y, ldy, V, ldi, M.sm, M.sm + 4 * 4096, M.img, ldi};
+      WArgs wa{m, M.Y, ldy, V, ldi, M.sm, M.Tm[cur], M.img[cur], ldi};
       hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
-      // ---- A(:, own strips) -= [W | V] [V | W]^T rows of the strip
-      const int Sf = r0 / 128, rank = mem[q].rank;
-      const int Sfl = Sf + ((rank - Sf) % P + P) % P;
-      const int NRB = ceil_div(n, 128);
-      if (Sfl >= NRB) continue;
-      const int nb = ceil_div(NRB - Sfl, P);
-      GemmDesc g{};
-      g.M = m; g.N = 128; g.K = 2 * SB; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
-      g.A = M.img; g.lda = ldi; g.strideA = 0; g.B = M.img + (size_t)SB * ldi; g.ldb = ldi; g.strideB = 0;
-      g.C = mem[q].A; g.ldc = mem[q].lda; g.strideC = 0; g.batch = nb; g.lower_only = true;
-      g.d_offs = M.offs + (size_t)p * L.maxb * 3; g.d_dims = M.dims + (size_t)p * L.maxb * 3;
-      gemm(s, g);
+    }
+    const bool has_next = m - SB >= 2;
+    if (la_on && has_next && m >= la_min) {
+      const int owner_next = (r0 / 128) % P;
+      for (int q = 0; q < nmem; ++q) {       // the next panel's 64 columns first, on their owner
+        if (mem[q].rank != owner_next) continue;
+        St &M = st[q];
+        gemm(s, false, true, m, SB, 2 * SB, -1.0, M.img[cur], ldi, M.img[cur] + (size_t)SB * ldi, ldi, 1.0,
+             mem[q].A + (size_t)r0 + (size_t)r0 * mem[q].lda, mem[q].lda, true);
+      }
+      (void)hipEventRecord(evA[cur], s);
+      (void)hipStreamWaitEvent(s2, evA[cur], 0);
+      issue_panel(s2, p + 1, cur ^ 1);
+      (void)hipEventRecord(evB[cur ^ 1], s2);
+      hipEvent_t e0 = g_dprof.on ? g_dprof.mark(s) : nullptr;
+      for (int q = 0; q < nmem; ++q) update_strips(q, p, cur, mem[q].rank == owner_next ? SB : 0);
+      if (e0) { g_dprof.mark(s); g_dprof.kind.push_back(1); }
+      waited = false;
+    } else {
+      hipEvent_t e0 = g_dprof.on ? g_dprof.mark(s) : nullptr;
+      for (int q = 0; q < nmem; ++q) update_strips(q, p, cur, 0);
+      if (e0) { g_dprof.mark(s); g_dprof.kind.push_back(1); }
+      if (has_next) issue_panel(s, p + 1, cur ^ 1);
+      waited = true;
     }
   }
 }

@@ -119,6 +119,8 @@ def load_library(path=None):
         "ek_hip_debug_last_solve_stats": (c_int, [_dp, c_int]),
         "ek_hip_debug_sy2sb_team": (c_int, [c_int, _dp, c_int, _dp, c_int, _dp, c_int, _ip, _llp]),
         "ek_hip_debug_sy2sb_team_timing": (c_int, [c_int, c_int, c_int, _dp]),
+        "ek_hip_debug_sy2sb_team_profile": (c_int, [c_int, c_int, c_int, c_int, _dp, _dp]),
+        "ek_hip_debug_workspace_bytes": (ctypes.c_ulonglong, [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
     }
     for name, (res, args) in sigs.items():
         try:
@@ -148,7 +150,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_comm_peer_enable", "ek_hip_comm_peer_disable", "ek_hip_debug_set_sytrd_maxcols", "ek_hip_debug_sytrd_work_bytes", "ek_hip_debug_sytrd_at", "ek_hip_debug_sytrd_split", "ek_hip_debug_gemm_at",
     "ek_hip_debug_sy2sb", "ek_hip_debug_sb2st", "ek_hip_debug_two_stage_timing", "ek_hip_debug_set_two_stage",
     "ek_hip_profile_kernels", "ek_hip_profile_kernels_get", "ek_hip_debug_last_solve_stats",
-    "ek_hip_debug_sy2sb_team", "ek_hip_debug_sy2sb_team_timing",
+    "ek_hip_debug_sy2sb_team", "ek_hip_debug_sy2sb_team_timing", "ek_hip_debug_sy2sb_team_profile", "ek_hip_debug_workspace_bytes",
 )
 
 
@@ -447,6 +449,22 @@ BAND_W = 64   # half bandwidth of the two-stage tridiagonalisation (kBandW in cs
 def set_two_stage(min_order=-1):
     """Order from which the whole-path calls tridiagonalise in two stages (-1: default, 0: never)."""
     load_library().ek_hip_debug_set_two_stage(int(min_order))
+
+
+def last_solve_stats():
+    """What the last whole-path call did: [flops of the D&C's merge products, 1 if it stayed on the two-stage path,
+    panels of the first stage that took the Householder rescue, 1 if the band short cut was taken, ...]."""
+    st = (ctypes.c_double * 8)()
+    load_library().ek_hip_debug_last_solve_stats(st, 8)
+    return [float(x) for x in st]
+
+
+def workspace_bytes(problem, n, n_vec=None, nranks=1):
+    """Bytes of device workspace one whole-path call asks for (host arithmetic: works without a GPU): returns
+    (total, parts) with parts = [one matrix, L + Q1 reflectors, eigenvector columns, X0, X1, rest]."""
+    parts = (ctypes.c_ulonglong * 6)()
+    tot = load_library().ek_hip_debug_workspace_bytes(int(problem), int(n), int(n if n_vec is None else n_vec), int(nranks), parts)
+    return int(tot), [int(x) for x in parts]
 
 
 def sy2sb(A):

@@ -59,6 +59,10 @@ int ek_hip_debug_set_two_stage(int min_order);
 int ek_hip_debug_sy2sb_team(int n, double *A, int lda, double *V, int ldv, double *tau, int nteam, int *flag,
                             long long *mismatch);
 int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds);   /* device-generated matrix; whole team */
+/* the same with the look-ahead threshold of the team form set (0: none, -1: default) and, optionally, HIP-event sums of
+   the panel chains and of the "rest of the update" sections: parts[0..3] = stage, chains, rest-updates, and
+   first chain + sum over panels of max(chain p + 1, update p / P) (seconds; meaningful with lookahead_min = 0) */
+int ek_hip_debug_sy2sb_team_profile(int n, int nteam, int reps, int lookahead_min, double *seconds, double *parts);
 
 /* Counters of this process's last whole-path solve: out[0] = flops the merge products of the divide & conquer
  * executed (2 M N K over both GEMMs of every merge, with the dimensions deflation and the column selection left
@@ -67,6 +71,12 @@ int ek_hip_debug_sy2sb_team_timing(int n, int nteam, int reps, double *seconds);
  * factor and the Householder rescue did, out[3] = 1 if the matrix was already a band of half width 64 on entry and
  * the dense -> band stage (and Q1) were skipped. */
 int ek_hip_debug_last_solve_stats(double *out, int count);
+
+/* workspace one whole-path call asks for (host arithmetic, no GPU): one GPU (nranks <= 1) or rank 0 of a 1 x nranks team;
+   parts[0..5] (optional): one padded matrix, the persistent operators (L, Q1's reflectors), the eigenvector columns,
+   X0 (the matrix, then the bulge chasing's reflectors), X1 (scratch of the reduction -> D&C bases -> Q2's records -> Q1's
+   scratch), the rest.  ek_solve.hip plan_path. */
+unsigned long long ek_hip_debug_workspace_bytes(int problem, int n, int n_vec, int nranks, unsigned long long *parts);
 
 #ifdef __cplusplus
 }

@@ -475,3 +475,29 @@ def test_bench_reports_no_traffic_from_a_stale_pmc_record(tmp_path, monkeypatch)
     src.write_text("// kernel source, version 2\n")
     t, why = bench.q2_traffic_record(16384, 16384)
     assert t is None and "stale" in why
+
+
+def test_workspace_of_a_team_member_shrinks_with_the_team():
+    """the reference allocates numroc x numroc per rank (distribute_matrix.f90:128-138).  Here the
+    operators every rank applies in full to its own eigenvector columns (L, the reflectors of both stages) stay whole;
+    everything else is laid out by lifetime (ek_solve.hip plan_path): the matrix and the bulge chasing's reflectors share
+    one array, the D&C's bases (compact for a cell's share), Q2's records and the scratch of the other stages another,
+    and the eigenvector columns are the cell's own.  Round 3 asked 9.5 padded matrices + 0.13 GB on EVERY rank whatever
+    the team (DESIGN.md section 6 of that round: 20 GiB at N = 16384, 81 GiB at N = 32768).  Pure host arithmetic."""
+    from eigenkernel_amd import solver
+    for n in (16384, 32768):
+        mat = 8 * n * n
+        r3_any_p = 9.5 * mat + 0.13e9                       # round 3: every rank, every team size
+        p1, parts1 = solver.workspace_bytes(1, n, n, 1)
+        p2, _ = solver.workspace_bytes(1, n, n, 2)
+        p4, _ = solver.workspace_bytes(1, n, n, 4)
+        p8, parts8 = solver.workspace_bytes(1, n, n, 8)
+        assert parts1[0] == mat
+        assert p8 <= 0.55 * r3_any_p, (p8 / 2 ** 30, r3_any_p / 2 ** 30)        # VERDICT r3's mark, against round 3's P = 1
+        assert p1 <= 0.66 * r3_any_p                         # one GPU: 6.2 matrices instead of 9.5
+        assert p8 < p4 < p2 < p1
+        assert p8 <= 5.0 * mat                               # L + Q1's reflectors + X0 + 1.63 (X1) + 1/8 (Z) + small
+        assert parts8[2] <= mat / 8 + 128 * 8 * n            # the eigenvector columns are the cell's share
+    # a *_select arm on one GPU keeps the D&C compact too (C5: 1024 of 16384 columns)
+    c5, _ = solver.workspace_bytes(1, 16384, 1024, 1)
+    assert c5 <= 5.0 * 8 * 16384 * 16384

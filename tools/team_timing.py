@@ -26,11 +26,26 @@ ts = (ctypes.c_double * 4)(); flag = ctypes.c_int(0)
 lib.ek_hip_debug_two_stage_timing(n, min(n, 1024), 1, ts, ctypes.byref(flag))
 lib.ek_hip_debug_two_stage_timing(n, min(n, 1024), 2, ts, ctypes.byref(flag))
 print("n=%d single GPU: dense->band %.4f s, band->tridiagonal %.4f s" % (n, ts[0], ts[1]), flush=True)
+# A rank's time in the dense -> band stage is NOT (whole team back to back) / P: the panel chain runs on ONE rank while
+# the others wait for its broadcast, so it counts in full.  The serial pieces are measured with the look-ahead off (HIP
+# events around every chain and every "rest of the update" section), then a rank's critical path is
+#   without look-ahead : chains + (everything else) / P
+#   with look-ahead    : first chain + sum_p max(chain p+1, update p / P) + (everything else but chains and updates) / P
+# (the wire -- one broadcast and one all-reduce per panel -- is in neither: one GPU).
+d2b = {}
 for P in teams:
     if P >= 1:
-        assert lib.ek_hip_debug_sy2sb_team_timing(n, P, 1, ctypes.byref(sec)) == 0
-        assert lib.ek_hip_debug_sy2sb_team_timing(n, P, 2, ctypes.byref(sec)) == 0
-        print("n=%d team of %d rehearsed: dense->band %.4f s total, %.4f s per rank" % (n, P, sec.value, sec.value / P), flush=True)
+        parts = (ctypes.c_double * 4)()
+        assert lib.ek_hip_debug_sy2sb_team_profile(n, P, 1, 0, ctypes.byref(sec), parts) == 0
+        assert lib.ek_hip_debug_sy2sb_team_profile(n, P, 2, 0, ctypes.byref(sec), parts) == 0
+        T, C, U, M = parts[0], parts[1], parts[2], parts[3]
+        serial = C + (T - C) / P
+        lookahead = M + (T - C - U) / P
+        assert lib.ek_hip_debug_sy2sb_team_profile(n, P, 2, -1, ctypes.byref(sec), None) == 0
+        d2b[P] = (serial, lookahead)
+        print("n=%d team of %d rehearsed: dense->band %.4f s back to back (chains %.4f, rest-of-update sections %.4f); "
+              "per rank: %.4f s without look-ahead, %.4f s with (model); the rehearsal with look-ahead on takes %.4f s"
+              % (n, P, T, C, U, serial, lookahead, sec.value), flush=True)
 # what a rank of a 1 x P team computes per solve (generalized problem, full spectrum), stage by stage: the distributed
 # stages rehearsed above / below (seconds / P), the replicated bulge chasing, and the column-sharded stages measured by
 # playing one grid cell of the replicated-input mode (ek_hip_solve_device_grid: no exchange, so a cell's stage times do
@@ -49,7 +64,6 @@ for P in teams:
         continue
     assert lib.ek_hip_debug_reduce_team(n, P, 1, red) == 0
     assert lib.ek_hip_debug_reduce_team(n, P, 2, red) == 0
-    assert lib.ek_hip_debug_sy2sb_team_timing(n, P, 2, ctypes.byref(sec)) == 0
     ncl = (n + P - 1) // P
     dZ = dmalloc((ncl + 64) * n * 8)
     for rep in range(2):
@@ -57,11 +71,11 @@ for P in teams:
         assert lib.ek_hip_synth_matrix_device(n, 2, dB, n) == 0
         rc = lib.ek_hip_solve_device_grid(1, n, n, dA, n, dB, n, dw, dZ, n, 64, 1, P, 0, 0, stage, 8)
         assert rc == 0, rc
-    parts = {"potrf (team)": red[0] / P, "sygst (team)": red[1] / P, "dense->band (team)": sec.value / P,
+    parts = {"potrf (team)": red[0] / P, "sygst (team)": red[1] / P, "dense->band (team, look-ahead, chain in full)": d2b[P][1],
              "band->tridiagonal (replicated)": ts[1], "stedc (top merge on own columns)": stage[4],
              "Q2 + Q1 (own columns)": stage[5], "recovery (own columns)": stage[6]}
-    print("n=%d P=%d per-rank compute: %.3f s = %s" % (n, P, sum(parts.values()),
-          ", ".join("%s %.3f" % kv for kv in parts.items())), flush=True)
+    print("n=%d P=%d per-rank compute: %.3f s = %s   [dense->band without look-ahead: %.3f]" % (n, P, sum(parts.values()),
+          ", ".join("%s %.3f" % kv for kv in parts.items()), d2b[P][0]), flush=True)
     lib.ek_hip_free(dZ)
 if os.environ.get("EK_TEAM_TWO_STAGE_ONLY"):
     sys.exit(0)
