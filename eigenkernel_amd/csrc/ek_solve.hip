@@ -109,7 +109,7 @@ void extract_local(int m, int n, const double *M_full, int ldf, const int *desc,
 // (memcpy) and hands the slot to the DMA engine (and the reverse on the way out), two slots per worker so that its
 // memcpy and its DMA overlap; the number of workers per direction follows the cores the process may run on.
 struct PinRing {
-  static constexpr size_t kSlot = (size_t)8 << 20;       // bytes per slot
+  static constexpr size_t kSlot = (size_t)16 << 20;      // bytes per slot
   static constexpr int kMaxWorkers = 16;
   char *base = nullptr;
   int nslots = 0;
@@ -157,6 +157,11 @@ struct HostPipe {
   int err = 0;
   std::vector<std::thread> th;
   hipStream_t cs[2 * kMaxThreads] = {};
+  // pinned ring: ALL transfers of a direction are issued on ONE stream (dma[0] in, dma[1] out), one after the other at
+  // the link's rate, whichever worker packed the slot -- six workers with a stream each shared the DMA engines at 33 GB/s
+  // in all on a box whose single transfers run at 57 (profiles/r04_pcie_probe.txt)
+  hipStream_t dma[2] = {};
+  std::mutex dma_mu[2];
   int device = 0;
   int z_slab = 2048;
   // EK_HIP_PIPE_TRACE=1: what every copy job and every wait of the main thread took (stderr, at the end of the call)
@@ -196,6 +201,7 @@ struct HostPipe {
     if (env_threads >= 1 && env_threads <= kMaxThreads) kThreads = env_threads;
     pinned = env_pinned != 0 && g_pin.ensure(2 * kThreads);
     for (int i = 0; i < 2 * kThreads; ++i) EK_HIP_CHECK(hipStreamCreateWithFlags(&cs[i], hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) EK_HIP_CHECK(hipStreamCreateWithFlags(&dma[i], hipStreamNonBlocking));
     for (int i = 0; i < 2 * kThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i], i); });
     return 0;
   }
@@ -217,16 +223,20 @@ struct HostPipe {
         const double *src = j.host + (size_t)c0 * j.ldh;
         if (j.ldh == j.m) memcpy(slot[k], src, col_bytes * nc);
         else for (int cc = 0; cc < nc; ++cc) memcpy(slot[k] + col_bytes * cc, src + (size_t)cc * j.ldh, col_bytes);
-        e = hipMemcpy2DAsync(j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, slot[k], col_bytes, col_bytes, nc, hipMemcpyHostToDevice, c);
-        if (e == hipSuccess) e = hipEventRecord(ev[k], c);
+        {
+          std::lock_guard<std::mutex> lk(dma_mu[0]);
+          e = hipMemcpy2DAsync(j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, slot[k], col_bytes, col_bytes, nc, hipMemcpyHostToDevice, dma[0]);
+          if (e == hipSuccess) e = hipEventRecord(ev[k], dma[0]);
+        }
       }
-      const hipError_t e2 = hipStreamSynchronize(c);
-      return e != hipSuccess ? e : e2;
+      for (int k = 0; k < 2 && k < nchunk; ++k) { const hipError_t e2 = hipEventSynchronize(ev[k]); if (e == hipSuccess) e = e2; }
+      return e;
     }
     auto fetch = [&](int q) {
       const int k = q & 1, c0 = q * cpc, nc = cols(q);
-      hipError_t f = hipMemcpy2DAsync(slot[k], col_bytes, j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, col_bytes, nc, hipMemcpyDeviceToHost, c);
-      if (f == hipSuccess) f = hipEventRecord(ev[k], c);
+      std::lock_guard<std::mutex> lk(dma_mu[1]);
+      hipError_t f = hipMemcpy2DAsync(slot[k], col_bytes, j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, col_bytes, nc, hipMemcpyDeviceToHost, dma[1]);
+      if (f == hipSuccess) f = hipEventRecord(ev[k], dma[1]);
       return f;
     };
     e = fetch(0);
@@ -239,8 +249,8 @@ struct HostPipe {
       if (j.ldh == j.m) memcpy(dst, slot[k], col_bytes * nc);
       else for (int cc = 0; cc < nc; ++cc) memcpy(dst + (size_t)cc * j.ldh, slot[k] + col_bytes * cc, col_bytes);
     }
-    const hipError_t e2 = hipStreamSynchronize(c);
-    return e != hipSuccess ? e : e2;
+    (void)c;
+    return e;
   }
   void run(bool input, hipStream_t c, int worker) {
     (void)hipSetDevice(device);
@@ -308,6 +318,7 @@ struct HostPipe {
     for (auto &t : th) t.join();
     th.clear();
     for (auto &c : cs) if (c) { (void)hipStreamDestroy(c); c = nullptr; }
+    for (auto &c : dma) if (c) { (void)hipStreamDestroy(c); c = nullptr; }
     for (auto &e : evs) (void)hipEventDestroy(e);
     evs.clear();
     report();
@@ -511,11 +522,13 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   }
   mark();                                                              // 2
   if (pipe) {
-    if (problem == 1) {        // L is final: it leaves while the reduction runs
+    // (L is final, but its way out waits until A is in: the output workers' memcpys would share the host's memory
+    // bandwidth with the input that the next stage is waiting for -- A came in at 24 GB/s beside them, B alone at 51)
+    rc = stage_in_A(); if (rc) { tm.destroy(); return rc; }
+    if (problem == 1) {        // L leaves while the reduction runs
       copy_matrix(s, n, n, wB, ld, dB, ldb);
       pipe->push(true, dB, ldb, pipe->hB, pipe->ldhb, n, n, pipe->mark(s), 0);
     }
-    rc = stage_in_A(); if (rc) { tm.destroy(); return rc; }
   }
   if (problem == 1) {
     // sharding the two solves costs 2 n^3 / P flops per rank against 1.0 - 1.57 n^3 replicated

@@ -360,9 +360,15 @@ __global__ void dc_permute_kernel(int mbeg, DcBufs b, const double *__restrict__
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= mg.n) return;
   const int off = mg.off;
+  // compact bases: the merge that spans both halves (the top one) reads a child basis whose OTHER half's rows hold the
+  // other child (stored hq columns to the left): those entries are zeros of the block-diagonal basis, not what is stored
+  const bool crossing = off < b.hq && off + mg.n > b.hq;
+  const bool row_hi = off + r >= b.hq;
   for (int t = blockIdx.y; t < mg.n; t += gridDim.y) {
     const int src = b.perm[off + t], dst = b.wcol[off + t];
-    W[(size_t)(off + r) + cw(b, off + dst) * ldw] = Q[(size_t)(off + r) + cq(b, off + src) * ldq];
+    double v = Q[(size_t)(off + r) + cq(b, off + src) * ldq];
+    if (crossing && ((off + src >= b.hq) != row_hi)) v = 0.0;
+    W[(size_t)(off + r) + cw(b, off + dst) * ldw] = v;
   }
 }
 

@@ -721,7 +721,16 @@ struct SymmArgs {
   int P, rank, r0;                      // DIST: this member of a team of P sums only the entries of A22 whose COLUMN lies
                                         // in a 128-wide global strip it owns (strip S on rank S mod P; A22 starts at global
                                         // row and column r0); the members' Y add up to A22 V
+  int SD = 0, ST = 0;                   // DIST: workgroups (rb, 0 .. SD-1) share the tiles up to the diagonal of block row rb,
+                                        // (rb, SD .. SD+ST-1) the transposed tiles below it (see symm_lower_kernel)
 };
+// DIST: a member's entries are a 1 / P share of the triangle but an uneven one per block row: a block row whose rows lie in
+// an owned strip takes ALL the transposed tiles below its diagonal (up to T of them), any other only every P-th direct
+// slab.  Cut over K like on one GPU, the launch lasts as long as its heaviest workgroup -- as long as the undistributed
+// SYMM (round 3: a team of 8 spent 0.066 s per rank in these launches at N = 16384, 1 / 8 of the flops each).  So the two
+// kinds of work have their own workgroups: SD chunks of the tiles up to the diagonal, ST chunks of the transposed run of an
+// owning block row (the others leave at once); yred_dist_kernel sums exactly the partials that were written.
+__host__ __device__ inline int symm_dist_chunk(int count, int parts) { return (count + parts - 1) / parts; }
 constexpr int BK = 32, MC_LD = 128 + 16, KC_LD = BK + 2;   // K-contiguous images: 34 keeps (x, k) and (x + 1, k - 1) in different banks and row pairs 16-byte aligned
 constexpr int A_TILE = (BK * MC_LD > 128 * KC_LD) ? BK * MC_LD : 128 * KC_LD;
 constexpr int V_LD = BK + 2;            // V slab: 64 x 32, K-contiguous image s[n][34]
@@ -736,9 +745,21 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
   __shared__ __attribute__((aligned(16))) double sV[SB * V_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int rb = blockIdx.x, ks = blockIdx.y;
-  const int kt0 = ks * p.tiles_per_split;
+  int kt0 = ks * p.tiles_per_split;
   int kt1 = kt0 + p.tiles_per_split; if (kt1 > p.T) kt1 = p.T;
   const int m0 = rb * 128;
+  if (DIST) {
+    const bool heavy = ((((p.r0 + m0) >> 7) % p.P) == p.rank) || ((((p.r0 + m0 + 64) >> 7) % p.P) == p.rank);
+    if (ks < p.SD) {                      // the tiles up to and including the diagonal one
+      const int td = symm_dist_chunk(p.T, p.SD);
+      kt0 = ks * td; kt1 = kt0 + td; if (kt1 > rb + 1) kt1 = rb + 1;
+      if (kt0 > rb) return;
+    } else {                              // the transposed tiles below the diagonal of an owning block row
+      const int cnt = p.T - rb - 1, len = symm_dist_chunk(cnt > 0 ? cnt : 1, p.ST);
+      kt0 = rb + 1 + (ks - p.SD) * len; kt1 = kt0 + len; if (kt1 > p.T) kt1 = p.T;
+      if (!heavy || kt0 >= kt1) return;
+    }
+  }
   const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
   double4_t acc[2][4];
 #pragma unroll
@@ -915,6 +936,51 @@ __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
   store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
 }
 
+// Team form: Y = the sum of the partials symm_lower_kernel<true> wrote for this block row, in a fixed order (the direct
+// chunks that reach it, then -- for a block row with owned rows -- the transposed chunks), Gp as above
+struct YredDistArgs {
+  int m, T, SD, ST, P, rank, r0;
+  const double *Ypart; int ldy; long long sY;
+  double *Y; int ldyo;
+  const double *V; int ldv;
+  double *Gpart;
+};
+__global__ __launch_bounds__(256) void yred_dist_kernel(YredDistArgs p) {
+  __shared__ double sY[IMG], sV[IMG];
+  const int t = threadIdx.x, r = t & 63, cg = t >> 6;
+  double4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int slab = 0; slab < CH / SB; ++slab) {
+    const int row0 = blockIdx.x * CH + slab * SB;
+    if (row0 >= p.m) break;
+    const int row = row0 + r;
+    const int rb = row0 >> 7, m0 = rb * 128;
+    const bool heavy = ((((p.r0 + m0) >> 7) % p.P) == p.rank) || ((((p.r0 + m0 + 64) >> 7) % p.P) == p.rank);
+    const int td = symm_dist_chunk(p.T, p.SD);
+    int nd = rb / td + 1; if (nd > p.SD) nd = p.SD;                    // direct chunks with kt0 <= rb
+    const int cnt = p.T - rb - 1, len = symm_dist_chunk(cnt > 0 ? cnt : 1, p.ST);
+    const int nt = (heavy && cnt > 0) ? symm_dist_chunk(cnt, len) : 0;  // transposed chunks with kt0 < T
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int col = 16 * cg + c;
+      double y = 0.0, v = 0.0;
+      if (row < p.m) {
+        const double *yp = p.Ypart + (size_t)row + (size_t)col * p.ldy;
+        for (int q = 0; q < nd; ++q) y += yp[(size_t)q * p.sY];
+        for (int q = 0; q < nt; ++q) y += yp[(size_t)(p.SD + q) * p.sY];
+        p.Y[(size_t)row + (size_t)col * p.ldyo] = y;
+        v = p.V[(size_t)row + (size_t)col * p.ldv];
+      }
+      sY[r * LD + col] = y; sV[r * LD + col] = v;
+    }
+    __syncthreads();
+    slab_gram(sV, sY, acc);
+  }
+  store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
+}
+
 // W = [Y | V] [T ; -1/2 T^T G T], G = V^T Y (the sum of yred_kernel's partials), written to columns 0..63 and
 // 128..191 of the image [W | V | W].  Every workgroup forms the 128 x 64 multiplier itself (two 64^3 products
 // on the matrix cores: less than the launch of a kernel that would do it once).
@@ -1006,7 +1072,7 @@ struct Layout {
   explicit Layout(int n, int P = 0) {
     mpad = round_up(n > 0 ? n : 1, 128);
     nparts = mpad / CH + 1;
-    maxsplit = 8;
+    maxsplit = P > 0 ? 20 : 8;           // (team form: up to 4 direct + 16 transposed chunks per block row)
     size_t o = 0;
     off_img = o; o += al256((size_t)mpad * 3 * SB * 8);
     off_img2 = o; o += al256((size_t)mpad * 3 * SB * 8);
@@ -1391,20 +1457,19 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
     // ---- Y = A22 V: every member its own entries, then the sum over the team
     const int nch = ceil_div(m, CH);
     const int T = ceil_div(m, 128);
-    int nsplit = (T >= 256) ? 2 : ceil_div(512, T);
-    if (nsplit > L.maxsplit) nsplit = L.maxsplit;
-    if (nsplit > T) nsplit = T;
-    const int tps = ceil_div(T, nsplit);
-    nsplit = ceil_div(T, tps);
+    // about eight tiles per workgroup: SD chunks of a block row's owned direct slabs (every P-th strip of its up to T
+    // tiles), ST chunks of the up to T transposed tiles of an owning block row
+    int SD = ceil_div(T, 8 * P), ST = ceil_div(T, 8);
+    if (SD < 1) SD = 1; if (SD > 4) SD = 4;
+    if (ST < 1) ST = 1; if (ST > 16) ST = 16;
     for (int q = 0; q < nmem; ++q) {
       St &M = st[q];
       double *A22 = mem[q].A + (size_t)r0 + (size_t)r0 * mem[q].lda;
       const double *V = M.img[cur] + (size_t)SB * ldi;
-      SymmArgs sy{m, A22, mem[q].lda, V, ldi, M.Ypart, L.mpad, (long long)L.mpad * SB, T, tps, P, mem[q].rank, r0};
-      hipLaunchKernelGGL(symm_lower_kernel<true>, dim3(T, nsplit), dim3(256), 0, s, sy);
-      YredArgs ya{m, nsplit, M.Ypart, L.mpad, (long long)L.mpad * SB, M.Y, V, ldi, M.Gpart};
-      ya.ldyo = ldy;
-      hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
+      SymmArgs sy{m, A22, mem[q].lda, V, ldi, M.Ypart, L.mpad, (long long)L.mpad * SB, T, 0, P, mem[q].rank, r0, SD, ST};
+      hipLaunchKernelGGL(symm_lower_kernel<true>, dim3(T, SD + ST), dim3(256), 0, s, sy);
+      YredDistArgs ya{m, T, SD, ST, P, mem[q].rank, r0, M.Ypart, L.mpad, (long long)L.mpad * SB, M.Y, ldy, V, ldi, M.Gpart};
+      hipLaunchKernelGGL(yred_dist_kernel, dim3(nch), dim3(256), 0, s, ya);
     }
     if (P > 1) x.allreduce(s, nmem, ys, (size_t)ldy * SB, x.user);
     for (int q = 0; q < nmem; ++q) {
