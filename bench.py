@@ -16,9 +16,7 @@ the safe measurement, kept in the line as "replicas"), then ONE problem on the 1
 with the library's RCCL communicator attached -- Cholesky factor, reduction and the dense -> band stage of
 the tridiagonalisation distributed over the ranks (per panel one broadcast and one all-reduce), band ->
 tridiagonal replicated, eigenvector stages sharded by columns -- to the full contract (W warm-up solves,
-exactly K solves between barriers, max over ranks, parity checked on every rank; `--grid-probe-modes all`
-adds the older one-stage PDSYTRD with its per-column exchange as an ncclAllReduce and through peer
-windows).  The (fastest) distributed mode that passed becomes the headline
+exactly K solves between barriers, max over ranks, parity checked on every rank).  If it passed it becomes the headline
 ("scaling": "strong", value = n_vec * K / time: the eigenpairs of the one problem all ranks worked
 on); if neither passes (or an exchange hangs: a watchdog abandons it) the replicas line is the
 headline ("scaling": "weak").  `--distribution replicas | columns | grid` force one mode.
@@ -329,10 +327,8 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
     reduction from three ranks on, tridiagonalisation always: distributed; eigenvector stages
     column-sharded), measured to the same contract as the headline (W warm-up solves, then exactly K
     solves between barriers, max over ranks) in the library's one distributed form ("two_stage": dense -> band over the
-    team, per panel one broadcast and one all-reduce) and, with --grid-probe-modes all, also in the older one-stage forms
-      "one_stage_collective"   : one ncclAllReduce per Householder column,
-      "one_stage_peer_windows" : contributions stored straight into the peers' HBM, one command-processor wait.
-    Runs after the replicas region; a watchdog abandons it (os._exit after printing the line that
+    team, per panel one broadcast and one all-reduce, the next panel's chain and broadcast on a second stream beside the
+    rest of the update).  Runs after the replicas region; a watchdog abandons it (os._exit after printing the line that
     exists by then) if an exchange never returns: a pool box has a single GPU, so this path could
     only be rehearsed there (team rehearsal, RCCL with one rank, processes sharing the GPU)."""
     import threading
@@ -383,13 +379,7 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
         m = {}
         # "two_stage": the library's distributed form (dense -> band over the team's column strips: per panel one
         # broadcast of [V | T | tau] and one all-reduce of Y; one all-gather of the band; bulge chasing replicated;
-        # back-transformations sharded by columns); "one_stage_*" (--grid-probe-modes all): the older distributed
-        # one-stage PDSYTRD with its per-column exchange as an all-reduce or through peer windows
-        lib.ek_hip_debug_set_two_stage(-1 if mode == "two_stage" else 0)
-        if mode == "one_stage_peer_windows":
-            rc = lib.ek_hip_comm_peer_enable(n)
-            if rc != 0:
-                raise RuntimeError("ek_hip_comm_peer_enable: %d" % rc)
+        # back-transformations sharded by columns)
         for _ in range(W):
             regenerate(0)
             solve(0)
@@ -443,31 +433,17 @@ def grid_probe(args, lib, solver, dist, torch, dev, cdev, rank, world, n, proble
         wmax = wt.clone(); wmin = wt.clone()
         dist.all_reduce(wmax, op=dist.ReduceOp.MAX); dist.all_reduce(wmin, op=dist.ReduceOp.MIN)
         m["eigenvalues_identical_on_all_ranks"] = bool(torch.equal(wmax, wmin))
-        if mode == "one_stage_peer_windows":
-            lib.ek_hip_comm_peer_disable()
-        lib.ek_hip_debug_set_two_stage(-1)
         return m, w.copy()
 
     try:
         threading.Thread(target=watchdog, daemon=True).start()
         attach_communicator(solver, dist, rank, world, args.rehearse_on_one_gpu)
-        w_first = None
-        modes = (("two_stage", "one_stage_collective", "one_stage_peer_windows") if args.grid_probe_modes == "all"
-                 else ("two_stage",))
-        for mode in modes:
+        for mode in ("two_stage",):
             try:
                 m, w = measure(mode)
-                if mode == "one_stage_collective":
-                    w_first = w
-                elif mode == "one_stage_peer_windows" and w_first is not None:
-                    same = allreduce(1.0 if bool((w == w_first).all()) else 0.0, dist.ReduceOp.MIN) > 0.5
-                    m["eigenvalues_bit_identical_to_collective_path"] = same
                 res["modes"][mode] = m
             except Exception as exc:          # ranks fail alike (collective calls): record and go on
                 res["modes"][mode] = {"error": repr(exc)}
-                if mode == "one_stage_peer_windows":
-                    lib.ek_hip_comm_peer_disable()
-                lib.ek_hip_debug_set_two_stage(-1)
         solver.comm_destroy()
     except Exception as exc:   # the probe never takes the line down
         res["error"] = repr(exc)
@@ -553,11 +529,6 @@ def main():
                     help="N>1 ranks that all use GPU 0 (a pool box has one): gloo process group, collective "
                          "tensors on the CPU, the library's HOST communicator instead of RCCL (which refuses two "
                          "ranks on one device).  Exercises the whole N>1 control flow; the timings mean nothing")
-    ap.add_argument("--grid-probe-modes", choices=["two_stage", "all"], default="two_stage",
-                    help="what the grid probe measures: 'two_stage' (default) = the library's one distributed form (dense -> "
-                         "band over the team, per panel one broadcast and one all-reduce; bulge chasing replicated; "
-                         "eigenvector stages sharded by columns); 'all' adds the older one-stage PDSYTRD with its per-column "
-                         "exchange as an all-reduce and through peer windows")
     ap.add_argument("--grid-probe-timeout", type=float, default=240.0,
                     help="seconds after which a stuck grid probe is abandoned (the main line is still printed)")
     args = ap.parse_args()

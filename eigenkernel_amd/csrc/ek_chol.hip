@@ -614,12 +614,14 @@ void potrf_lower_rl(hipStream_t s, hipStream_t s2, int n, double *B, int ldb, do
     double *C = B + (size_t)c1 + (size_t)c1 * ldb;
     gemm(s, false, true, m2, wnext, kw, -1.0, P, ldb, P, ldb, 1.0, C, ldb, true);
     (void)hipEventRecord(evU[(o + 1) & 1], s);
-    (void)hipStreamWaitEvent(s2, evU[(o + 1) & 1], 0);
-    factor_outer(s2, o + 1);
-    (void)hipEventRecord(evP[(o + 1) & 1], s2);
+    // (host order: the rest of the update is submitted before the sixteen launches of the next panel's chain, behind
+    // which it would start ~0.1 ms late)
     if (m2 > wnext)
       gemm(s, false, true, m2 - wnext, m2 - wnext, kw, -1.0, P + wnext, ldb, P + wnext, ldb, 1.0,
            C + (size_t)wnext + (size_t)wnext * ldb, ldb, true);
+    (void)hipStreamWaitEvent(s2, evU[(o + 1) & 1], 0);
+    factor_outer(s2, o + 1);
+    (void)hipEventRecord(evP[(o + 1) & 1], s2);
   }
   (void)hipStreamWaitEvent(s, evP[(NOB - 1) & 1], 0);
   hipLaunchKernelGGL(info_to_double_kernel, dim3(ceil_div(NRB, 256)), dim3(256), 0, s, NRB, infos, infod);

@@ -907,9 +907,8 @@ struct Q2ApplyArgs {
   double *Z; int ldz; int ncols;
   int nslab, npass, npair;   // npair = ceil(nS / NBLK) bundles of blocks of sweeps (NBLK q ..); bundle q = 0 is the lowest
   unsigned *prog;        // [npass] chunks stored by pass (bundle, slab) at index (npair-1-bundle) * nslab + slab
-  unsigned *ctl;         // [2] ticket, [1] abort (shared with the chase); [32 + x]: ticket of XCD x's queue (xcd_queues)
+  unsigned *ctl;         // [2] ticket, [1] abort (shared with the chase)
   int extra;             // chunks a pass keeps behind its predecessor beyond the two it must
-  int xcd_queues;        // 1: the passes of slab c are dealt to the workgroups that sit on XCD c % 8 (below)
 };
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -935,32 +934,13 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
   double *st = q2smem + QOPSZ + wave * 16 * QSTLD;      // this wave's transposing buffer
   const int n = p.g.n;
   const double *sV = sOp, *sVT = sOp + QR * QVS;
-  // Which pass next.  One queue: ticket -> (bundle, slab) bundle-major, whoever is free takes it.  XCD queues: the passes
-  // of the slabs c with c % 8 = x form queue x, served first by the workgroups that find themselves on XCD x
-  // (HW_REG_XCC_ID) -- the group records a bundle reads are then fetched into ONE L2 by the ~32 passes that walk down
-  // the same bundle side by side there, and a slab's chunks pass from a bundle to the next inside that L2 -- and, once
-  // their own queue is empty, by everybody else (a queue is taken in order whoever takes it, so a pass's predecessor --
-  // same queue, earlier ticket -- is always in the hands of a running workgroup: nothing depends on the placement).
-  unsigned xcc = 0;
-  if (p.xcd_queues) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 7u; }
-  int steal = 0;
+  // (Measured and withdrawn, round 4: the passes of slab c dealt to the workgroups that sit on XCD c % 8 -- read from
+  // HW_REG_XCC_ID, with stealing once a queue is empty -- so that the ~32 passes walking down one bundle side by side
+  // share its group records in ONE L2: 0.2033 s against 0.2015 at N = 16384, full spectrum; the passes drift apart
+  // within a few hundred steps and the records come from the Infinity Cache either way.)
   while (true) {
     __syncthreads();
-    if (t == 0) {
-      if (!p.xcd_queues) s_pass = (int)atomicAdd(&p.ctl[2], 1u);
-      else {
-        int got = -1;
-        for (; steal < 8 && got < 0; ) {
-          const int x = (int)((xcc + (unsigned)steal) & 7u);
-          const int nsx = (p.nslab - x + 7) / 8;                          // slabs x, x + 8, ..
-          const int cap = nsx * p.npair;
-          const int tk = (nsx > 0) ? (int)atomicAdd(&p.ctl[32 + x], 1u) : cap;
-          if (tk < cap) got = (tk / nsx) * p.nslab + x + 8 * (tk % nsx);  // pass id: bundle-major over ALL slabs
-          else ++steal;
-        }
-        s_pass = got < 0 ? p.npass : got;
-      }
-    }
+    if (t == 0) s_pass = (int)atomicAdd(&p.ctl[2], 1u);
     __syncthreads();
     const int pass = __builtin_amdgcn_readfirstlane(s_pass);
     if (pass >= p.npass) break;
@@ -1412,16 +1392,12 @@ void sb2st_apply_q2(hipStream_t s, int n, int ncols, const double *V2, int ldv2,
   const int nslab = ceil_div(ncols, QNC), npair = ceil_div(L.nS, per), npass = npair * nslab;
   (void)hipMemsetAsync(qprog, 0, (size_t)npass * 4, s);
   (void)hipMemsetAsync(ctl + 2, 0, 4, s);
-  (void)hipMemsetAsync(ctl + 32, 0, 8 * 4, s);
   // extra: how many further steps a pass stays behind its predecessor in the slab (fetch distance).  With few slabs
   // the passes of a slab are one dependent chain and every step of distance is paid npair times: 0 / 1 / 2 / 3 give
   // 21.0 / 22.2 / 24.2 / 26.2 ms for 1024 columns at N = 16384, 5.1 / 5.4 / 5.6 / 6.0 ms at N = 4096, and the same
   // 227 ms for all 16384 columns.
-  Q2ApplyArgs a{g, Rec, Z, ldz, ncols, nslab, npass, npair, qprog, ctl, 0, 0};
+  Q2ApplyArgs a{g, Rec, Z, ldz, ncols, nslab, npass, npair, qprog, ctl, 0};
   if (const char *ev = getenv("EK_Q2_EXTRA")) a.extra = atoi(ev);
-  static int xcdq = -1;
-  if (xcdq < 0) { const char *ev = getenv("EK_Q2_XCD"); xcdq = ev ? atoi(ev) : 0; }
-  a.xcd_queues = (xcdq != 0 && nslab >= 16) ? 1 : 0;
   int nwg = 512;
   if (const char *ev = getenv("EK_Q2_WGS")) { const int v = atoi(ev); if (v > 0) nwg = v; }
   if (nwg > npass) nwg = npass;

@@ -147,7 +147,14 @@ struct HostPipe {
   struct Job { double *dev; int ldd; double *host; int ldh; int m, n; hipEvent_t after; int tag; bool to_host; };
   static constexpr int kMaxThreads = 8;
   int kThreads = 2;                          // per direction (EK_HIP_PIPE_THREADS; default by the cores the process has)
-  bool pinned = false;                       // the copies go through the pinned ring (EK_HIP_PIPE_PINNED=0: as round 3)
+  // which directions go through the pinned ring (EK_HIP_PIPE_PINNED = 0 none: round 3's form, 1 in, 2 out, 3 both).
+  // Default: the way in only.  Measured on one pool box (profiles/r04_host_path.txt): in, ring 53 GB/s against 56 for
+  // the pageable arrays handed to the runtime there (a box whose runtime stages pageable memory at 27 - 36 GB/s, as
+  // rounds 2 and 3 met, is where the ring pays); out, the transfers into the ring's slots crawl at ~1 GB/s per worker
+  // while the GPU is busy with the stages (the same transfers into pageable memory: 30), so the way out stays as it was.
+  bool pinned = false;
+  int pinned_dirs = 1;
+  bool lower_only = true;                    // EK_HIP_PIPE_LOWER=0: whole matrices both ways, as round 3
   std::mutex mu;
   std::condition_variable cv;
   std::deque<Job> in_q, out_q;
@@ -195,7 +202,9 @@ struct HostPipe {
     { static int tr = -1; if (tr < 0) { const char *e = getenv("EK_HIP_PIPE_TRACE"); tr = (e && atoi(e) != 0) ? 1 : 0; } trace = tr != 0; }
     static int env_threads = -2, env_pinned = -1;
     if (env_threads == -2) { const char *e = getenv("EK_HIP_PIPE_THREADS"); env_threads = e ? atoi(e) : -1; }
-    if (env_pinned < 0) { const char *e = getenv("EK_HIP_PIPE_PINNED"); env_pinned = (e && atoi(e) == 0) ? 0 : 1; }
+    if (env_pinned < 0) { const char *e = getenv("EK_HIP_PIPE_PINNED"); env_pinned = e ? (atoi(e) & 3) : 1; }
+    pinned_dirs = env_pinned;
+    { static int lo = -1; if (lo < 0) { const char *e = getenv("EK_HIP_PIPE_LOWER"); lo = (e && atoi(e) == 0) ? 0 : 1; } lower_only = lo != 0; }
     const int cores = usable_cores();
     kThreads = cores >= 16 ? 6 : cores >= 8 ? 4 : 2;      // (both directions are rarely busy at once)
     if (env_threads >= 1 && env_threads <= kMaxThreads) kThreads = env_threads;
@@ -225,7 +234,10 @@ struct HostPipe {
         else for (int cc = 0; cc < nc; ++cc) memcpy(slot[k] + col_bytes * cc, src + (size_t)cc * j.ldh, col_bytes);
         {
           std::lock_guard<std::mutex> lk(dma_mu[0]);
-          e = hipMemcpy2DAsync(j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, slot[k], col_bytes, col_bytes, nc, hipMemcpyHostToDevice, dma[0]);
+          // (a contiguous device image -- the n x n user-side arrays of ek_hip_solve -- as ONE linear transfer: the
+          // 2-D form is not guaranteed the DMA engines)
+          if (j.ldd == j.m) e = hipMemcpyAsync(j.dev + (size_t)c0 * j.ldd, slot[k], col_bytes * nc, hipMemcpyHostToDevice, dma[0]);
+          else e = hipMemcpy2DAsync(j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, slot[k], col_bytes, col_bytes, nc, hipMemcpyHostToDevice, dma[0]);
           if (e == hipSuccess) e = hipEventRecord(ev[k], dma[0]);
         }
       }
@@ -235,7 +247,9 @@ struct HostPipe {
     auto fetch = [&](int q) {
       const int k = q & 1, c0 = q * cpc, nc = cols(q);
       std::lock_guard<std::mutex> lk(dma_mu[1]);
-      hipError_t f = hipMemcpy2DAsync(slot[k], col_bytes, j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, col_bytes, nc, hipMemcpyDeviceToHost, dma[1]);
+      hipError_t f = (j.ldd == j.m)
+          ? hipMemcpyAsync(slot[k], j.dev + (size_t)c0 * j.ldd, col_bytes * nc, hipMemcpyDeviceToHost, dma[1])
+          : hipMemcpy2DAsync(slot[k], col_bytes, j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, col_bytes, nc, hipMemcpyDeviceToHost, dma[1]);
       if (f == hipSuccess) f = hipEventRecord(ev[k], dma[1]);
       return f;
     };
@@ -267,7 +281,7 @@ struct HostPipe {
       if (j.after) e = hipEventSynchronize(j.after);
       const double tj0 = trace ? now() : 0.0;
       if (e == hipSuccess && j.m > 0 && j.n > 0) {
-        if (pinned && (size_t)j.m * 8 <= PinRing::kSlot) e = copy_pinned(j, c, worker);
+        if (pinned && (pinned_dirs & (j.to_host ? 2 : 1)) && (size_t)j.m * 8 <= PinRing::kSlot) e = copy_pinned(j, c, worker);
         else {
           if (j.to_host)
             e = hipMemcpy2DAsync(j.host, (size_t)j.ldh * 8, j.dev, (size_t)j.ldd * 8, (size_t)j.m * 8, j.n, hipMemcpyDeviceToHost, c);
@@ -287,14 +301,25 @@ struct HostPipe {
   }
   // host array (m x n, ldh) <-> device image (ldd), cut into column pieces for the threads (in column order: the
   // first columns of a matrix arrive first)
-  void push(bool to_host, double *dev, int ldd, double *host, int ldh, int m, int n, hipEvent_t after, int tag) {
+  // lower: a square matrix of which only the lower triangle is referenced (A, B on the way in; what the call leaves in A,
+  // L on the way out: uplo = 'L' throughout the reference, generalized_to_standard.f90:24,37, solver_scalapack_all.f90:59):
+  // a piece then carries the rows from its first column down -- half the bytes, the upper triangle of the destination is
+  // not touched (as PDPOTRF / PDSYTRD leave it) -- and the pieces are cut to equal areas
+  void push(bool to_host, double *dev, int ldd, double *host, int ldh, int m, int n, hipEvent_t after, int tag,
+            bool lower = false) {
     const int pieces = (n >= 256) ? 4 * kThreads : 1;
+    lower = lower && lower_only && m == n;
     {
       std::lock_guard<std::mutex> lk(mu);
+      int c0 = 0;
       for (int p = 0; p < pieces; ++p) {
-        const int c0 = (int)((long long)n * p / pieces), c1 = (int)((long long)n * (p + 1) / pieces);
-        Job j{dev + (size_t)c0 * ldd, ldd, host + (size_t)c0 * ldh, ldh, m, c1 - c0, after, tag, to_host};
+        int c1 = (int)((long long)n * (p + 1) / pieces);
+        if (lower) c1 = (p + 1 == pieces) ? n : (int)((double)n * (1.0 - sqrt(1.0 - (double)(p + 1) / pieces)));
+        if (c1 < c0) c1 = c0;
+        const int r0 = lower ? (c0 & ~1) : 0;                          // (even: 16-byte aligned rows)
+        Job j{dev + (size_t)c0 * ldd + r0, ldd, host + (size_t)c0 * ldh + r0, ldh, m - r0, c1 - c0, after, tag, to_host};
         if (to_host) { out_q.push_back(j); ++pending_out; } else { in_q.push_back(j); ++pending_in[tag]; }
+        c0 = c1;
       }
     }
     cv.notify_all();
@@ -527,7 +552,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     rc = stage_in_A(); if (rc) { tm.destroy(); return rc; }
     if (problem == 1) {        // L leaves while the reduction runs
       copy_matrix(s, n, n, wB, ld, dB, ldb);
-      pipe->push(true, dB, ldb, pipe->hB, pipe->ldhb, n, n, pipe->mark(s), 0);
+      pipe->push(true, dB, ldb, pipe->hB, pipe->ldhb, n, n, pipe->mark(s), 0, /*lower=*/true);
     }
   }
   if (problem == 1) {
@@ -546,7 +571,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   //  -- goes back to the caller as soon as it is final: its place (X0) is needed again
   auto a_out = [&]() {
     copy_matrix(s, n, n, wA, ld, dA, lda);
-    if (pipe) pipe->push(true, dA, lda, pipe->hA, pipe->ldha, n, n, pipe->mark(s), 0);
+    if (pipe) pipe->push(true, dA, lda, pipe->hA, pipe->ldha, n, n, pipe->mark(s), 0, /*lower=*/true);
   };
   if (dist && !two_stage) {
     const SytrdMember me{wA, ld, dd, de, dt, wV, ld, sytrd_work, g_comm.rank};
@@ -611,6 +636,14 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // with a staging pipeline the LAST stage (the recovery; the back-transformation of a standard problem) runs in column
   // slabs, each leaving for the host while the next is computed (columns of Z are independent there)
   const int zslab = (pipe && two_stage_done && nc_loc > pipe->z_slab) ? pipe->z_slab : nc_loc;
+  // (the last slabs are narrower: what remains exposed at the end of the call is the last slab's way out)
+  auto slab_width = [&](int c0) {
+    const int left = nc_loc - c0;
+    if (zslab >= nc_loc) return left;
+    if (left > 2 * zslab) return zslab;
+    if (left > zslab) return zslab / 2 < left ? zslab / 2 : left;
+    return (left > 512) ? (left + 1) / 2 : left;
+  };
   auto z_out = [&](int c0, int nc) {
     copy_matrix(s, n, nc, wZ + (size_t)c0 * ld, ld, dZ + (size_t)c0 * ldz, ldz);
     pipe->push(true, dZ + (size_t)c0 * ldz, ldz, pipe->hZ + (size_t)c0 * pipe->ldhz, pipe->ldhz, n, nc, pipe->mark(s), 0);
@@ -624,8 +657,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     const bool q1 = !band_input;               // (a band on entry: the first stage did nothing, Q1 = I)
     if (q1) ormtr_prepare(s, n, wV, ld, dt1, q1prep);
     if (pipe && problem == 0 && zslab < nc_loc) {
-      for (int c0 = 0; c0 < nc_loc; c0 += zslab) {
-        const int nc = (nc_loc - c0 < zslab) ? nc_loc - c0 : zslab;
+      for (int c0 = 0, nc = 0; c0 < nc_loc; c0 += nc) {
+        nc = slab_width(c0);
         if (q1) ormtr_apply(s, n, nc, wV, ld, q1prep, zc + (size_t)c0 * ld, ld, work, n_vec);
         z_out(c0, nc);
       }
@@ -638,8 +671,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   mark();                                                              // 6
   if (problem == 1) {
     if (pipe) {
-      for (int c0 = 0; c0 < nc_loc; c0 += zslab) {
-        const int nc = (nc_loc - c0 < zslab) ? nc_loc - c0 : zslab;
+      for (int c0 = 0, nc = 0; c0 < nc_loc; c0 += nc) {
+        nc = slab_width(c0);
         trsm_llt(s, n, nc, wB, ld, dInv, zc + (size_t)c0 * ld, ld, twork);
         z_out(c0, nc);
       }
@@ -1005,8 +1038,16 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
     pipe.hZ = Z_loc; pipe.ldhz = desc_Z[8];
     rc = pipe.start(g_ctx.device);
     if (rc) return rc;
-    if (problem == 1) pipe.push(false, uB, n, B_loc, desc_B[8], n, n, nullptr, 0);
-    pipe.push(false, uA, n, A_loc, desc_A[8], n, n, nullptr, 1);
+    // (only the lower triangles travel: the device images' upper triangles are zeros, never garbage)
+    auto zero_first = [&](double *u) -> int {
+      if (!pipe.lower_only) return 0;
+      EK_HIP_CHECK(hipMemsetAsync(u, 0, nn, s));
+      EK_HIP_CHECK(hipStreamSynchronize(s));
+      return 0;
+    };
+    if (problem == 1) { rc = zero_first(uB); if (rc) return rc; pipe.push(false, uB, n, B_loc, desc_B[8], n, n, nullptr, 0, /*lower=*/true); }
+    rc = zero_first(uA); if (rc) return rc;
+    pipe.push(false, uA, n, A_loc, desc_A[8], n, n, nullptr, 1, /*lower=*/true);
     double st[EK_HIP_N_STAGES] = {0};
     int info = solve_device_locked(problem, n, n_vec, uA, n, uB, n, uw, uZ, n, st, EK_HIP_N_STAGES, nullptr, &pipe);
     const int rcp = pipe.finish();

@@ -744,7 +744,24 @@ __global__ __launch_bounds__(256, 2) void symm_lower_kernel(SymmArgs p) {
   __shared__ __attribute__((aligned(16))) double sA[A_TILE];
   __shared__ __attribute__((aligned(16))) double sV[SB * V_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int rb = blockIdx.x, ks = blockIdx.y;
+  int rb = blockIdx.x, ks = blockIdx.y;
+  if (DIST) {
+    // 1-D grid: T * SD workgroups for the direct chunks, then ST per block row that has owned rows (a grid over all T
+    // block rows launched six thousand workgroups of which five thousand left at once)
+    const int b = blockIdx.x, nd = p.T * p.SD;
+    if (b < nd) { rb = b / p.SD; ks = b % p.SD; }
+    else {
+      const int h = (b - nd) / p.ST, j = (b - nd) % p.ST, q = p.r0 >> 7;
+      ks = p.SD + j;
+      if (p.P == 1) rb = h;
+      else {
+        const int first = q + ((p.rank - q) % p.P + p.P) % p.P;            // first owned strip at or beyond q
+        if ((p.r0 & 127) == 0) rb = first + h * p.P - q;                       // block row = strip
+        else rb = first + (h >> 1) * p.P - q - 1 + (h & 1);                    // a strip lies in two block rows
+      }
+      if (rb < 0 || rb >= p.T) return;
+    }
+  }
   int kt0 = ks * p.tiles_per_split;
   int kt1 = kt0 + p.tiles_per_split; if (kt1 > p.T) kt1 = p.T;
   const int m0 = rb * 128;
@@ -968,8 +985,19 @@ __global__ __launch_bounds__(256) void yred_dist_kernel(YredDistArgs p) {
       double y = 0.0, v = 0.0;
       if (row < p.m) {
         const double *yp = p.Ypart + (size_t)row + (size_t)col * p.ldy;
-        for (int q = 0; q < nd; ++q) y += yp[(size_t)q * p.sY];
-        for (int q = 0; q < nt; ++q) y += yp[(size_t)(p.SD + q) * p.sY];
+        // (fixed order: direct chunks ascending, then transposed chunks ascending; four loads in flight at a time)
+        auto sum_run = [&](const double *base, int cnt) {      // (eight loads in flight; the order of the sum is fixed)
+          int q = 0;
+          for (; q + 8 <= cnt; q += 8) {
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = base[(size_t)(q + u) * p.sY];
+            y += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+          }
+          for (; q < cnt; ++q) y += base[(size_t)q * p.sY];
+        };
+        sum_run(yp, nd);
+        sum_run(yp + (size_t)p.SD * p.sY, nt);
         p.Y[(size_t)row + (size_t)col * p.ldyo] = y;
         v = p.V[(size_t)row + (size_t)col * p.ldv];
       }
@@ -1072,7 +1100,7 @@ struct Layout {
   explicit Layout(int n, int P = 0) {
     mpad = round_up(n > 0 ? n : 1, 128);
     nparts = mpad / CH + 1;
-    maxsplit = P > 0 ? 20 : 8;           // (team form: up to 4 direct + 16 transposed chunks per block row)
+    maxsplit = P > 0 ? 56 : 8;           // (team form: up to 8 direct + 48 transposed chunks per block row)
     size_t o = 0;
     off_img = o; o += al256((size_t)mpad * 3 * SB * 8);
     off_img2 = o; o += al256((size_t)mpad * 3 * SB * 8);
@@ -1276,11 +1304,13 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     if (has_next && m >= la_min) {
       gemm(s, false, true, m, SB, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true);
       (void)hipEventRecord(evA[cur], s);
+      // (host order: the rest of the update first, then the eleven launches of the chain -- submitted behind them the
+      // update would start ~70 us late on every panel)
+      gemm(s, false, true, m - SB, m - SB, 2 * SB, -1.0, P1 + SB, ldi, P2 + SB, ldi, 1.0,
+           A22 + (size_t)SB + (size_t)SB * lda, lda, true, /*staged_rank_k=*/m < staged_max);
       (void)hipStreamWaitEvent(s2, evA[cur], 0);
       panel_chain(s2, r0, img[cur ^ 1], Tm[cur ^ 1]);
       (void)hipEventRecord(evB[cur ^ 1], s2);
-      gemm(s, false, true, m - SB, m - SB, 2 * SB, -1.0, P1 + SB, ldi, P2 + SB, ldi, 1.0,
-           A22 + (size_t)SB + (size_t)SB * lda, lda, true, /*staged_rank_k=*/m < staged_max);
       waited = false;
     } else {
       gemm(s, false, true, m, m, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true);
@@ -1457,17 +1487,23 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
     // ---- Y = A22 V: every member its own entries, then the sum over the team
     const int nch = ceil_div(m, CH);
     const int T = ceil_div(m, 128);
-    // about eight tiles per workgroup: SD chunks of a block row's owned direct slabs (every P-th strip of its up to T
-    // tiles), ST chunks of the up to T transposed tiles of an owning block row
-    int SD = ceil_div(T, 8 * P), ST = ceil_div(T, 8);
-    if (SD < 1) SD = 1; if (SD > 4) SD = 4;
-    if (ST < 1) ST = 1; if (ST > 16) ST = 16;
+    // about three tiles per workgroup (a member's T^2 / P tile products spread over the chip's ~512 workgroup slots; a
+    // tile takes a workgroup ~14 us, and the launch lasts as long as its longest workgroup): SD chunks of a block row's
+    // owned direct slabs (every P-th strip of its up to T tiles), ST chunks of the up to T transposed tiles of an
+    // owning block row
+    int SD = ceil_div(T, 3 * P), ST = ceil_div(T, 3);
+    if (SD < 1) SD = 1; if (SD > 8) SD = 8;
+    if (ST < 1) ST = 1; if (ST > 48) ST = 48;
     for (int q = 0; q < nmem; ++q) {
       St &M = st[q];
       double *A22 = mem[q].A + (size_t)r0 + (size_t)r0 * mem[q].lda;
       const double *V = M.img[cur] + (size_t)SB * ldi;
       SymmArgs sy{m, A22, mem[q].lda, V, ldi, M.Ypart, L.mpad, (long long)L.mpad * SB, T, 0, P, mem[q].rank, r0, SD, ST};
-      hipLaunchKernelGGL(symm_lower_kernel<true>, dim3(T, SD + ST), dim3(256), 0, s, sy);
+      // block rows with owned rows: one per owned strip when A22 starts on a strip boundary, two when it starts in the
+      // middle of one (a team of one: all of them)
+      const int nown = ceil_div(T + 1, P) + 1;
+      const int NH = (P == 1) ? T : (((r0 & 127) == 0) ? nown : 2 * nown);
+      hipLaunchKernelGGL(symm_lower_kernel<true>, dim3(T * SD + NH * ST), dim3(256), 0, s, sy);
       YredDistArgs ya{m, T, SD, ST, P, mem[q].rank, r0, M.Ypart, L.mpad, (long long)L.mpad * SB, M.Y, ldy, V, ldi, M.Gpart};
       hipLaunchKernelGGL(yred_dist_kernel, dim3(nch), dim3(256), 0, s, ya);
     }
@@ -1494,12 +1530,15 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
              mem[q].A + (size_t)r0 + (size_t)r0 * mem[q].lda, mem[q].lda, true);
       }
       (void)hipEventRecord(evA[cur], s);
-      (void)hipStreamWaitEvent(s2, evA[cur], 0);
-      issue_panel(s2, p + 1, cur ^ 1);
-      (void)hipEventRecord(evB[cur ^ 1], s2);
+      // (the update is handed to its stream FIRST: the launches of a chain and of its broadcast take the host ~0.1 ms, and
+      // an update submitted behind them would start that much later -- the trace of round 4's first version showed the
+      // two streams' kernels strictly one after the other for exactly that reason)
       hipEvent_t e0 = g_dprof.on ? g_dprof.mark(s) : nullptr;
       for (int q = 0; q < nmem; ++q) update_strips(q, p, cur, mem[q].rank == owner_next ? SB : 0);
       if (e0) { g_dprof.mark(s); g_dprof.kind.push_back(1); }
+      (void)hipStreamWaitEvent(s2, evA[cur], 0);
+      issue_panel(s2, p + 1, cur ^ 1);
+      (void)hipEventRecord(evB[cur ^ 1], s2);
       waited = false;
     } else {
       hipEvent_t e0 = g_dprof.on ? g_dprof.mark(s) : nullptr;
