@@ -278,20 +278,40 @@ def run_other_config(lib, torch, dev, name, steps, warmup):
     return res
 
 
+def gemm_ceiling(lib, torch, dev, dA, n):
+    """What the library's own large GEMM sustains on this box right now: C(n/2, n/2) -= A B with K = n/2, operands taken from
+    a device array that is spent at this point, C its own scratch (three repetitions, HIP events; ek_hip_debug_gemm_at) --
+    the practical fp64 MFMA ceiling the dominant kernel's issued rate is compared with (the datasheet's 78.6 is the
+    `peak` of the roofline object)."""
+    try:
+        h = n // 2
+        dC = torch.zeros((h, h), dtype=torch.float64, device=dev)
+        sec = ctypes.c_double(0)
+        a = ctypes.c_void_p(dA.data_ptr())
+        rc = lib.ek_hip_debug_gemm_at(0, 0, h, h, h, a, n, ctypes.c_void_p(dA.data_ptr() + 8 * h * n), n,
+                                      1.0, ctypes.c_void_p(dC.data_ptr()), h, 0, 3, ctypes.byref(sec))
+        del dC
+        if rc != 0 or sec.value <= 0:
+            return None
+        return 2.0 * h * h * h / sec.value / 1e12
+    except Exception:
+        return None
+
+
 def q2_traffic_record(n, ncols):
     """HBM bytes per q2_apply_nb_kernel launch from the committed PMC measurement -- only while the kernel's source is
     the file the measurement was taken from (the record carries its sha256); a stale record is not reported."""
     import hashlib
-    tpath = os.path.join(ROOT, "profiles", "r03_q2_apply_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r04_q2_apply_traffic.json")
     src = os.path.join(ROOT, "eigenkernel_amd", "csrc", "ek_sb2st.hip")
     try:
         tj = json.load(open(tpath))
         sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
         if tj.get("n") != n or tj.get("ncols") != int(ncols):
-            return None, "profiles/r03_q2_apply_traffic.json is for another shape"
+            return None, "profiles/r04_q2_apply_traffic.json is for another shape"
         if tj.get("source_sha256") != sha:
-            return None, "profiles/r03_q2_apply_traffic.json is stale: ek_sb2st.hip has changed since it was measured"
-        return tj.get("hbm_bytes_per_launch"), ("profiles/r03_q2_apply_traffic.json (rocprofv3 --pmc at git %s, not live)"
+            return None, "profiles/r04_q2_apply_traffic.json is stale: ek_sb2st.hip has changed since it was measured"
+        return tj.get("hbm_bytes_per_launch"), ("profiles/r04_q2_apply_traffic.json (rocprofv3 --pmc at git %s, not live)"
                                                 % tj.get("git", "?"))
     except Exception as exc:
         return None, "no PMC record (%r)" % (exc,)
@@ -713,7 +733,7 @@ def main():
                 "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                 "launches": int(kp_l[0]), "avg_launch_us": 1e6 * dur, "algorithmic_flops_per_launch": fl,
-                "measured_mfma_ceiling_tflops": 69.0,   # largest GEMM shapes of this library (profiles/r02_gemm_shapes_n16384_v6.txt); register-only loop: 49.6
+                "measured_mfma_ceiling_tflops": gemm_ceiling(lib, torch, dev, dAs[0], n),   # live, see gemm_ceiling()
                 "other_kernels": {
                     "chase_pos_kernel (band -> tridiagonal: positions of the band in registers, sweeps pass through by mail)":
                         {"launches": int(kp_l[1]), "avg_launch_us": 1e6 * kp_s[1] / max(kp_l[1], 1)},

@@ -36,6 +36,23 @@ int ensure_init() {
   return 0;
 }
 
+// device images of the caller's host arrays (ek_hip_solve on a 1 x 1 grid): grown, never shrunk, released in ek_hip_finalize
+namespace { void *g_uimg = nullptr; size_t g_uimg_bytes = 0; }
+int user_images(size_t bytes, void **p) {
+  if (bytes > g_uimg_bytes) {
+    if (g_uimg) EK_HIP_CHECK(hipFree(g_uimg));
+    g_uimg = nullptr; g_uimg_bytes = 0;
+    EK_HIP_CHECK(hipMalloc(&g_uimg, bytes));
+    g_uimg_bytes = bytes;
+  }
+  *p = g_uimg;
+  return 0;
+}
+void release_user_images() {
+  if (g_uimg) (void)hipFree(g_uimg);
+  g_uimg = nullptr; g_uimg_bytes = 0;
+}
+
 int workspace(size_t bytes, void **p) {
   if (bytes > g_ctx.ws_bytes) {
     if (g_ctx.ws_alloc) EK_HIP_CHECK(hipFree(g_ctx.ws_alloc));
@@ -239,7 +256,8 @@ int ek_hip_finalize(void) {
   if (g_ctx.ws_alloc) (void)hipFree(g_ctx.ws_alloc);
   g_ctx.ws = nullptr; g_ctx.ws_alloc = nullptr; g_ctx.ws_bytes = 0;
   release_scratch_choice();
-  // a communicator and its peer windows do not outlive the library's device state
+  release_user_images();
+  // a communicator does not outlive the library's device state
   comm_teardown();
   return 0;
 }

@@ -1,7 +1,7 @@
 // ek_api_internal.h -- what the translation units behind the C-ABI of libek_hip.so share (not installed):
 //   ek_api.hip    boundary: context, memory, the stage-level entries (one per ScaLAPACK call), acceptance checks
 //   ek_comm.hip   the communicator that stands where the reference has its BLACS context: RCCL (bound at run time),
-//                 the host-hook exchange, peer windows, the team's agreements
+//                 the host-hook exchange, the team's agreements
 //   ek_solve.hip  the whole-path driver (solve_device_locked), the staging pipeline of the host path, ek_hip_solve*
 //   ek_debug.hip  tuning / profiling / rehearsal hooks of include/ek_hip_debug.h and the *_team entries
 #pragma once
@@ -54,6 +54,8 @@ struct Arena {
 inline size_t al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
 void release_scratch_choice();
+int user_images(size_t bytes, void **p);   // device images of host arrays, kept between calls (ek_api.hip)
+void release_user_images();
 void *choose_sytrd_scratch(int n, int ld, double *wA, void *arena_work, double *vecs, size_t need);
 
 // device buffers of one host-array call: released on every exit path
@@ -98,8 +100,7 @@ constexpr int kPotrfRlMin = 1024;
 extern int g_two_stage_min;
 int two_stage_min();
 int dist_min_ranks();
-void peer_teardown();
-void comm_teardown();     // peer windows and the communicator itself (ek_hip_finalize)
+void comm_teardown();     // the communicator itself (ek_hip_finalize)
 SytrdExchange team_exchange(int nteam, int n = 0);
 int comm_any(int local);
 int comm_agree(int local_rc);

@@ -1,6 +1,6 @@
 // ek_comm.hip -- the communicator of the distributed path: what stands where the reference has its
 // BLACS context (processes.f90:17-36).  RCCL bound at run time (one rank per GPU over xGMI), the same two exchanges
-// through the host's allgatherv hook, peer windows, and the team's agreements; see include/ek_hip.h.
+// through the host's allgatherv hook, and the team's agreements; see include/ek_hip.h.
 #include "ek_api_internal.h"
 #include <dlfcn.h>
 
@@ -140,52 +140,11 @@ void host_allgatherv(hipStream_t s, int nmem, int, double *const *bufs, const si
   if (!ok && !g_comm.err) g_comm.err = (int)ncclSystemError;
 }
 
-// ---- peer windows (ek_hip_comm_peer_enable): the per-column exchange of the tridiagonalisation
-// without a collective.  Each rank allocates one receive area in its HBM, exports it with
-// hipIpcGetMemHandle, and maps everybody else's; contributions are stored straight into the peers'
-// areas by yreduce and announced by stream memory operations.
-struct PeerX {
-  bool on = false;
-  PeerWindow win{};
-  unsigned long long seq = 0;
-  size_t bytes = 0;
-  bool opened[kMaxTeam] = {};
-};
-PeerX g_peer;
-constexpr size_t kPeerFlagBytes = 256;    // kMaxTeam 64-bit flags, padded
-
-void peer_signal(hipStream_t s, unsigned long long seq, void *) {
-  const PeerWindow &w = g_peer.win;
-  if (w.nranks <= 1) return;
-  const hipError_t e = hipStreamWaitValue64(s, w.base[w.me], seq * (unsigned long long)(w.nranks - 1),
-                                            hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull);
-  if (e != hipSuccess && !g_comm.err) g_comm.err = (int)ncclSystemError;
-}
-
-// Releases whatever has been allocated, opened or mapped so far: also called on the failure exits of
-// ek_hip_comm_peer_enable, where the windows are not "on" yet.
-void peer_teardown() {
-  const PeerWindow &w = g_peer.win;
-  bool any = g_peer.on || w.done != nullptr;
-  for (int r = 0; r < kMaxTeam; ++r) any = any || g_peer.opened[r] || w.base[r] != nullptr;
-  if (!any) return;
-  if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
-  for (int r = 0; r < w.nranks && r < kMaxTeam; ++r)
-    if (r != w.me && g_peer.opened[r]) (void)hipIpcCloseMemHandle(w.base[r]);
-  if (w.me >= 0 && w.me < kMaxTeam && w.base[w.me]) (void)hipFree(w.base[w.me]);
-  if (w.done) (void)hipFree(w.done);
-  (void)hipGetLastError();
-  g_peer = PeerX{};
-}
-
-// n: order of the solve the exchange is for.  The peer windows were sized for ek_hip_comm_peer_enable's
-// n_max (slots of 2 * pad(n_max) + 8 doubles in every peer's HBM); a larger order would store past the
-// slots in other processes' memory, so it takes the collective exchange instead (n is the same on every
-// rank: all ranks decide alike).  n = 0: no window exchange will be issued (Cholesky, reduction).
-SytrdExchange team_exchange(int nteam, int n) {
+// The exchange a team of this process uses: the device-side emulation of a rehearsed team (nteam members in this
+// process), the host's allgatherv hook, or RCCL.  (n is kept for the callers' sake: it sized the peer windows of the
+// one-stage form, removed in round 4.)
+SytrdExchange team_exchange(int nteam, int) {
   SytrdExchange x{nteam > 0 ? nteam : g_comm.nranks, nullptr, nullptr};
-  const bool fits = 2 * (size_t)pad_ld(n > 0 ? n : 1) + 1 <= g_peer.win.maxcount;
-  if (nteam == 0 && g_peer.on && g_peer.win.nranks == g_comm.nranks && fits) x.peer = &g_peer.win;
   if (nteam > 0) { x.allreduce = sytrd_team_allreduce; x.allgatherv = team_allgatherv; }
   else if (g_comm.host) { x.allreduce = host_allreduce; x.allgatherv = host_allgatherv; }
   else { x.allreduce = rccl_allreduce; x.allgatherv = rccl_allgatherv; }
@@ -241,7 +200,6 @@ const char *comm_error_string() {
 
 
 void comm_teardown() {
-  peer_teardown();
   if (g_comm.on && !g_comm.host && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_comm.comm);
   g_comm = Comm{};
 }
@@ -278,7 +236,6 @@ int ek_hip_comm_init(const void *id, int bytes, int nranks, int rank) {
   int rc = ensure_init(); if (rc) return rc;
   std::lock_guard<std::mutex> lk(g_mu);
   rc = g_rccl.load(); if (rc) return rc;
-  peer_teardown();
   if (g_comm.on && !g_comm.host) (void)g_rccl.CommDestroy(g_comm.comm);
   g_comm = Comm{};
   EK_HIP_CHECK(hipSetDevice(g_ctx.device));
@@ -298,88 +255,9 @@ int ek_hip_comm_attach_host(int nranks, int rank) {
   int rc = ensure_init(); if (rc) return rc;
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_allgatherv) return -998;
-  peer_teardown();
   if (g_comm.on && !g_comm.host) (void)g_rccl.CommDestroy(g_comm.comm);
   g_comm = Comm{};
   g_comm.on = true; g_comm.host = true; g_comm.nranks = nranks; g_comm.rank = rank;
-  return 0;
-}
-
-// Peer windows for the attached communicator (collective call).  n_max = largest matrix order that
-// will be solved while they are enabled.  The handles travel through the communicator itself.
-int ek_hip_comm_peer_enable(int n_max) {
-  if (n_max < 1) return -1;
-  int rc = ensure_init(); if (rc) return rc;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_comm.on) return -995;
-  peer_teardown();
-  hipStream_t s = g_ctx.stream;
-  const int P = g_comm.nranks, me = g_comm.rank;
-  PeerWindow &w = g_peer.win;
-  w.nranks = P; w.me = me; w.slots_off = kPeerFlagBytes;
-  w.maxcount = 2 * (size_t)pad_ld(n_max) + 8;
-  w.seq = &g_peer.seq; w.signal = peer_signal; w.user = nullptr;
-  g_peer.bytes = kPeerFlagBytes + (size_t)P * 2 * w.maxcount * sizeof(double);
-  // A rank whose local step fails keeps taking part in the exchanges below and says so in its
-  // status word, so that all ranks give up together (-993) instead of waiting for each other.
-  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
-  constexpr int kRec = 9;                    // doubles per rank: 8 = the 64-byte handle, 1 = status
-  double rec[kMaxTeam * kRec];
-  memset(rec, 0, sizeof(rec));
-  bool ok = true;
-  char *mine = nullptr;
-  ok = ok && hipExtMallocWithFlags((void **)&mine, g_peer.bytes, hipDeviceMallocFinegrained) == hipSuccess;
-  ok = ok && hipMemset(mine, 0, g_peer.bytes) == hipSuccess;
-  ok = ok && hipMalloc((void **)&w.done, 256) == hipSuccess && hipMemset(w.done, 0, 256) == hipSuccess;
-  ok = ok && hipDeviceSynchronize() == hipSuccess;
-  w.base[me] = mine;
-  if (ok && P > 1) {
-    hipIpcMemHandle_t h;
-    ok = hipIpcGetMemHandle(&h, mine) == hipSuccess;
-    if (ok) memcpy(&rec[me * kRec], &h, sizeof(h));
-  }
-  rec[me * kRec + 8] = ok ? 0.0 : 1.0;
-  (void)hipGetLastError();
-  double *dh = nullptr;
-  DevMem mem;
-  rc = mem.alloc(&dh, sizeof(rec));
-  if (rc) { peer_teardown(); return rc; }
-  size_t offs[kMaxTeam], counts[kMaxTeam];
-  for (int r = 0; r < P; ++r) { offs[r] = (size_t)r * kRec; counts[r] = kRec; }
-  double *bufs[1] = {dh};
-  const SytrdExchange x = team_exchange(0);
-  auto exchange_status = [&]() -> int {     // everyone's record; returns the number of ranks that failed, or < 0
-    if (hipMemcpy(dh, rec, sizeof(rec), hipMemcpyHostToDevice) != hipSuccess) return -1;
-    g_comm.err = 0;
-    if (P > 1) x.allgatherv(s, 1, me, bufs, offs, counts, P, x.user);
-    if (hipStreamSynchronize(s) != hipSuccess || g_comm.err) return -1;
-    if (hipMemcpy(rec, dh, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    int bad = 0;
-    for (int r = 0; r < P; ++r) if (rec[r * kRec + 8] != 0.0) ++bad;
-    return bad;
-  };
-  int bad = exchange_status();
-  if (bad != 0) { peer_teardown(); return bad < 0 ? -996 : -993; }
-  for (int r = 0; r < P && ok; ++r) {
-    if (r == me) continue;
-    hipIpcMemHandle_t h;
-    memcpy(&h, &rec[r * kRec], sizeof(h));
-    ok = hipIpcOpenMemHandle((void **)&w.base[r], h, hipIpcMemLazyEnablePeerAccess) == hipSuccess;
-    if (ok) g_peer.opened[r] = true;
-  }
-  (void)hipGetLastError();
-  // nobody stores into a peer before every rank has mapped every area -- and has said so
-  rec[me * kRec + 8] = ok ? 0.0 : 1.0;
-  bad = exchange_status();
-  if (bad != 0) { peer_teardown(); return bad < 0 ? -996 : -993; }
-  g_peer.seq = 0;
-  g_peer.on = true;
-  return 0;
-}
-
-int ek_hip_comm_peer_disable(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  peer_teardown();
   return 0;
 }
 
@@ -388,7 +266,6 @@ int ek_hip_comm_rank(void) { return g_comm.on ? g_comm.rank : -1; }
 
 int ek_hip_comm_destroy(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  peer_teardown();
   if (g_comm.on) {
     if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
     if (!g_comm.host) (void)g_rccl.CommDestroy(g_comm.comm);

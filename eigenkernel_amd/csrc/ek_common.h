@@ -163,23 +163,6 @@ struct SytrdMember {
   void *work;          // >= sytrd_dist_work_bytes(n, nranks)
   int rank;
 };
-// Peer mode of the per-column exchange: every rank owns a receive area in its HBM
-//   [arrival counter (64 bit) | slots: nranks x 2 x maxcount doubles]
-// that all ranks have mapped (base[r], hipIpc across processes).  The producing kernel stores the
-// rank's contribution into its slot on every rank and its last workgroup bumps every peer's arrival
-// counter; signal() enqueues, on the stream, ONE wait "my arrival counter >= seq * (nranks - 1)"
-// executed by the command processor (hipStreamWaitValue64), after which the consumer kernel sums the
-// slots.  (A sender raises counters only after all its stores of that exchange are visible
-// system-wide, so early arrivals of a faster peer's next exchange cannot expose missing data.)
-struct PeerWindow {
-  int nranks, me;
-  char *base[kMaxTeam];
-  size_t slots_off, maxcount;
-  unsigned int *done;          // device: workgroups-done counter of the producing kernel
-  unsigned long long *seq;     // host counter of exchanges, identical on all ranks
-  void (*signal)(hipStream_t s, unsigned long long seq, void *user);
-  void *user;
-};
 struct SytrdExchange {
   int nranks;
   // in-place sum over ALL ranks of the team of `count` doubles; bufs = the windows of the nmem
@@ -191,8 +174,6 @@ struct SytrdExchange {
   // members held by this process are the ranks rank0 .. rank0 + nmem - 1)
   void (*allgatherv)(hipStream_t s, int nmem, int rank0, double *const *bufs, const size_t *offs,
                      const size_t *counts, int nranks, void *user) = nullptr;
-  const PeerWindow *peer = nullptr;   // if set (and one member per process): the window exchange of the
-                                      // tridiagonalisation goes peer to peer instead of through allreduce
 };
 size_t sytrd_dist_work_bytes(int n, int nranks);
 void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, const SytrdExchange &x);

@@ -1018,16 +1018,20 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
     return info;
   }
   hipStream_t s = g_ctx.stream;
-  // user-side device images (exact n x n); freed before returning: the library keeps nothing
+  // user-side device images (exact n x n) of A, B, Z and w: one allocation that the library keeps between calls like its
+  // workspace (6 GiB of hipMalloc + hipFree per call were 0.05 s of a 1.0 s call at N = 16384) and releases in
+  // ek_hip_finalize; the caller's pointers are borrowed for the duration of the call only, as before
   double *uA = nullptr, *uB = nullptr, *uZ = nullptr, *uw = nullptr;
   const size_t nn = (size_t)n * n * 8;
   auto t0 = std::chrono::steady_clock::now();
-  DevMem mem;
-  rc = mem.alloc(&uA, nn);
-  if (!rc) rc = mem.alloc(&uZ, nn);
-  if (!rc) rc = mem.alloc(&uw, (size_t)n * 8);
-  if (!rc && problem == 1) rc = mem.alloc(&uB, nn);
-  if (rc) return rc;
+  {
+    const size_t nnal = al(nn), need = (problem == 1 ? 3 : 2) * nnal + al((size_t)n * 8);
+    rc = user_images(need, (void **)&uA);
+    if (rc) return rc;
+    uZ = (double *)((char *)uA + nnal);
+    uw = (double *)((char *)uZ + nnal);
+    if (problem == 1) uB = (double *)((char *)uw + al((size_t)n * 8));
+  }
   int pipe_min = 2048;           // EK_HIP_PIPE_MIN: order from which the host path stages through the pipeline (0: never)
   if (const char *e = getenv("EK_HIP_PIPE_MIN")) pipe_min = atoi(e);
   if (pipe_min > 0 && n >= pipe_min) {

@@ -684,13 +684,24 @@ __global__ __launch_bounds__(256) void tall_finish_kernel(TallFinishArgs p) {
   store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
 }
 
-// T (column-major, ld 64) of a rescued panel from G = V^T V and tau (DLARFT, forward columnwise)
-__global__ __launch_bounds__(256) void t_from_gram_kernel(const double *__restrict__ G, const double *__restrict__ tau,
+// T (column-major, ld 64) of a rescued panel from G = V^T V -- the sum, in a fixed order, of the npart partial Gram
+// matrices tall_finish_kernel left (this one workgroup adds them itself: a launch of reduce_parts_kernel in front of it
+// cost every panel of every matrix 4.7 us to save the rare rescued panel ~0.1 ms) -- and tau (DLARFT, forward columnwise)
+__global__ __launch_bounds__(256) void t_from_gram_kernel(int npart, const double *__restrict__ Gpart, const double *__restrict__ tau,
                                                           double *__restrict__ T, const int *pflag) {
   __shared__ double sG[IMG], sT[IMG], s_tau[SB];
   if (!*pflag) return;
   const int t = threadIdx.x;
-  for (int idx = t; idx < SB * SB; idx += 256) { sG[(idx >> 6) * LD + (idx & 63)] = G[idx]; sT[(idx >> 6) * LD + (idx & 63)] = 0.0; }
+  for (int idx = t; idx < SB * SB; idx += 256) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int q = 0;
+    for (; q + 4 <= npart; q += 4) {
+      a0 += Gpart[(size_t)q * 4096 + idx]; a1 += Gpart[(size_t)(q + 1) * 4096 + idx];
+      a2 += Gpart[(size_t)(q + 2) * 4096 + idx]; a3 += Gpart[(size_t)(q + 3) * 4096 + idx];
+    }
+    for (; q < npart; ++q) a0 += Gpart[(size_t)q * 4096 + idx];
+    sG[(idx >> 6) * LD + (idx & 63)] = (a0 + a1) + (a2 + a3); sT[(idx >> 6) * LD + (idx & 63)] = 0.0;
+  }
   if (t < SB) s_tau[t] = tau[t];
   __syncthreads();
   for (int i = 0; i < SB; ++i) {
@@ -1176,8 +1187,7 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
                      b.nzrows ? b.nzrows + c0 / SB : nullptr);
   TallFinishArgs tf{m, Ap, lda, Vp, ldv, Vimg, ldi, b.Gpart2, b.pflag};
   hipLaunchKernelGGL(tall_finish_kernel, dim3(nch), dim3(256), 0, st, tf);
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2, b.pflag);
-  hipLaunchKernelGGL(t_from_gram_kernel, dim3(1), dim3(256), 0, st, b.Gred2, tau1 + c0, Tp, b.pflag);
+  hipLaunchKernelGGL(t_from_gram_kernel, dim3(1), dim3(256), 0, st, nch, b.Gpart2, tau1 + c0, Tp, b.pflag);
 }
 
 // team form: the strips a member updates after panel p (batched GEMM: one problem per owned strip that still has

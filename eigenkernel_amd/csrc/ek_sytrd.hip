@@ -117,46 +117,20 @@ __device__ __forceinline__ int num_pieces(int s, int T, int q, int P = 1) {
   return (tile_start(s + 1, T, P) - 1) / q - tile_start(s, T, P) / q + 1;
 }
 
-// Where the exchange window of a distributed run lives.  Collective mode: one local array that an
-// all-reduce has summed in place.  Peer mode: every rank has stored its contribution straight into
-// a slot of every rank's receive area (xGMI stores from yreduce), and the reader sums the P slots
-// in rank order -- the same order on every rank, so the sums are bit-identical across the team.
+// The exchange window of a distributed run: one local array that the team's all-reduce sums in place (the same sum on
+// every rank, so everything computed from it is bit-identical across the team).  (Until round 4 a second, "peer" form
+// stored every rank's contribution straight into every other rank's HBM; it never ran on two devices and went with the
+// one-stage form's retirement from the whole-path call.)
 struct XWin {
-  const double *slot[kMaxTeam];   // slot[r]: rank r's contribution (peer mode); slot[0]: the summed window
-  int nslots;                     // P in peer mode, 1 in collective mode
-  __device__ __forceinline__ double get(size_t i) const {
-    double v = slot[0][i];
-    for (int r = 1; r < nslots; ++r) v += slot[r][i];
-    return v;
-  }
+  const double *slot[1];          // the summed window
+  int nslots;
+  __device__ __forceinline__ double get(size_t i) const { return slot[0][i]; }
 };
 struct XDst {
-  double *slot[kMaxTeam];         // where this rank's contribution goes: its slot on every rank (peer
-  int nslots;                     // mode), or its own window (collective mode, nslots = 1)
-  // peer mode: arrival counters of the other ranks (null for this rank itself and in collective
-  // mode) and this rank's local "workgroups done" counter
-  unsigned long long *ctr[kMaxTeam];
-  unsigned int *done;
-  __device__ __forceinline__ void put(size_t i, double v) const {
-    for (int d = 0; d < nslots; ++d) slot[d][i] = v;
-  }
-  // Called by every thread at the end of the producing kernel.  The last workgroup to finish, after
-  // every workgroup's stores have been fenced system-wide, adds 1 to each peer's arrival counter
-  // (a remote atomic over xGMI); the peer's stream waits for P-1 such arrivals per exchange.
-  __device__ __forceinline__ void announce() const {
-    if (!done) return;
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned prev = atomicAdd(done, 1u);
-      if (prev == gridDim.x - 1) {
-        *done = 0;                       // the next producer launch is stream-ordered after this one
-        __threadfence_system();
-        for (int d = 0; d < nslots; ++d)
-          if (ctr[d]) __hip_atomic_fetch_add(ctr[d], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
+  double *slot[1];                // this rank's window
+  int nslots;
+  __device__ __forceinline__ void put(size_t i, double v) const { slot[0][i] = v; }
+  __device__ __forceinline__ void announce() const {}
 };
 
 struct ColupdArgs {
@@ -916,33 +890,8 @@ void sytrd_lower_dist(hipStream_t s, int n, int nmem, const SytrdMember *mem, co
     yr.xd.slot[0] = M.xch; yr.xd.nslots = 1;
   }
   // exchange of the window of column jn (with or without the symv sums), then colupd on every member
-  const PeerWindow *pw_ = (nmem == 1) ? x.peer : nullptr;   // peer mode needs one member per process
   auto exchange = [&](int jn, bool with_y) {
     const int r0 = (jn / CR) * CR, cnt = npad - r0;
-    if (pw_) {
-      // peer mode: yreduce stores this rank's contribution into its slot on every rank; the command
-      // processors then raise this rank's sequence number in every peer's flag and wait for every
-      // peer's number in ours (stream-ordered memory operations: no collective kernel, no spinning
-      // wavefront); colupd sums the P slots.  Slots alternate with the parity of the sequence
-      // number: a peer can only be one exchange ahead, because its next contribution needs ours.
-      const PeerWindow &pw = *pw_;
-      const unsigned long long seq = ++*pw.seq;
-      const int par = (int)(seq & 1), me = pw.me;
-      YredArgs &yr = st[0].yr;
-      ColupdArgs &c = st[0].c;
-      yr.xd.nslots = P; c.xw.nslots = P;
-      yr.xd.done = pw.done;
-      for (int r = 0; r < P; ++r) {
-        yr.xd.slot[r] = (double *)(pw.base[r] + pw.slots_off) + ((size_t)me * 2 + par) * pw.maxcount;
-        yr.xd.ctr[r] = (r == me) ? nullptr : (unsigned long long *)pw.base[r];
-        c.xw.slot[r] = (const double *)(pw.base[me] + pw.slots_off) + ((size_t)r * 2 + par) * pw.maxcount;
-      }
-      yr.r0 = r0; yr.cnt = cnt; yr.jn = jn; yr.with_y = with_y ? 1 : 0;
-      yr.own_next = ((jn / TS) % P == mem[0].rank) ? 1 : 0;
-      hipLaunchKernelGGL(yreduce_kernel, dim3(ceil_div(cnt, YR)), dim3(256), 0, s, yr);
-      pw.signal(s, seq, pw.user);
-      return cnt;
-    }
     for (int m = 0; m < nmem; ++m) {
       YredArgs &yr = st[m].yr;
       yr.r0 = r0; yr.cnt = cnt; yr.jn = jn; yr.with_y = with_y ? 1 : 0;

@@ -78,8 +78,6 @@ def load_library(path=None):
         "ek_hip_comm_unique_id": (c_int, [vp, c_int]),
         "ek_hip_comm_init": (c_int, [vp, c_int, c_int, c_int]),
         "ek_hip_comm_attach_host": (c_int, [c_int, c_int]),
-        "ek_hip_comm_peer_enable": (c_int, [c_int]),
-        "ek_hip_comm_peer_disable": (c_int, []),
         "ek_hip_comm_size": (c_int, []),
         "ek_hip_comm_rank": (c_int, []),
         "ek_hip_comm_destroy": (c_int, []),
@@ -147,7 +145,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_sytrd_team", "ek_hip_comm_unique_id", "ek_hip_comm_init", "ek_hip_comm_size", "ek_hip_comm_rank",
     "ek_hip_comm_destroy", "ek_hip_comm_allreduce_device", "ek_hip_debug_sytrd_team", "ek_hip_sygst_team",
     "ek_hip_potrf_team", "ek_hip_debug_reduce_team", "ek_hip_comm_attach_host",
-    "ek_hip_comm_peer_enable", "ek_hip_comm_peer_disable", "ek_hip_debug_set_sytrd_maxcols", "ek_hip_debug_sytrd_work_bytes", "ek_hip_debug_sytrd_at", "ek_hip_debug_sytrd_split", "ek_hip_debug_gemm_at",
+    "ek_hip_debug_set_sytrd_maxcols", "ek_hip_debug_sytrd_work_bytes", "ek_hip_debug_sytrd_at", "ek_hip_debug_sytrd_split", "ek_hip_debug_gemm_at",
     "ek_hip_debug_sy2sb", "ek_hip_debug_sb2st", "ek_hip_debug_two_stage_timing", "ek_hip_debug_set_two_stage",
     "ek_hip_profile_kernels", "ek_hip_profile_kernels_get", "ek_hip_debug_last_solve_stats",
     "ek_hip_debug_sy2sb_team", "ek_hip_debug_sy2sb_team_timing", "ek_hip_debug_sy2sb_team_profile", "ek_hip_debug_workspace_bytes",

@@ -1,13 +1,13 @@
 /* ek_ranks_demo.c -- a plain-C, MPI-shaped host for libek_hip.so (nothing but include/ek_hip.h).
  *
- *   ek_ranks_demo [n=1500] [nprow=2] [npcol=2] [peer_windows=1] [problem=1]
+ *   ek_ranks_demo [n=1500] [nprow=2] [npcol=2] [problem=1]
  *
  * What an MPI host of the reference does around eigen_solver (main.f90:84-104), with fork() and a
  * shared-memory segment standing in for mpirun and MPI_Allgatherv, so that it runs on a box with
  * one GPU and no MPI: nprow*npcol ranks (processes) bind to GPU 0, build their block-cyclic
  * pieces of the synthetic pair of SURVEY.md 8(d) (setup_distributed_matrix +
  * distribute_global_sparse_matrix of the reference), lend the library the all-gather hook, attach
- * the host communicator, optionally enable peer windows, and call ek_hip_solve -- the reference's
+ * the host communicator, and call ek_hip_solve -- the reference's
  * own data contract: pieces of A and B in; eigenvalues on every rank, pieces of Z, of the
  * reflectors and of L out.  Rank 0 then collects the pieces of Z and checks
  * ||A z - lambda B z|| for a few eigenpairs and that every rank holds the same eigenvalues.
@@ -73,14 +73,13 @@ static int numroc(int n, int nb, int me, int np) {
 }
 static int l2g(int l, int nb, int me, int np) { return ((l / nb) * np + me) * nb + l % nb; }
 
-static int run_rank(int rank, int n, int nprow, int npcol, int peer, int problem) {
+static int run_rank(int rank, int n, int nprow, int npcol, int problem) {
   g_rank = rank;
   const int P = nprow * npcol, myrow = rank / npcol, mycol = rank % npcol, nb = 64;
   int rc = ek_hip_init(0);
   if (rc) { fprintf(stderr, "[%d] ek_hip_init: %d\n", rank, rc); return 2; }
   rc = ek_hip_set_allgatherv(hook_allgatherv, NULL);
   if (!rc) rc = ek_hip_comm_attach_host(P, rank);
-  if (!rc && peer) rc = ek_hip_comm_peer_enable(n);
   if (rc) { fprintf(stderr, "[%d] communicator: %d\n", rank, rc); return 2; }
   const int nr = numroc(n, nb, myrow, nprow), nc = numroc(n, nb, mycol, npcol), lld = nr > 1 ? nr : 1;
   const int desc[9] = {1, 0, n, n, nb, nb, 0, 0, lld};
@@ -138,7 +137,7 @@ static int run_rank(int rank, int n, int nprow, int npcol, int peer, int problem
       printf("n=%d grid %dx%d (%d processes on GPU 0), %s exchange, %s problem: solve %.3f s "
              "(potrf %.3f sygst %.3f sytrd %.3f gather %.3f stedc %.3f ormtr %.3f trtrs %.3f), "
              "lambda_min %.12f lambda_max %.12f, max |A z - lambda B z| over 6 eigenpairs %.2e\n",
-             n, nprow, npcol, P, peer ? "peer-window" : "host-hook", problem ? "generalized" : "standard",
+             n, nprow, npcol, P, "host-hook", problem ? "generalized" : "standard",
              stage[0] + stage[1] + stage[2] + stage[3] + stage[4] + stage[5] + stage[6], stage[0], stage[1], stage[2],
              stage[3], stage[4], stage[5], stage[6], w[0], w[n - 1], worst);
       fflush(stdout);
@@ -157,9 +156,9 @@ static int run_rank(int rank, int n, int nprow, int npcol, int peer, int problem
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 1500;
   const int nprow = argc > 2 ? atoi(argv[2]) : 2, npcol = argc > 3 ? atoi(argv[3]) : 2;
-  const int peer = argc > 4 ? atoi(argv[4]) : 1, problem = argc > 5 ? atoi(argv[5]) : 1;
+  const int problem = argc > 4 ? atoi(argv[4]) : 1;
   const int P = nprow * npcol;
-  if (n < 2 || P < 1 || P > 16) { fprintf(stderr, "usage: ek_ranks_demo [n] [nprow] [npcol] [peer_windows] [problem]\n"); return 64; }
+  if (n < 2 || P < 1 || P > 16) { fprintf(stderr, "usage: ek_ranks_demo [n] [nprow] [npcol] [problem]\n"); return 64; }
   /* the largest exchange is an all-gather of a matrix in the library's padded layout (ld <= n + 255) */
   const size_t bytes = sizeof(shared_t) + ((size_t)(n + 256) * (n + 256)) * sizeof(double);
   g_sh = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
@@ -173,7 +172,7 @@ int main(int argc, char **argv) {
   pid_t pids[16];
   for (int r = 0; r < P; ++r) {          /* fork BEFORE anything touches the GPU */
     pids[r] = fork();
-    if (pids[r] == 0) _exit(run_rank(r, n, nprow, npcol, peer, problem));
+    if (pids[r] == 0) _exit(run_rank(r, n, nprow, npcol, problem));
   }
   int rc = 0;
   for (int r = 0; r < P; ++r) {

@@ -26,7 +26,7 @@
  *     states of the device pipeline and of the team, decided jointly by all ranks of a grid:
  *       -992  a bounded wait inside a persistent kernel of the two-stage path ran out (the
  *             application of the bulge-chasing reflectors was abandoned; outputs undefined),
- *       -993  another rank of the team failed (workspace, staging, peer windows): this rank's
+ *       -993  another rank of the team failed (workspace, staging): this rank's
  *             own step was fine, the call ended on all ranks together,
  *       -994  rank / grid-cell mismatch with the attached communicator,
  *       -995  no communicator attached,  -996  exchange (RCCL / host hook) failed,
@@ -174,17 +174,6 @@ int ek_hip_comm_init(const void *id, int bytes, int nranks, int rank);
  * RCCL-capable fabric, and for multi-process tests that share one GPU.  Every exchange drains
  * the stream and crosses PCIe twice -- a compatibility path.  -998 if no hook is registered. */
 int ek_hip_comm_attach_host(int nranks, int rank);
-/* Peer windows (optional, collective): the per-column exchange of the distributed PDSYTRD without a
- * collective kernel.  Every rank allocates a receive area in its HBM, the ranks map each other's
- * areas (hipIpc handles carried by the communicator), and from then on a column's contribution is
- * stored by the producing kernel straight into every peer's area over xGMI and announced with
- * stream memory operations (hipStreamBatchMemOp: write my sequence number on every peer, wait for
- * every peer's number here).  n_max = largest order solved while enabled.  The all-gather and the
- * broadcasts of the other distributed stages keep using the communicator.  Returns 0 on every rank
- * or the same failure on every rank: -993 = some rank could not allocate, export or map an area
- * (the ranks agree on it through the communicator, so nobody is left waiting), -995/-996 as above. */
-int ek_hip_comm_peer_enable(int n_max);
-int ek_hip_comm_peer_disable(void);
 int ek_hip_comm_size(void);                     /* 0 when none is attached */
 int ek_hip_comm_rank(void);                     /* -1 when none is attached */
 int ek_hip_comm_destroy(void);

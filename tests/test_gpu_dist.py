@@ -399,18 +399,6 @@ def _mp_worker(rank, world, port, q):
             res[solver_name] = (ep.values.copy(), cols, ep.Vectors[:, :len(cols)].copy())
             say(solver_name + " done")
         out["solve"] = res
-        # (4) the same tridiagonalisation and whole path with PEER WINDOWS: contributions stored
-        # straight into the other processes' HBM (hipIpc), announced by stream memory operations
-        assert lib.ek_hip_comm_peer_enable(n) == 0
-        Ar2, dd2, ee2, tau2, info, _ = sv.sytrd_team(A, 0)
-        assert info == 0
-        out["sytrd_peer"] = (dd2.copy(), ee2.copy(), tau2.copy(), np.tril(Ar2))
-        proc = sv.Process(rank, world, 0, 1, world, 0, rank)
-        ep, _ = sv.eigen_solver("general_hip", A, B, proc=proc)
-        cols = d.local_indices(n, int(ep.desc[d.BLOCK_ROW_]), rank, world)
-        out["solve_peer"] = (ep.values.copy(), ep.Vectors[:, :len(cols)].copy())
-        assert lib.ek_hip_comm_peer_disable() == 0
-        say("peer windows done")
         # (5) failures are reported alike on every rank: a B that is not positive definite (the
         # failing block column belongs to rank 1) and a NaN in A
         Bbad = B.copy(); Bbad[150, 150] = -1.0
@@ -485,12 +473,6 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
     assert np.array_equal(dd, outs[0]["sytrd"][0]) and np.array_equal(ee, outs[0]["sytrd"][1])
     assert np.array_equal(tau, outs[0]["sytrd"][2]) and np.array_equal(np.tril(Ar), outs[0]["sytrd"][3])
     _check_against_single(hip, oracle, A, outs[0]["sytrd"][3], *outs[0]["sytrd"][:3])
-    # peer windows: the very same bits as through the collective
-    for o in outs:
-        for a, b in zip(o["sytrd"], o["sytrd_peer"]):
-            assert np.array_equal(a, b)
-        assert np.array_equal(o["solve"]["general_hip"][0], o["solve_peer"][0])
-        assert np.array_equal(o["solve"]["general_hip"][2], o["solve_peer"][1])
     for o in outs:
         assert o["info_bad_B"] == 151 and o["info_nan_A"] == -4
         assert np.array_equal(o["w_after"], outs[0]["solve"]["hip"][0])
@@ -617,75 +599,10 @@ def test_four_processes_on_a_2x2_grid(hip, oracle, inputs, two_stage_min):
         assert np.abs(L @ L.T - B).max() <= 16 * n * EPS * np.abs(B).max()
 
 
-def test_peer_windows_need_a_communicator(hip):
-    lib = hip.load_library()
-    assert lib.ek_hip_comm_size() == 0
-    assert lib.ek_hip_comm_peer_enable(128) == -995
-    assert lib.ek_hip_comm_peer_disable() == 0       # nothing to release: still fine
-
-
-def test_peer_windows_with_one_rank_over_rccl(hip, oracle, comm1):
-    """A team of one has no peers: the window is this rank's own receive area, no wait is issued,
-    and the result is the collective path's bit for bit; enabling twice / disabling twice is legal."""
-    lib = comm1
-    A = oracle.synth_matrix(700, 1)
-    ref = hip.sytrd_team(A, 0)
-    assert ref[4] == 0
-    assert lib.ek_hip_comm_peer_enable(700) == 0
-    assert lib.ek_hip_comm_peer_enable(1024) == 0
-    got = hip.sytrd_team(A, 0)
-    assert got[4] == 0
-    for a, b in zip(ref[1:4], got[1:4]):
-        assert np.array_equal(a, b)
-    assert np.array_equal(np.tril(ref[0]), np.tril(got[0]))
-    assert lib.ek_hip_comm_peer_disable() == 0
-    assert lib.ek_hip_comm_peer_disable() == 0
-    again = hip.sytrd_team(A, 0)
-    assert np.array_equal(again[1], ref[1])
-
-
-def test_peer_windows_too_small_for_the_order_fall_back_to_the_collective(hip, oracle, comm1):
-    """The windows hold 2 * pad(n_max) + 8 doubles per slot in every peer's HBM.  An order larger than
-    the n_max they were enabled for must not be stored into them (it would run past the slots in other
-    processes' memory): that solve takes the collective exchange instead and gives the same result."""
-    lib = comm1
-    A = oracle.synth_matrix(900, 1)
-    ref = hip.sytrd_team(A, 0)
-    assert ref[4] == 0
-    assert lib.ek_hip_comm_peer_enable(200) == 0         # slots for orders up to 256
-    got = hip.sytrd_team(A, 0)                            # order 900 > 256
-    assert got[4] == 0
-    for a, b in zip(ref[1:4], got[1:4]):
-        assert np.array_equal(a, b)
-    small = oracle.synth_matrix(200, 1)                  # an order that fits still goes through the windows
-    s1 = hip.sytrd_team(small, 0)
-    assert lib.ek_hip_comm_peer_disable() == 0
-    s2 = hip.sytrd_team(small, 0)
-    assert s1[4] == 0 and np.array_equal(s1[1], s2[1]) and np.array_equal(s1[2], s2[2])
-
-
-@pytest.mark.parametrize("n,P", [(4096, 8), (5000, 3), (6144, 5)])
-def test_sytrd_team_large_orders(hip, oracle, n, P):
-    """Many strips per rank (T = 32 .. 48): the strip-stride tile enumeration at sizes the small
-    cases do not reach.  Checked without an O(n^3) CPU step: the ranks agree bit for bit, and the
-    spectrum of T equals that of the single-GPU tridiagonalisation of the same matrix."""
-    from scipy.linalg import eigvalsh_tridiagonal
-    A = oracle.synth_matrix(n, 1)
-    Ar, d, e, tau, info, mismatch = hip.sytrd_team(A, P)
-    assert info == 0 and mismatch == 0
-    Ar1, d1, e1, tau1, info1 = hip.sytrd(A)
-    assert info1 == 0
-    w = eigvalsh_tridiagonal(d, e)
-    w1 = eigvalsh_tridiagonal(d1, e1)
-    assert np.abs(w - w1).max() <= 8 * n * EPS * np.abs(w1).max()
-    assert abs(d.sum() - np.trace(A)) <= 8 * n * EPS * np.abs(np.diag(A)).sum()
-    assert np.isfinite(Ar).all() and np.abs(tau).max() <= 2.0 + 1e-12
-
-
-@pytest.mark.parametrize("argv", [["1500", "2", "2", "1", "1"], ["900", "1", "3", "0", "0"], ["700", "2", "1", "1", "1"]])
+@pytest.mark.parametrize("argv", [["1500", "2", "2", "1"], ["900", "1", "3", "0"], ["700", "2", "1", "1"]])
 def test_plain_c_host_with_forked_ranks(hip, argv):
     """host/ek_ranks_demo.c: an MPI-shaped C program that uses nothing but include/ek_hip.h -- forked
-    ranks on a process grid, the all-gather hook over shared memory, host communicator, peer windows,
+    ranks on a process grid, the all-gather hook over shared memory, host communicator,
     ek_hip_solve on block-cyclic pieces; it checks its own eigenpairs and exits non-zero otherwise."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

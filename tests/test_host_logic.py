@@ -496,7 +496,8 @@ def test_workspace_of_a_team_member_shrinks_with_the_team():
         assert p8 <= 0.55 * r3_any_p, (p8 / 2 ** 30, r3_any_p / 2 ** 30)        # VERDICT r3's mark, against round 3's P = 1
         assert p1 <= 0.66 * r3_any_p                         # one GPU: 6.2 matrices instead of 9.5
         assert p8 < p4 < p2 < p1
-        assert p8 <= 5.0 * mat                               # L + Q1's reflectors + X0 + 1.63 (X1) + 1/8 (Z) + small
+        assert p8 <= 5.25 * mat                              # L + Q1's reflectors + X0 + 1.63 (X1) + 1/8 (Z) + small (0.4: the
+        #                                                      team SYMM's partial sums are 56 slots of n x 64)
         assert parts8[2] <= mat / 8 + 128 * 8 * n            # the eigenvector columns are the cell's share
     # a *_select arm on one GPU keeps the D&C compact too (C5: 1024 of 16384 columns)
     c5, _ = solver.workspace_bytes(1, 16384, 1024, 1)
