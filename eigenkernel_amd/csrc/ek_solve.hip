@@ -134,6 +134,17 @@ struct PinRing {
   char *slot(int i) const { return base + kSlot * (size_t)i; }
 };
 PinRing g_pin;
+// the pipeline's streams live as long as the process (creating its 14 streams took a call ~25 ms)
+struct PipeStreams {
+  hipStream_t cs[2 * 8] = {}, dma[2] = {};
+  int made = 0;
+  int ensure(int n) {
+    for (; made < n; ++made) EK_HIP_CHECK(hipStreamCreateWithFlags(&cs[made], hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) if (!dma[i]) EK_HIP_CHECK(hipStreamCreateWithFlags(&dma[i], hipStreamNonBlocking));
+    return 0;
+  }
+};
+PipeStreams g_pipe_streams;
 
 int usable_cores() {
   cpu_set_t set;
@@ -209,8 +220,9 @@ struct HostPipe {
     kThreads = cores >= 16 ? 6 : cores >= 8 ? 4 : 2;      // (both directions are rarely busy at once)
     if (env_threads >= 1 && env_threads <= kMaxThreads) kThreads = env_threads;
     pinned = env_pinned != 0 && g_pin.ensure(2 * kThreads);
-    for (int i = 0; i < 2 * kThreads; ++i) EK_HIP_CHECK(hipStreamCreateWithFlags(&cs[i], hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) EK_HIP_CHECK(hipStreamCreateWithFlags(&dma[i], hipStreamNonBlocking));
+    { const int rc = g_pipe_streams.ensure(2 * kThreads); if (rc) return rc; }
+    for (int i = 0; i < 2 * kThreads; ++i) cs[i] = g_pipe_streams.cs[i];
+    for (int i = 0; i < 2; ++i) dma[i] = g_pipe_streams.dma[i];
     for (int i = 0; i < 2 * kThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i], i); });
     return 0;
   }
@@ -342,8 +354,8 @@ struct HostPipe {
     cv.notify_all();
     for (auto &t : th) t.join();
     th.clear();
-    for (auto &c : cs) if (c) { (void)hipStreamDestroy(c); c = nullptr; }
-    for (auto &c : dma) if (c) { (void)hipStreamDestroy(c); c = nullptr; }
+    for (auto &c : cs) c = nullptr;              // (the streams belong to the process-wide pool)
+    for (auto &c : dma) c = nullptr;
     for (auto &e : evs) (void)hipEventDestroy(e);
     evs.clear();
     report();

@@ -62,7 +62,7 @@ extern "C" {
 /* Library / device management ---------------------------------------------------------- */
 int ek_hip_version(void);                       /* 100*major + minor                        */
 int ek_hip_init(int device);                    /* bind this process (rank) to a GPU        */
-int ek_hip_finalize(void);                      /* release cached workspaces                */
+int ek_hip_finalize(void);                      /* release cached workspaces / device images */
 const char *ek_hip_stage_name(int stage);       /* reference event name of a stage index    */
 
 /* Whole path -- replaces solve_with_general_scalapack (solver_scalapack_all.f90:127-168),
@@ -71,8 +71,12 @@ const char *ek_hip_stage_name(int stage);       /* reference event name of a sta
  *   problem : 0 standard (A x = l x), 1 generalized (A x = l B x, B SPD)
  *   n_vec   : n for the full spectrum; < n only for the *_select arms
  *   A_loc   : in: symmetric, lower triangle referenced; out: Householder reflectors
- *             below the sub-diagonal (as PDSYTRD leaves it)
+ *             below the sub-diagonal (as PDSYTRD leaves it; from order 512 on, two-stage
+ *             reduction: the band and the first stage's R factors -- INTEGRATION.md)
  *   B_loc   : in: SPD, lower; out: Cholesky factor L (needed by recovery); NULL if problem==0
+ *             (uplo = 'L' as everywhere in the reference: the strictly upper triangles of A_loc
+ *             and B_loc are neither read nor, on a 1 x 1 grid from order 2048 on, written --
+ *             only the lower triangles cross PCIe, as PDPOTRF / PDSYTRD leave the upper ones alone)
  *   w       : out: n doubles, ascending, first n_vec valid (eigenpairs%blacs%values)
  *   Z_loc   : out: eigenvectors (eigenpairs%blacs%Vectors), N x N descriptor, same NB as A;
  *             B-orthonormal (generalized) / orthonormal (standard)
