@@ -197,8 +197,8 @@ size_t sy2sb_work_bytes(int n);
 // A (lower, lda multiple of 128, zero padded) -> band in the lower band of A (A(i,j), 0 <= i-j <= 64;
 // the rest of the lower triangle is zeroed except the R factors' upper triangles inside the band).
 // Vall (n x n, ldv; must be zero on entry): explicit reflectors, column j = v_j with its unit entry
-// at row j + 64; tau1[j] (must be zero on entry).  *d_flag (device int, 0 on entry) becomes non-zero if
-// a panel could not be factored by CholeskyQR2 (the caller then falls back to the one-stage path).
+// at row j + 64; tau1[j] (must be zero on entry).  *d_flag (device int, 0 on entry): bits 8.. count the panels
+// CholeskyQR2 could not factor and the Householder rescue did (informational); the low byte stays 0.
 // s2: second stream, the panel factorisation of the next panel runs on it beside the trailing update.
 void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
                  int *d_flag, void *work);

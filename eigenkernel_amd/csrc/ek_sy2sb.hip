@@ -15,8 +15,9 @@
 //                  GEMM) followed by Householder reconstruction (Ballard et al. 2014: an LU of the
 //                  top 64x64 block of Q - S without pivoting gives V, T and the signs S), checked on
 //                  the device (Cholesky pivots, ||Q1^T Q1 - I||): a panel CholeskyQR2 cannot handle
-//                  (rank deficient / cond > 1e7) raises *d_flag and the caller falls back to the
-//                  one-stage path;
+//                  (rank deficient / cond > 1e7) sets THAT PANEL's flag and is factored by Householder
+//                  reflections inside the stage (house_tall_kernel and its companions: the per-panel rescue);
+//                  bits 8.. of *d_flag count the panels that took it, the low byte stays 0;
 //        m <= 192: Householder QR of the panel inside one workgroup's LDS (handles any rank).
 //   2. Y = A22 V            (SYMM on the lower triangle, split-K partial sums)
 //   3. W = Y T - 1/2 V (T^T V^T Y T)
