@@ -220,6 +220,40 @@ inline int split(int n) {   // first part of a recursive split, multiple of 128
   return n1;
 }
 
+// Leaves of 256 for the triangular solves (round 4).  A solve against a 256 x 256 diagonal block of L through the
+// two 128-block inverses is leaf, rank-128 correction, leaf: three small GEMMs and two copies of ~25 us each.  With the
+// explicit inverse of the 256-block, inv256 = [I11 0; -I22 L21 I11  I22] (two 128^3 products per block, batched, once
+// per factorisation), it is ONE product with K = 256 and one copy.  The whole-path call registers the array for the L it
+// has just factored (trsm_register_inv256); a solve whose `invdiag` pointer lies in the registered array of 128-block
+// inverses, at an even block, with n = 256, takes it; everything else is as before.
+struct Inv256 { const double *base128 = nullptr; const double *inv256 = nullptr; int nblk256 = 0; };
+Inv256 g_inv256;
+inline const double *leaf256(const double *invdiag, int n) {
+  if (!g_inv256.inv256 || n != 2 * NB || invdiag < g_inv256.base128) return nullptr;
+  const size_t d = (size_t)(invdiag - g_inv256.base128);
+  if (d % ((size_t)2 * NB * NB) != 0) return nullptr;
+  const size_t b = d / ((size_t)2 * NB * NB);
+  return b < (size_t)g_inv256.nblk256 ? g_inv256.inv256 + b * (size_t)4 * NB * NB : nullptr;
+}
+inline int split_t(int n) {   // the solves split on multiples of 256 where they can, so that aligned 256-leaves appear
+  if (n <= 2 * NB) return NB;
+  int n1 = round_up(n / 2, 2 * NB);
+  if (n1 >= n) n1 -= 2 * NB;
+  if (n1 < 2 * NB) n1 = 2 * NB;
+  return n1;
+}
+__global__ void inv256_assemble_kernel(const double *__restrict__ inv128, double *__restrict__ inv256) {
+  const int b = blockIdx.x;
+  double *D = inv256 + (size_t)b * 4 * NB * NB;
+  const double *I11 = inv128 + (size_t)(2 * b) * NB * NB, *I22 = I11 + NB * NB;
+  for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
+    const int i = idx & (NB - 1), j = idx >> 7;
+    D[i + (size_t)j * 2 * NB] = I11[idx];
+    D[(NB + i) + (size_t)(NB + j) * 2 * NB] = I22[idx];
+    D[i + (size_t)(NB + j) * 2 * NB] = 0.0;
+  }
+}
+
 void potrf_rec(hipStream_t s, int n, double *B, int ldb, int off, double *invdiag, int *d_info,
                double *work) {
   double *Bd = B + (size_t)off + (size_t)off * ldb;
@@ -254,6 +288,27 @@ void potrf_lower(hipStream_t s, int n, double *B, int ldb, double *invdiag, int 
   potrf_rec(s, n, B, ldb, 0, invdiag, d_info, work);
 }
 
+// inv256 (n / 256 blocks of 256 x 256, ld 256) from L and the 128-block inverses; scratch: >= (n / 256) * 128 * 128 doubles
+void trtri256_blocks(hipStream_t s, int n, const double *L, int ldl, const double *invdiag, double *inv256, double *scratch) {
+  const int nb2 = n / (2 * NB);
+  if (nb2 <= 0) return;
+  GemmDesc g{};
+  g.M = NB; g.N = NB; g.K = NB; g.transA = false; g.transB = false; g.alpha = 1.0; g.beta = 0.0; g.batch = nb2; g.lower_only = false;
+  g.A = L + NB; g.lda = ldl; g.strideA = (long long)2 * NB * ((long long)ldl + 1);             // L21 of block b
+  g.B = invdiag; g.ldb = NB; g.strideB = (long long)2 * NB * NB;                              // I11
+  g.C = scratch; g.ldc = NB; g.strideC = (long long)NB * NB;
+  gemm(s, g);
+  g.alpha = -1.0;
+  g.A = invdiag + (size_t)NB * NB; g.lda = NB; g.strideA = (long long)2 * NB * NB;            // I22
+  g.B = scratch; g.ldb = NB; g.strideB = (long long)NB * NB;
+  g.C = inv256 + NB; g.ldc = 2 * NB; g.strideC = (long long)4 * NB * NB;                      // lower-left quarter
+  gemm(s, g);
+  hipLaunchKernelGGL(inv256_assemble_kernel, dim3(nb2), dim3(256), 0, s, invdiag, inv256);
+}
+void trsm_register_inv256(const double *invdiag, const double *inv256, int n) {
+  g_inv256.base128 = inv256 ? invdiag : nullptr; g_inv256.inv256 = inv256; g_inv256.nblk256 = inv256 ? n / (2 * NB) : 0;
+}
+
 void trtri_diag_blocks(hipStream_t s, int n, const double *L, int ldl, double *invdiag) {
   set_attrs();
   if (n <= 0) return;
@@ -268,12 +323,17 @@ void trtri_diag_blocks(hipStream_t s, int n, const double *L, int ldl, double *i
 void trsm_rlt(hipStream_t s, int m, int n, const double *L, int ldl, const double *invdiag,
               double *X, int ldx, double *work) {
   if (m <= 0 || n <= 0) return;
+  if (const double *i2 = leaf256(invdiag, n)) {
+    gemm(s, false, true, m, n, n, 1.0, X, ldx, i2, 2 * NB, 0.0, work, m);
+    copy_matrix(s, m, n, work, m, X, ldx);
+    return;
+  }
   if (n <= NB) {
     gemm(s, false, true, m, n, n, 1.0, X, ldx, invdiag, NB, 0.0, work, m);
     copy_matrix(s, m, n, work, m, X, ldx);
     return;
   }
-  const int n1 = split(n), n2 = n - n1;
+  const int n1 = split_t(n), n2 = n - n1;
   double *X2 = X + (size_t)n1 * ldx;
   const double *L21 = L + n1, *L22 = L + (size_t)n1 + (size_t)n1 * ldl;
   trsm_rlt(s, m, n1, L, ldl, invdiag, X, ldx, work);
@@ -285,12 +345,17 @@ void trsm_rlt(hipStream_t s, int m, int n, const double *L, int ldl, const doubl
 void trsm_lln(hipStream_t s, int n, int m, const double *L, int ldl, const double *invdiag,
               double *X, int ldx, double *work) {
   if (m <= 0 || n <= 0) return;
+  if (const double *i2 = leaf256(invdiag, n)) {
+    gemm(s, false, false, n, m, n, 1.0, i2, 2 * NB, X, ldx, 0.0, work, n);
+    copy_matrix(s, n, m, work, n, X, ldx);
+    return;
+  }
   if (n <= NB) {
     gemm(s, false, false, n, m, n, 1.0, invdiag, NB, X, ldx, 0.0, work, n);
     copy_matrix(s, n, m, work, n, X, ldx);
     return;
   }
-  const int n1 = split(n), n2 = n - n1;
+  const int n1 = split_t(n), n2 = n - n1;
   double *X2 = X + n1;
   const double *L21 = L + n1, *L22 = L + (size_t)n1 + (size_t)n1 * ldl;
   trsm_lln(s, n1, m, L, ldl, invdiag, X, ldx, work);
@@ -302,12 +367,17 @@ void trsm_lln(hipStream_t s, int n, int m, const double *L, int ldl, const doubl
 void trsm_llt(hipStream_t s, int n, int m, const double *L, int ldl, const double *invdiag,
               double *X, int ldx, double *work) {
   if (m <= 0 || n <= 0) return;
+  if (const double *i2 = leaf256(invdiag, n)) {
+    gemm(s, true, false, n, m, n, 1.0, i2, 2 * NB, X, ldx, 0.0, work, n);
+    copy_matrix(s, n, m, work, n, X, ldx);
+    return;
+  }
   if (n <= NB) {
     gemm(s, true, false, n, m, n, 1.0, invdiag, NB, X, ldx, 0.0, work, n);
     copy_matrix(s, n, m, work, n, X, ldx);
     return;
   }
-  const int n1 = split(n), n2 = n - n1;
+  const int n1 = split_t(n), n2 = n - n1;
   double *X2 = X + n1;
   const double *L21 = L + n1, *L22 = L + (size_t)n1 + (size_t)n1 * ldl;
   trsm_llt(s, n2, m, L22, ldl, invdiag + (size_t)(n1 / NB) * NB * NB, X2, ldx, work);
@@ -359,8 +429,8 @@ static inline dim3 grid_mn(int m, int n) { return dim3(ceil_div(m, 256), n < 204
 static void trsm_rlt_lower(hipStream_t s, int n, const double *L, int ldl, const double *invdiag,
                            double *X, int ldx, double *work) {
   if (n <= 0) return;
-  if (n <= NB) { trsm_rlt(s, n, n, L, ldl, invdiag, X, ldx, work); return; }
-  const int n1 = split(n), n2 = n - n1;
+  if (n <= NB || leaf256(invdiag, n)) { trsm_rlt(s, n, n, L, ldl, invdiag, X, ldx, work); return; }
+  const int n1 = split_t(n), n2 = n - n1;
   const double *L21 = L + n1, *L22 = L + (size_t)n1 + (size_t)n1 * ldl;
   double *X21 = X + n1, *X22 = X + (size_t)n1 + (size_t)n1 * ldx;
   trsm_rlt(s, n, n1, L, ldl, invdiag, X, ldx, work);                          // all rows of block column 1
@@ -393,7 +463,7 @@ static void sygst_rec(hipStream_t s, int n, double *A, int lda, const double *L,
     trsm_rlt_lower(s, n, L, ldl, invdiag, A, lda, work);
     return;
   }
-  const int n1 = split(n), n2 = n - n1;
+  const int n1 = split_t(n), n2 = n - n1;
   double *A21 = A + n1, *A22 = A + (size_t)n1 + (size_t)n1 * lda;
   const double *L21 = L + n1, *L22 = L + (size_t)n1 + (size_t)n1 * ldl;
   const double *inv2 = invdiag + (size_t)(n1 / NB) * NB * NB;

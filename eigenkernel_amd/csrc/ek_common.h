@@ -105,6 +105,11 @@ inline size_t sygst_scratch_doubles(int n) {
   const size_t a = 2 * h * h, b = 2 * 128 * 128;
   return a > b ? a : b;
 }
+// Leaves of 256 for the three solves above (and the reduction below): inverses of the 256 x 256 diagonal blocks of L
+// (n / 256 of them, ld 256) from L and its 128-block inverses; registered for the array `invdiag` they belong to until
+// trsm_register_inv256(nullptr, nullptr, 0).  scratch: >= (n / 256) * 128 * 128 doubles.
+void trtri256_blocks(hipStream_t s, int n, const double *L, int ldl, const double *invdiag, double *inv256, double *scratch);
+void trsm_register_inv256(const double *invdiag, const double *inv256, int n);
 void sygst_lower(hipStream_t s, int n, double *A, int lda, const double *L, int ldl,
                  const double *invdiag, double *work, double *scratch);
 // Distributed form (PDSYGST on a 1 x P grid): both triangular solves are sharded by columns,

@@ -403,7 +403,7 @@ struct PathPlan {
   int ld, nblk, zcols;
   bool two_stage, potrf_rl, compact_dc;
   size_t mat, zmat, x0, x1, sygst_dbl, potrf_wb, wb_sytrd, wb_stedc, wb_ormtr, wb_sy2sb, wb_sb2st, wb_rec, wb_q1prep,
-         trsm_work, total;
+         trsm_work, inv256, total;
 };
 PathPlan plan_path(int problem, int n, int n_vec, int nc_loc, int nranks_dist /* 0: not distributed */) {
   PathPlan p{};
@@ -420,7 +420,8 @@ PathPlan plan_path(int problem, int n, int n_vec, int nc_loc, int nranks_dist /*
   p.wb_sytrd = (p.two_stage) ? 0 : (dist ? sytrd_dist_work_bytes(n, nranks_dist) : sytrd_work_bytes(n));
   p.wb_stedc = stedc_work_bytes(n, nc_loc);
   p.wb_ormtr = ormtr_work_bytes(n, nc_loc, n_vec);
-  p.trsm_work = al((size_t)128 * p.ld * 8);
+  p.trsm_work = al((size_t)256 * p.ld * 8);       // (a leaf of the solves writes its m x 256 result here before it goes back)
+  p.inv256 = (problem == 1) ? al((size_t)(n / 256 > 0 ? n / 256 : 1) * 256 * 256 * 8) : 0;   // 256-block inverses of L
   p.sygst_dbl = (problem == 1) ? sygst_scratch_doubles(n) : 0;
   if (problem == 1 && dist) {
     const size_t dd = sygst_dist_scratch_doubles(n, p.ld, nranks_dist);
@@ -441,7 +442,7 @@ PathPlan plan_path(int problem, int n, int n_vec, int nc_loc, int nranks_dist /*
   if (p.wb_rec > p.x1) p.x1 = p.wb_rec;
   if (al(p.wb_ormtr) > p.x1) p.x1 = al(p.wb_ormtr);
   p.total = 2 * p.mat + p.zmat + p.x0 + p.x1 + al((size_t)p.nblk * kDiagNB * kDiagNB * 8) + p.trsm_work +
-            5 * al((size_t)p.ld * 8) + p.wb_sy2sb + p.wb_sb2st + p.wb_q1prep + 4096;
+            5 * al((size_t)p.ld * 8) + p.wb_sy2sb + p.wb_sb2st + p.wb_q1prep + p.inv256 + 4096;
   return p;
 }
 
@@ -475,19 +476,32 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   if (dist) rc = comm_agree(rc);         // a rank that cannot get its workspace takes the team out with it (-993)
   if (rc) return rc;
   Arena a(ws, g_ctx.ws_bytes);
-  double *wB = a.get<double>((size_t)ld * ld);
+  // A caller's device array IS the internal work array when it already has the internal layout (order a multiple of 128,
+  // leading dimension = order, 256-byte aligned: the bench's and the host path's arrays at the BASELINE orders): the
+  // stage-in / stage-out copies of A, B and Z -- five passes over 2 GiB at N = 16384, 4.4 ms of a 0.86 s solve -- are
+  // then not made (EK_HIP_ALIAS=0: always copy).  The plan above keeps its sizes: an upper bound.
+  static int alias_env = -1;
+  if (alias_env < 0) { const char *e = getenv("EK_HIP_ALIAS"); alias_env = (e && atoi(e) == 0) ? 0 : 1; }
+  auto alias_ok = [&](const double *p, int ldu) {
+    return alias_env && p && n % 128 == 0 && ldu == ld && (((size_t)p) & 255) == 0;
+  };
+  const bool aliasA = alias_ok(dA, lda), aliasB = problem == 1 && alias_ok(dB, ldb);
+  const bool aliasZ = !cell && nc_loc == n && zcols == ld && alias_ok(dZ, ldz);
+  double *wB = aliasB ? dB : a.get<double>((size_t)ld * ld);
   double *wV = a.get<double>((size_t)ld * ld);
-  double *wZ = a.get<double>((size_t)ld * zcols);
+  double *wZ = aliasZ ? dZ : a.get<double>((size_t)ld * zcols);
   double *x0 = a.get<double>((size_t)ld * ld);
   char *x1 = a.get<char>(pl.x1);
   double *dInv = a.get<double>((size_t)nblk * kDiagNB * kDiagNB);
-  double *twork = a.get<double>((size_t)128 * ld);
+  double *twork = a.get<double>((size_t)256 * ld);
   double *dd = a.get<double>(ld), *de = a.get<double>(ld), *dt = a.get<double>(ld), *dwv = a.get<double>(ld);
   double *dt1 = a.get<double>(ld);
   char *work_sy2sb = two_stage ? a.get<char>(pl.wb_sy2sb) : nullptr;
   char *work_sb2st = two_stage ? a.get<char>(pl.wb_sb2st) : nullptr;
   char *q1prep = two_stage ? a.get<char>(pl.wb_q1prep) : nullptr;
-  double *wA = x0;                       // X0, first life: the matrix
+  double *inv256 = pl.inv256 ? (double *)a.get<char>(pl.inv256) : nullptr;
+  struct Inv256Guard { ~Inv256Guard() { trsm_register_inv256(nullptr, nullptr, 0); } } inv256_guard;   // (whichever way the call ends)
+  double *wA = aliasA ? dA : x0;         // X0, first life: the matrix (unless the caller's array serves)
   double *wV2 = x0;                      // X0, second life: the reflectors of the bulge chasing
   double *sscr = (problem == 1) ? (double *)x1 : nullptr;                       // X1, phase A
   char *pwork = pl.potrf_wb ? x1 + al(pl.sygst_dbl * 8) : nullptr;
@@ -495,7 +509,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   double *q2rec = (double *)x1;          // X1 as the records of Q2
   // where the one-stage tridiagonalisation keeps x, the panel and its partial sums (probed once per workspace)
   char *sytrd_arena = x1 + al(pl.sygst_dbl * 8) + pl.potrf_wb + 256;
-  void *sytrd_work = two_stage ? nullptr : choose_sytrd_scratch(n, ld, wA, sytrd_arena, dd, wb_sytrd);
+  // (the probe overwrites the matrix it is given: X0, never the caller's array)
+  void *sytrd_work = two_stage ? nullptr : choose_sytrd_scratch(n, ld, x0, sytrd_arena, dd, wb_sytrd);
 
   StageTimer tm;
   const bool timing = stage_seconds && n_stages > 0;
@@ -514,14 +529,17 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   auto stage_in_B = [&]() -> int {
     if (problem != 1) return 0;
     if (pipe) { const int e = pipe->wait_in(0); if (e) return e; }
+    if (aliasB) return 0;
     if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wB, 0, (size_t)ld * ld * 8, s));
     copy_matrix(s, n, n, dB, ldb, wB, ld);
     return 0;
   };
   auto stage_in_A = [&]() -> int {
     if (pipe) { const int e = pipe->wait_in(1); if (e) return e; }
-    if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s));   // (the copy covers all of an unpadded array)
-    copy_matrix(s, n, n, dA, lda, wA, ld);
+    if (!aliasA) {
+      if (ld != n) EK_HIP_CHECK(hipMemsetAsync(wA, 0, (size_t)ld * ld * 8, s));   // (the copy covers all of an unpadded array)
+      copy_matrix(s, n, n, dA, lda, wA, ld);
+    }
     // Scale A into the safe range when its entries are extreme (as DSYEV / PDSYEV do before
     // DSYTRD): the Householder norms are plain sums of squares.  Eigenvalues scale back linearly.
     double *d_part = (double *)work;   // stage scratch, free until the reduction starts
@@ -557,13 +575,17 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
       potrf_lower(s, n, wB, ld, dInv, g_ctx.d_info, twork);
     }
   }
+  if (problem == 1 && n >= 256) {      // leaves of 256 for the solves of the reduction and of the recovery (ek_chol.hip)
+    trtri256_blocks(s, n, wB, ld, dInv, inv256, twork);
+    trsm_register_inv256(dInv, inv256, n);
+  }
   mark();                                                              // 2
   if (pipe) {
     // (L is final, but its way out waits until A is in: the output workers' memcpys would share the host's memory
     // bandwidth with the input that the next stage is waiting for -- A came in at 24 GB/s beside them, B alone at 51)
     rc = stage_in_A(); if (rc) { tm.destroy(); return rc; }
     if (problem == 1) {        // L leaves while the reduction runs
-      copy_matrix(s, n, n, wB, ld, dB, ldb);
+      if (!aliasB) copy_matrix(s, n, n, wB, ld, dB, ldb);
       pipe->push(true, dB, ldb, pipe->hB, pipe->ldhb, n, n, pipe->mark(s), 0, /*lower=*/true);
     }
   }
@@ -582,7 +604,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // what the call leaves in A -- PDSYTRD's reflectors; after a two-stage reduction the band and the first stage's R factors
   //  -- goes back to the caller as soon as it is final: its place (X0) is needed again
   auto a_out = [&]() {
-    copy_matrix(s, n, n, wA, ld, dA, lda);
+    if (!aliasA) copy_matrix(s, n, n, wA, ld, dA, lda);
     if (pipe) pipe->push(true, dA, lda, pipe->hA, pipe->ldha, n, n, pipe->mark(s), 0, /*lower=*/true);
   };
   if (dist && !two_stage) {
@@ -657,7 +679,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     return (left > 512) ? (left + 1) / 2 : left;
   };
   auto z_out = [&](int c0, int nc) {
-    copy_matrix(s, n, nc, wZ + (size_t)c0 * ld, ld, dZ + (size_t)c0 * ldz, ldz);
+    if (!aliasZ) copy_matrix(s, n, nc, wZ + (size_t)c0 * ld, ld, dZ + (size_t)c0 * ldz, ldz);
     pipe->push(true, dZ + (size_t)c0 * ldz, ldz, pipe->hZ + (size_t)c0 * pipe->ldhz, pipe->ldhz, n, nc, pipe->mark(s), 0);
   };
   if (two_stage_done) {
@@ -701,8 +723,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   EK_HIP_CHECK(hipMemcpyAsync(dw, dwv, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
   if (!pipe) {
     if (cell) gather_block_cyclic(s, nr_loc, nc_loc, zc, ld, cell->nb, cell->nprow, cell->myrow, 1, 0, dZ, ldz);
-    else copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
-    if (problem == 1) copy_matrix(s, n, n, wB, ld, dB, ldb);
+    else if (!aliasZ) copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
+    if (problem == 1 && !aliasB) copy_matrix(s, n, n, wB, ld, dB, ldb);
   }
   mark();                                                              // 8
   EK_HIP_CHECK(hipGetLastError());
