@@ -216,6 +216,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
 }
 
+// (Measured and withdrawn, round 4: the same kernel with K walked in steps of 32 -- half the barrier pairs, 2 x 36 KB of
+// LDS, sixteen doubles of prefetch per operand: 256 VGPRs with 11 - 30 spilled, 54 TFLOP/s against 68 on the (n/2)^3
+// shapes.)
+
 // ---------------------------------------------------------------------------------------
 // 8-wave variant of the 128x128 tile: 512 threads, each wave a 64x32 slice (4x2 MFMA tiles,
 // 64 accumulator VGPRs), so two workgroups = 4 waves per SIMD are resident.
