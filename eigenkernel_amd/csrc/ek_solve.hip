@@ -399,6 +399,8 @@ struct StageTimer {      // events are released when the timer goes out of scope
 //                THEN the compact-WY records of Q2 (1.55 n^2, made from V2 after the D&C), THEN the scratch of Q1.
 // The copy of the reduced matrix for a fall-back to the one-stage reduction is gone: a bulge chasing that abandons a
 // bounded wait is repeated from the band it started from (a few MB) instead.
+int g_debug_fail_chase = 0;     // test aid (ek_hip_debug_fail_next_chase): pretend the next k bulge chasings abandoned a wait
+
 struct PathPlan {
   int ld, nblk, zcols;
   bool two_stage, potrf_rl, compact_dc;
@@ -645,6 +647,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
       EK_HIP_CHECK(hipMemcpyAsync(&flag, g_ctx.d_info + 2, sizeof(int), hipMemcpyDeviceToHost, s));
       EK_HIP_CHECK(hipStreamSynchronize(s));
       rescued_panels = (double)(flag >> 8);      // panels of the first stage that took the Householder rescue
+      if (g_debug_fail_chase > 0) { --g_debug_fail_chase; flag |= 4; }
       int low = flag & 0xff;
       if (dist) { low = comm_any(low); if (low < 0) return low; }
       if (low == 0) { two_stage_done = true; break; }
@@ -841,6 +844,14 @@ unsigned long long ek_hip_debug_workspace_bytes(int problem, int n, int n_vec, i
     parts[5] = p.total - (2 * p.mat + p.zmat + p.x0 + p.x1);
   }
   return p.total;
+}
+
+// Test aid: the whole-path call treats its next `times` bulge chasings as if they had abandoned a bounded wait (the
+// repetition from the saved band with the older kernel, and -992 after the third failure, are otherwise unreachable).
+int ek_hip_debug_fail_next_chase(int times) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_debug_fail_chase = times > 0 ? times : 0;
+  return 0;
 }
 
 int ek_hip_set_allgatherv(ek_hip_allgatherv_fn fn, void *user) {

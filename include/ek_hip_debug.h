@@ -78,6 +78,10 @@ int ek_hip_debug_last_solve_stats(double *out, int count);
    scratch), the rest.  ek_solve.hip plan_path. */
 unsigned long long ek_hip_debug_workspace_bytes(int problem, int n, int n_vec, int nranks, unsigned long long *parts);
 
+/* test aid: the next `times` bulge chasings of whole-path calls count as abandoned (exercises the repetition from the
+   saved band and the -992 exit of ek_solve.hip) */
+int ek_hip_debug_fail_next_chase(int times);
+
 #ifdef __cplusplus
 }
 #endif

@@ -425,3 +425,25 @@ def test_grid_cell_piece_through_two_stages_is_bit_identical(hip, oracle, forced
     ri = dsc.local_indices(n, nb, 1, 2); ci = dsc.local_indices(n, nb, 1, 2)
     assert np.array_equal(epg.values, ep.values)
     assert np.array_equal(epg.Vectors[:len(ri), :len(ci)], ep.Vectors[np.ix_(ri, ci)])
+
+
+def test_an_abandoned_bulge_chasing_is_repeated_from_the_saved_band(hip, oracle):
+    """The whole-path call keeps no copy of the reduced matrix any more (round 4): a bulge chasing that abandons a bounded
+    wait -- a matter of timing, simulated here by a debug hook -- is repeated from the band it started from with the
+    older kernel, up to twice; the result is the undisturbed one bit for bit (both kernels run the same arithmetic), and a
+    third failure ends the call with -992."""
+    n = 900
+    A = oracle.synth_matrix(n, 1); B = oracle.synth_matrix(n, 2)
+    lib = hip.load_library()
+    ref, _ = hip.eigen_solver("general_hip", A, B)
+    for times in (1, 2):
+        assert lib.ek_hip_debug_fail_next_chase(times) == 0
+        ep, _ = hip.eigen_solver("general_hip", A, B)
+        assert np.array_equal(ep.values, ref.values) and np.array_equal(ep.Vectors, ref.Vectors)
+    assert lib.ek_hip_debug_fail_next_chase(3) == 0
+    with pytest.raises(Exception) as err:
+        hip.eigen_solver("general_hip", A, B)
+    assert "-992" in str(err.value)
+    assert lib.ek_hip_debug_fail_next_chase(0) == 0
+    ep, _ = hip.eigen_solver("general_hip", A, B)
+    assert np.array_equal(ep.values, ref.values)
