@@ -367,7 +367,15 @@ def _mp_worker(rank, world, port, q):
         lib = sv.load_library()
         assert lib.ek_hip_init(0) == 0
         say("GPU bound")
-        sv.set_allgatherv(sv.torch_allgatherv(dist))
+        base_hook = sv.torch_allgatherv(dist)
+        inject = {"calls": 0, "fail_at": -1}
+
+        def hook(send, counts, displs):       # the exchange itself always happens; one call may then REPORT a failure
+            res = base_hook(send, counts, displs)
+            inject["calls"] += 1
+            return res[:-1] if inject["calls"] == inject["fail_at"] else res
+        hook.n_ranks = base_hook.n_ranks
+        sv.set_allgatherv(hook)
         sv.comm_attach_host(world, rank)
         out = {}
         # (1) the distributed tridiagonalisation, this process being rank `rank` of the team
@@ -399,6 +407,21 @@ def _mp_worker(rank, world, port, q):
             res[solver_name] = (ep.values.copy(), cols, ep.Vectors[:, :len(cols)].copy())
             say(solver_name + " done")
         out["solve"] = res
+        # (4) an exchange that fails on ONE rank in the middle of a solve (here: rank 1's hook reports a failure of its
+        # 12th exchange from now, inside the dense -> band stage at this order) ends the call on EVERY rank with -996: the sticky
+        # record travels in the team's votes (ek_comm.hip comm_vote); the next call starts clean
+        if rank == 1:
+            inject["fail_at"] = inject["calls"] + 12
+        proc = sv.Process(rank, world, 0, 1, world, 0, rank)
+        try:
+            sv.eigen_solver("general_hip", A, B, proc=proc)
+            out["info_exchange_failure"] = 0
+        except sv.SolverError as exc:
+            out["info_exchange_failure"] = exc.info
+        inject["fail_at"] = -1
+        ep, _ = sv.eigen_solver("general_hip", A, B, proc=proc)
+        out["w_after_exchange_failure"] = ep.values.copy()
+        say("exchange failure on one rank done")
         # (5) failures are reported alike on every rank: a B that is not positive definite (the
         # failing block column belongs to rank 1) and a NaN in A
         Bbad = B.copy(); Bbad[150, 150] = -1.0
@@ -474,6 +497,8 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
     assert np.array_equal(tau, outs[0]["sytrd"][2]) and np.array_equal(np.tril(Ar), outs[0]["sytrd"][3])
     _check_against_single(hip, oracle, A, outs[0]["sytrd"][3], *outs[0]["sytrd"][:3])
     for o in outs:
+        assert o["info_exchange_failure"] == -996
+        assert np.array_equal(o["w_after_exchange_failure"], outs[0]["solve"]["general_hip"][0])
         assert o["info_bad_B"] == 151 and o["info_nan_A"] == -4
         assert np.array_equal(o["w_after"], outs[0]["solve"]["hip"][0])
     # potrf: the complete factor on every process
