@@ -515,10 +515,10 @@ def main():
                     help="order of the ScaLAPACK-path sample (all physical cores)")
     ap.add_argument("--distribution", choices=["auto", "replicas", "columns", "grid"], default="auto",
                     help="N>1 GPUs: 'auto' (default) = measure replicas first (one independent problem per rank: "
-                         "the safe line), then ONE problem distributed over the 1 x N grid in both exchange modes "
-                         "(the 'grid_probe'), and report the faster distributed mode that passed the parity check on "
-                         "every rank as the headline (\"scaling\": \"strong\"), the replicas numbers beside it; if "
-                         "neither did, the replicas line is the headline.  "
+                         "the safe line), then ONE problem distributed over the 1 x N grid "
+                         "(the 'grid_probe'), and report it, if it passed the parity check on every rank, as the "
+                         "headline (\"scaling\": \"strong\"), the replicas numbers beside it; if it did not, the "
+                         "replicas line is the headline.  "
                          "'replicas' = one independent problem per rank (weak scaling) as the headline; "
                          "'columns' = ONE problem on a 1 x N process grid in replicated-input mode "
                          "(ek_hip_solve_device_grid: reduction replicated, eigenvector columns sharded; strong scaling); "
