@@ -43,13 +43,16 @@ struct GemmDesc {
   const long long *d_offs = nullptr;   // device: per-batch element offsets {A, B, C} (added to strides)
   const int *d_dims = nullptr;         // device: per-batch {M, N, K}; host M, N, K are then upper bounds
   bool even_offs = false;              // the caller's promise that every d_offs entry for A and B is even (16-byte loads stay aligned)
+  bool small_tiles = false;            // lower_only only: the caller does not need whole 128 x 128 diagonal tiles written -- the
+                                       // 64 x 64 tiling may serve (short trailing updates: four times the workgroups, a quarter of the work each)
 };
 void gemm(hipStream_t s, const GemmDesc &g);
 
 inline void gemm(hipStream_t s, bool ta, bool tb, int M, int N, int K, double alpha,
                  const double *A, int lda, const double *B, int ldb, double beta, double *C,
-                 int ldc, bool lower_only = false, bool staged_rank_k = false) {
+                 int ldc, bool lower_only = false, bool staged_rank_k = false, bool small_tiles = false) {
   GemmDesc g{M, N, K, ta, tb, alpha, beta, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, lower_only, staged_rank_k};
+  g.small_tiles = small_tiles;
   gemm(s, g);
 }
 

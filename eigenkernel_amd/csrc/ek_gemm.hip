@@ -615,7 +615,7 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   // lower_only is defined on the 128x128 tiling (callers rely on whole diagonal tiles being
   // written), so the small-grid variant is used for plain products only
   const long long big_tiles = (long long)ceil_div(g.M, BM) * ceil_div(g.N, BN) * g.batch;
-  if (big_tiles < 256 && !g.lower_only) {
+  if ((big_tiles < 256 && !g.lower_only) || (g.lower_only && g.small_tiles)) {
     p.tiles_m = ceil_div(g.M, SM); p.tiles_n = ceil_div(g.N, SN);
     dim3 sgrid(p.tiles_m * p.tiles_n, g.batch), sblock(256);
     if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, false>), sgrid, sblock, 0, s, p);

@@ -134,6 +134,11 @@ struct PinRing {
   char *slot(int i) const { return base + kSlot * (size_t)i; }
 };
 PinRing g_pin;
+// what the last staging pipeline did (ek_hip_debug_last_pipe_stats): [0] bytes in, [1] span of the input transfers (s),
+// [2] busy seconds of the input workers, [3..5] the same on the way out, [6] seconds the main thread waited for inputs,
+// [7] for the drain at the end, [8] workers per direction, [9] directions through the pinned ring, [10] seconds from the
+// start of the pipeline to its end, [11] seconds before the first input job started
+double g_pipe_stats[12] = {0};
 // the pipeline's streams live as long as the process (creating its 14 streams took a call ~25 ms)
 struct PipeStreams {
   hipStream_t cs[2 * 8] = {}, dma[2] = {};
@@ -188,7 +193,24 @@ struct HostPipe {
   struct TraceRec { double t0, t1; double bytes; int kind; };      // kind 0 = in, 1 = out, 2 = wait_in, 3 = finish
   std::vector<TraceRec> trace_log;
   double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_origin).count(); }
+  void collect_stats() {
+    double busy[2] = {0, 0}, bytes[2] = {0, 0}, first[2] = {1e30, 1e30}, last[2] = {0, 0}, win = 0, wdrain = 0;
+    for (const auto &r : trace_log) {
+      if (r.kind < 2) {
+        busy[r.kind] += r.t1 - r.t0; bytes[r.kind] += r.bytes;
+        if (r.t0 < first[r.kind]) first[r.kind] = r.t0;
+        if (r.t1 > last[r.kind]) last[r.kind] = r.t1;
+      } else if (r.kind == 2) win += r.t1 - r.t0;
+      else wdrain += r.t1 - r.t0;
+    }
+    for (int k = 0; k < 2; ++k) {
+      g_pipe_stats[3 * k] = bytes[k]; g_pipe_stats[3 * k + 1] = bytes[k] > 0 ? last[k] - first[k] : 0.0; g_pipe_stats[3 * k + 2] = busy[k];
+    }
+    g_pipe_stats[6] = win; g_pipe_stats[7] = wdrain; g_pipe_stats[8] = kThreads; g_pipe_stats[9] = pinned ? pinned_dirs : 0;
+    g_pipe_stats[10] = now(); g_pipe_stats[11] = bytes[0] > 0 ? first[0] : 0.0;
+  }
   void report() {
+    collect_stats();
     if (!trace) return;
     double busy[2] = {0, 0}, bytes[2] = {0, 0}, first[2] = {1e30, 1e30}, last[2] = {0, 0};
     for (const auto &r : trace_log) {
@@ -227,6 +249,15 @@ struct HostPipe {
     return 0;
   }
   // one job through the worker's two pinned slots (m rows of 8 bytes, n columns; a chunk = as many columns as fit a slot)
+  // completion of a slot's transfer by POLLING: hipEventSynchronize sleeps, and a worker that waits for every 16 MiB chunk
+  // of the way out that way moved ~1 GB/s (round 4's first ring)
+  static hipError_t wait_event(hipEvent_t e) {
+    for (unsigned spins = 0;; ++spins) {
+      const hipError_t q = hipEventQuery(e);
+      if (q != hipErrorNotReady) return q;
+      if ((spins & 63u) == 63u) std::this_thread::yield();
+    }
+  }
   hipError_t copy_pinned(const Job &j, hipStream_t c, int worker) {
     const size_t col_bytes = (size_t)j.m * 8;
     if (col_bytes > PinRing::kSlot) return hipErrorInvalidValue;      // (orders beyond a million)
@@ -239,7 +270,7 @@ struct HostPipe {
     if (!j.to_host) {
       for (int q = 0; q < nchunk && e == hipSuccess; ++q) {
         const int k = q & 1, c0 = q * cpc, nc = cols(q);
-        if (q >= 2) e = hipEventSynchronize(ev[k]);                   // the slot's previous DMA has read it
+        if (q >= 2) e = wait_event(ev[k]);                            // the slot's previous DMA has read it
         if (e != hipSuccess) break;
         const double *src = j.host + (size_t)c0 * j.ldh;
         if (j.ldh == j.m) memcpy(slot[k], src, col_bytes * nc);
@@ -253,7 +284,7 @@ struct HostPipe {
           if (e == hipSuccess) e = hipEventRecord(ev[k], dma[0]);
         }
       }
-      for (int k = 0; k < 2 && k < nchunk; ++k) { const hipError_t e2 = hipEventSynchronize(ev[k]); if (e == hipSuccess) e = e2; }
+      for (int k = 0; k < 2 && k < nchunk; ++k) { const hipError_t e2 = wait_event(ev[k]); if (e == hipSuccess) e = e2; }
       return e;
     }
     auto fetch = [&](int q) {
@@ -269,7 +300,7 @@ struct HostPipe {
     for (int q = 0; q < nchunk && e == hipSuccess; ++q) {
       const int k = q & 1, c0 = q * cpc, nc = cols(q);
       if (q + 1 < nchunk) e = fetch(q + 1);                           // (its slot was emptied by this thread one round ago)
-      if (e == hipSuccess) e = hipEventSynchronize(ev[k]);
+      if (e == hipSuccess) e = wait_event(ev[k]);
       if (e != hipSuccess) break;
       double *dst = j.host + (size_t)c0 * j.ldh;
       if (j.ldh == j.m) memcpy(dst, slot[k], col_bytes * nc);
@@ -291,7 +322,7 @@ struct HostPipe {
       }
       hipError_t e = hipSuccess;
       if (j.after) e = hipEventSynchronize(j.after);
-      const double tj0 = trace ? now() : 0.0;
+      const double tj0 = now();
       if (e == hipSuccess && j.m > 0 && j.n > 0) {
         if (pinned && (pinned_dirs & (j.to_host ? 2 : 1)) && (size_t)j.m * 8 <= PinRing::kSlot) e = copy_pinned(j, c, worker);
         else {
@@ -305,7 +336,7 @@ struct HostPipe {
       {
         std::lock_guard<std::mutex> lk(mu);
         if (e != hipSuccess && !err) err = -1000 - (int)e;
-        if (trace) trace_log.push_back(TraceRec{tj0, now(), (double)j.m * j.n * 8.0, input ? 0 : 1});
+        trace_log.push_back(TraceRec{tj0, now(), (double)j.m * j.n * 8.0, input ? 0 : 1});
         if (input) --pending_in[j.tag]; else --pending_out;
       }
       cv.notify_all();
@@ -337,19 +368,19 @@ struct HostPipe {
     cv.notify_all();
   }
   int wait_in(int tag) {
-    const double t0 = trace ? now() : 0.0;
+    const double t0 = now();
     std::unique_lock<std::mutex> lk(mu);
     cv.wait(lk, [&]() { return pending_in[tag] == 0; });
-    if (trace) trace_log.push_back(TraceRec{t0, now(), 0.0, 2});
+    trace_log.push_back(TraceRec{t0, now(), 0.0, 2});
     return err;
   }
   int finish() {                              // all copies done; threads joined; streams released
     {
-      const double t0 = trace ? now() : 0.0;
+      const double t0 = now();
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&]() { return pending_out == 0 && pending_in[0] == 0 && pending_in[1] == 0; });
       closing = true;
-      if (trace) trace_log.push_back(TraceRec{t0, now(), 0.0, 3});
+      trace_log.push_back(TraceRec{t0, now(), 0.0, 3});
     }
     cv.notify_all();
     for (auto &t : th) t.join();
@@ -848,6 +879,12 @@ unsigned long long ek_hip_debug_workspace_bytes(int problem, int n, int n_vec, i
 
 // Test aid: the whole-path call treats its next `times` bulge chasings as if they had abandoned a bounded wait (the
 // repetition from the saved band with the older kernel, and -992 after the third failure, are otherwise unreachable).
+int ek_hip_debug_last_pipe_stats(double *out, int count) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < count && i < 12; ++i) out[i] = g_pipe_stats[i];
+  return 0;
+}
+
 int ek_hip_debug_fail_next_chase(int times) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_debug_fail_chase = times > 0 ? times : 0;

@@ -1270,6 +1270,8 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   if (staged_max < 0) { const char *e = getenv("EK_SY2SB_STAGED_MAX"); staged_max = e ? atoi(e) : 8192; }
   static int la_min = -1;
   if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 5120; }
+  static int small_max = -1;
+  if (small_max < 0) { const char *e = getenv("EK_SY2SB_SMALL_MAX"); small_max = e ? atoi(e) : 0; }
 
   int *nzrows = (int *)(sm + 13 * 4096);               // one word per panel (room for 8192)
   (void)hipMemsetAsync(nzrows, 0, (size_t)ceil_div(n, SB) * sizeof(int), s);
@@ -1324,7 +1326,9 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
       (void)hipEventRecord(evB[cur ^ 1], s2);
       waited = false;
     } else {
-      gemm(s, false, true, m, m, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true);
+      // (short trailing matrices: the 64 x 64 tiling -- a launch of the 128 x 128 one lasts one tile time, 44 us, however
+      // few tiles there are)
+      gemm(s, false, true, m, m, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true, false, /*small_tiles=*/m <= small_max);
       if (has_next) panel_chain(s, r0, img[cur ^ 1], Tm[cur ^ 1]);
       waited = true;
     }

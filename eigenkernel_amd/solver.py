@@ -119,6 +119,7 @@ def load_library(path=None):
         "ek_hip_debug_sy2sb_team_timing": (c_int, [c_int, c_int, c_int, _dp]),
         "ek_hip_debug_sy2sb_team_profile": (c_int, [c_int, c_int, c_int, c_int, _dp, _dp]),
         "ek_hip_debug_fail_next_chase": (c_int, [c_int]),
+        "ek_hip_debug_last_pipe_stats": (c_int, [_dp, c_int]),
         "ek_hip_debug_workspace_bytes": (ctypes.c_ulonglong, [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
     }
     for name, (res, args) in sigs.items():
@@ -149,7 +150,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_debug_set_sytrd_maxcols", "ek_hip_debug_sytrd_work_bytes", "ek_hip_debug_sytrd_at", "ek_hip_debug_sytrd_split", "ek_hip_debug_gemm_at",
     "ek_hip_debug_sy2sb", "ek_hip_debug_sb2st", "ek_hip_debug_two_stage_timing", "ek_hip_debug_set_two_stage",
     "ek_hip_profile_kernels", "ek_hip_profile_kernels_get", "ek_hip_debug_last_solve_stats",
-    "ek_hip_debug_sy2sb_team", "ek_hip_debug_sy2sb_team_timing", "ek_hip_debug_sy2sb_team_profile", "ek_hip_debug_workspace_bytes", "ek_hip_debug_fail_next_chase",
+    "ek_hip_debug_sy2sb_team", "ek_hip_debug_sy2sb_team_timing", "ek_hip_debug_sy2sb_team_profile", "ek_hip_debug_workspace_bytes", "ek_hip_debug_fail_next_chase", "ek_hip_debug_last_pipe_stats",
 )
 
 
