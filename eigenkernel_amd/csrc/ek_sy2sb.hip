@@ -1271,7 +1271,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   static int la_min = -1;
   if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 5120; }
   static int small_max = -1;
-  if (small_max < 0) { const char *e = getenv("EK_SY2SB_SMALL_MAX"); small_max = e ? atoi(e) : 0; }
+  if (small_max < 0) { const char *e = getenv("EK_SY2SB_SMALL_MAX"); small_max = e ? atoi(e) : 4096; }   // N = 4096: stage 14.6 -> 13.9 ms
 
   int *nzrows = (int *)(sm + 13 * 4096);               // one word per panel (room for 8192)
   (void)hipMemsetAsync(nzrows, 0, (size_t)ceil_div(n, SB) * sizeof(int), s);
