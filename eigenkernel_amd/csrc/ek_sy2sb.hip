@@ -950,10 +950,13 @@ __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
       double y = 0.0, v = 0.0;
       if (row < p.m) {
         const double *yp = p.Ypart + (size_t)row + (size_t)col * p.ldy;
-        double ys[8];
+        double ys[16];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) ys[s] = (s < p.nsplit) ? yp[(size_t)s * p.sY] : 0.0;
+        for (int s = 0; s < 16; ++s) ys[s] = (s < p.nsplit) ? yp[(size_t)s * p.sY] : 0.0;
         y = ((ys[0] + ys[1]) + (ys[2] + ys[3])) + ((ys[4] + ys[5]) + (ys[6] + ys[7]));
+        // (up to sixteen partials since round 4 -- short trailing matrices are cut finer; with eight or fewer the sum is
+        // the one of rounds 2 - 3 bit for bit: adding +0.0 changes nothing)
+        if (p.nsplit > 8) y += ((ys[8] + ys[9]) + (ys[10] + ys[11])) + ((ys[12] + ys[13]) + (ys[14] + ys[15]));
         p.Y[(size_t)row + (size_t)col * (p.ldyo ? p.ldyo : p.ldy)] = y;
         v = p.V[(size_t)row + (size_t)col * p.ldv];
       }
@@ -1112,7 +1115,7 @@ struct Layout {
   explicit Layout(int n, int P = 0) {
     mpad = round_up(n > 0 ? n : 1, 128);
     nparts = mpad / CH + 1;
-    maxsplit = P > 0 ? 56 : 8;           // (team form: up to 8 direct + 48 transposed chunks per block row)
+    maxsplit = P > 0 ? 56 : 16;          // (team form: up to 8 direct + 48 transposed chunks per block row)
     size_t o = 0;
     off_img = o; o += al256((size_t)mpad * 3 * SB * 8);
     off_img2 = o; o += al256((size_t)mpad * 3 * SB * 8);
