@@ -1318,7 +1318,11 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     const bool has_next = m - SB >= 2;
     const double *P1 = Vimg, *P2 = Vimg + (size_t)SB * ldi;
     if (has_next && m >= la_min) {
-      gemm(s, false, true, m, SB, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true);
+      static int fc_small = -1;
+      if (fc_small < 0) { const char *e = getenv("EK_SY2SB_FIRSTCOL_SMALL"); fc_small = e ? atoi(e) : 1; }
+      // (the next panel's 64 columns: m / 64 workgroups of the 64 x 64 tiling instead of m / 128 of the 128 x 128 one, whose
+      // launch lasts a whole tile time however narrow the product)
+      gemm(s, false, true, m, SB, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true, false, /*small_tiles=*/fc_small != 0);
       (void)hipEventRecord(evA[cur], s);
       // (host order: the rest of the update first, then the eleven launches of the chain -- submitted behind them the
       // update would start ~70 us late on every panel)
@@ -1545,7 +1549,7 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
         if (mem[q].rank != owner_next) continue;
         St &M = st[q];
         gemm(s, false, true, m, SB, 2 * SB, -1.0, M.img[cur], ldi, M.img[cur] + (size_t)SB * ldi, ldi, 1.0,
-             mem[q].A + (size_t)r0 + (size_t)r0 * mem[q].lda, mem[q].lda, true);
+             mem[q].A + (size_t)r0 + (size_t)r0 * mem[q].lda, mem[q].lda, true, false, /*small_tiles=*/true);
       }
       (void)hipEventRecord(evA[cur], s);
       // (the update is handed to its stream FIRST: the launches of a chain and of its broadcast take the host ~0.1 ms, and
