@@ -442,7 +442,11 @@ static void trsm_rlt_lower(hipStream_t s, int n, const double *L, int ldl, const
 // and largest GEMMs); above it the blocked recursion (n^3).  Measured on MI355X at N = 16384
 // (sygst stage), round 1: no recursion 0.133 s, threshold 2048 -> 0.115 s, 1024 -> 0.120 s, 512 -> 0.126 s;
 // with the 16-byte-load GEMM of round 2: 1024 -> 0.110, 2048 -> 0.103, 4096 -> 0.099, 8192 -> 0.099, none 0.115.
-constexpr int kSygstDirect = 4096;
+static int sygst_direct() {      // (EK_SYGST_DIRECT: tuning)
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("EK_SYGST_DIRECT"); v = e ? atoi(e) : 4096; if (v < 256) v = 256; }
+  return v;
+}
 
 // Recursive blocked DSYGST(itype = 1, 'L'):  with A = [A11 .; A21 A22], L = [L11 0; L21 L22]
 //   C11 = sygst(A11, L11)
@@ -455,7 +459,7 @@ constexpr int kSygstDirect = 4096;
 static void sygst_rec(hipStream_t s, int n, double *A, int lda, const double *L, int ldl,
                       const double *invdiag, double *work, double *scratch) {
   if (n <= 0) return;
-  if (n <= kSygstDirect) {
+  if (n <= sygst_direct()) {
     // small block: the recursion would drown in tiny launches; a full left solve plus a right
     // solve restricted to the lower triangle (1.57 n^3 flops, but few and larger GEMMs)
     symmetrize_lower(s, n, A, lda);
