@@ -403,14 +403,53 @@ __device__ __forceinline__ void sstore_slab(const double (&r)[8], double *s, int
     else         { const int x = idx & 63, k = idx >> 6; s[k * SMC_LD + x] = r[i]; }
   }
 }
+// the same slab as 16-byte pairs (interior slabs of operands with even leading dimension and aligned base: the VEC
+// conditions of gemm()): MC: pair = rows (2 xp, 2 xp + 1) at one k, xp = idx & 31, k = idx >> 5; KC: pair = k indices
+// (2 kp, 2 kp + 1) of one row, kp = idx & 15, x = idx >> 4 (idx = t + 256 i, i < 4).  Same LDS images.
+template <bool KCONTIG>
+__device__ __forceinline__ void sload_slab_v(double (&r)[8], const double *__restrict__ P, int ld, int x0, int X,
+                                             int k0, int K, int t) {
+  if (x0 + SM <= X && k0 + SK <= K) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + 256 * i;
+      double2g_t v;
+      if (KCONTIG) v = *reinterpret_cast<const double2g_t *>(P + (size_t)(k0 + 2 * (idx & 15)) + (size_t)(x0 + (idx >> 4)) * ld);
+      else         v = *reinterpret_cast<const double2g_t *>(P + (size_t)(x0 + 2 * (idx & 31)) + (size_t)(k0 + (idx >> 5)) * ld);
+      r[2 * i] = v.x; r[2 * i + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + 256 * i;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gx = x0 + (KCONTIG ? (idx >> 4) : 2 * (idx & 31) + h);
+        const int gk = k0 + (KCONTIG ? 2 * (idx & 15) + h : (idx >> 5));
+        double v = 0.0;
+        if (gx < X && gk < K) v = KCONTIG ? P[(size_t)gk + (size_t)gx * ld] : P[(size_t)gx + (size_t)gk * ld];
+        r[2 * i + h] = v;
+      }
+    }
+  }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void sstore_slab_v(const double (&r)[8], double *s, int t) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 256 * i;
+    if (KCONTIG) { const int k = 2 * (idx & 15), x = idx >> 4; s[x * SKC_LD + k] = r[2 * i]; s[x * SKC_LD + k + 1] = r[2 * i + 1]; }
+    else { const int x = 2 * (idx & 31), k = idx >> 5; *reinterpret_cast<double2g_t *>(&s[k * SMC_LD + x]) = (double2g_t){r[2 * i], r[2 * i + 1]}; }
+  }
+}
 template <bool KCONTIG>
 __device__ __forceinline__ double sfrag(const double *s, int x, int k) {
   return KCONTIG ? s[x * SKC_LD + k] : s[k * SMC_LD + x];
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs p) {
-  __shared__ double smem[2 * STILE_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double smem[2 * STILE_DOUBLES];
   double *sA = smem, *sB = smem + STILE_DOUBLES;
   const int tile = blockIdx.x;
   const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
@@ -435,16 +474,16 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   double ra[8], rb[8];
-  sload_slab<TA>(ra, A, p.lda, m0, p.M, 0, p.K, t);
-  sload_slab<!TB>(rb, B, p.ldb, n0, p.N, 0, p.K, t);
+  if (VEC) { sload_slab_v<TA>(ra, A, p.lda, m0, p.M, 0, p.K, t); sload_slab_v<!TB>(rb, B, p.ldb, n0, p.N, 0, p.K, t); }
+  else { sload_slab<TA>(ra, A, p.lda, m0, p.M, 0, p.K, t); sload_slab<!TB>(rb, B, p.ldb, n0, p.N, 0, p.K, t); }
   for (int k0 = 0; k0 < p.K; k0 += SK) {
     __syncthreads();
-    sstore_slab<TA>(ra, sA, t);
-    sstore_slab<!TB>(rb, sB, t);
+    if (VEC) { sstore_slab_v<TA>(ra, sA, t); sstore_slab_v<!TB>(rb, sB, t); }
+    else { sstore_slab<TA>(ra, sA, t); sstore_slab<!TB>(rb, sB, t); }
     __syncthreads();
     if (k0 + SK < p.K) {
-      sload_slab<TA>(ra, A, p.lda, m0, p.M, k0 + SK, p.K, t);
-      sload_slab<!TB>(rb, B, p.ldb, n0, p.N, k0 + SK, p.K, t);
+      if (VEC) { sload_slab_v<TA>(ra, A, p.lda, m0, p.M, k0 + SK, p.K, t); sload_slab_v<!TB>(rb, B, p.ldb, n0, p.N, k0 + SK, p.K, t); }
+      else { sload_slab<TA>(ra, A, p.lda, m0, p.M, k0 + SK, p.K, t); sload_slab<!TB>(rb, B, p.ldb, n0, p.N, k0 + SK, p.K, t); }
     }
 #pragma unroll
     for (int kk = 0; kk < SK; kk += 4) {
@@ -615,13 +654,28 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   // lower_only is defined on the 128x128 tiling (callers rely on whole diagonal tiles being
   // written), so the small-grid variant is used for plain products only
   const long long big_tiles = (long long)ceil_div(g.M, BM) * ceil_div(g.N, BN) * g.batch;
+  // 16-byte operand fetch: every slab start must be 16-byte aligned -- even leading dimensions, aligned bases,
+  // even batch strides, no per-batch offsets from device memory (EK_GEMM_VEC=0 turns the variants off)
+  static int vec_env = -1;
+  if (vec_env < 0) { const char *e = getenv("EK_GEMM_VEC"); vec_env = e ? atoi(e) : 1; }
+  const bool vec = vec_env && (!g.d_offs || g.even_offs) && ((g.lda | g.ldb) & 1) == 0 &&
+                   ((((size_t)g.A | (size_t)g.B) & 15) == 0) && (g.batch == 1 || ((g.strideA | g.strideB) & 1) == 0);
   if ((big_tiles < 256 && !g.lower_only) || (g.lower_only && g.small_tiles)) {
     p.tiles_m = ceil_div(g.M, SM); p.tiles_n = ceil_div(g.N, SN);
     dim3 sgrid(p.tiles_m * p.tiles_n, g.batch), sblock(256);
-    if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, false>), sgrid, sblock, 0, s, p);
-    else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, true>), sgrid, sblock, 0, s, p);
-    else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<true, false>), sgrid, sblock, 0, s, p);
-    else hipLaunchKernelGGL((gemm_small_kernel<true, true>), sgrid, sblock, 0, s, p);
+    static int svec = -1;
+    if (svec < 0) { const char *e = getenv("EK_GEMM_SMALL_VEC"); svec = e ? atoi(e) : 1; }
+    if (vec && svec) {
+      if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, false, true>), sgrid, sblock, 0, s, p);
+      else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, true, true>), sgrid, sblock, 0, s, p);
+      else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<true, false, true>), sgrid, sblock, 0, s, p);
+      else hipLaunchKernelGGL((gemm_small_kernel<true, true, true>), sgrid, sblock, 0, s, p);
+      return;
+    }
+    if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, false, false>), sgrid, sblock, 0, s, p);
+    else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, true, false>), sgrid, sblock, 0, s, p);
+    else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<true, false, false>), sgrid, sblock, 0, s, p);
+    else hipLaunchKernelGGL((gemm_small_kernel<true, true, false>), sgrid, sblock, 0, s, p);
     return;
   }
   p.tiles_m = ceil_div(g.M, BM); p.tiles_n = ceil_div(g.N, BN);
@@ -643,12 +697,6 @@ void gemm(hipStream_t s, const GemmDesc &g) {
     hipLaunchKernelGGL(gemm_rankk_kernel, grid, dim3(512), 2 * RK * RK_LD * sizeof(double), s, p);
     return;
   }
-  // 16-byte operand fetch: every slab start must be 16-byte aligned -- even leading dimensions, aligned bases,
-  // even batch strides, no per-batch offsets from device memory (EK_GEMM_VEC=0 turns the variants off)
-  static int vec_env = -1;
-  if (vec_env < 0) { const char *e = getenv("EK_GEMM_VEC"); vec_env = e ? atoi(e) : 1; }
-  const bool vec = vec_env && (!g.d_offs || g.even_offs) && ((g.lda | g.ldb) & 1) == 0 &&
-                   ((((size_t)g.A | (size_t)g.B) & 15) == 0) && (g.batch == 1 || ((g.strideA | g.strideB) & 1) == 0);
   const bool use_w8 = (w8 >= 0) ? (w8 != 0) : (g.K <= 512 && g.beta != 0.0);
   if (use_w8) {
     dim3 b8(512);
