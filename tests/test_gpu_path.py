@@ -674,3 +674,40 @@ def test_staging_pipeline_of_the_host_path_changes_no_bit(hip, oracle, monkeypat
     _, _, mx = eval_residual_norm(A, ep1.values[:n_vec], ep1.Vectors[:, :n_vec], Bm)
     assert mx <= 1e-14 * max(1.0, np.sqrt(n / 1024.0))
     assert eval_orthogonality(ep1.Vectors[:, :n_vec], Bm) <= 1e-11
+
+
+@pytest.mark.parametrize("problem,n,n_vec,pipe_min", [(1, 2100, 2100, "0"), (1, 2100, 2100, "1024"), (0, 2304, 500, "1024"),
+                                                      (1, 300, 300, "0")])
+def test_caller_leading_dimensions_larger_than_the_order(hip, oracle, monkeypatch, problem, n, n_vec, pipe_min):
+    """ScaLAPACK descriptors carry their own LLD (descriptor_parameters.f90:2-4): local arrays with LLD = n + 5, + 3 and
+    + 7 for A, B and Z give the bits of the tightly packed call -- with the serial staging and with the pipeline (which
+    moves lower triangles in trapezoid pieces) -- and the padding rows below row n come back untouched."""
+    from eigenkernel_amd import descriptor as d
+    lib = hip.load_library()
+    monkeypatch.setenv("EK_HIP_PIPE_MIN", pipe_min)
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2) if problem == 1 else None
+
+    def call(pa, pb, pz):
+        la, lb, lz = n + pa, n + pb, n + pz
+        Al = np.asfortranarray(np.full((la, n), 7.5)); Al[:n, :] = A
+        Bl = None
+        if B is not None:
+            Bl = np.asfortranarray(np.full((lb, n), -3.25)); Bl[:n, :] = B
+        Z = np.asfortranarray(np.full((lz, n), 1.125))
+        w = np.zeros(n)
+        da, db, dz = (d.descinit(n, n, n, n, 0, 0, 0, l) for l in (la, lb, lz))
+        rc = lib.ek_hip_solve(problem, n, n_vec, hip._P(Al), hip._I(da), hip._P(Bl) if Bl is not None else None,
+                              hip._I(db) if Bl is not None else None, hip._P(w), hip._P(Z), hip._I(dz), 1, 1, 0, 0, None, 0)
+        assert rc == 0
+        return Al, Bl, Z, w
+
+    A0, B0, Z0, w0 = call(0, 0, 0)
+    A1, B1, Z1, w1 = call(5, 3, 7)
+    assert np.array_equal(w0, w1)
+    assert np.array_equal(Z0[:, :n_vec], Z1[:n, :n_vec])
+    assert np.array_equal(np.tril(A0), np.tril(A1[:n]))
+    assert (A1[n:] == 7.5).all() and (Z1[n:] == 1.125).all()
+    if B is not None:
+        assert np.array_equal(np.tril(B0), np.tril(B1[:n]))
+        assert (B1[n:] == -3.25).all()
