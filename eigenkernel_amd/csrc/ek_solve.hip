@@ -513,8 +513,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // leading dimension = order, 256-byte aligned: the bench's and the host path's arrays at the BASELINE orders): the
   // stage-in / stage-out copies of A, B and Z -- five passes over 2 GiB at N = 16384, 4.4 ms of a 0.86 s solve -- are
   // then not made (EK_HIP_ALIAS=0: always copy).  The plan above keeps its sizes: an upper bound.
-  static int alias_env = -1;
-  if (alias_env < 0) { const char *e = getenv("EK_HIP_ALIAS"); alias_env = (e && atoi(e) == 0) ? 0 : 1; }
+  const char *alias_e = getenv("EK_HIP_ALIAS");          // (read per call: the tests switch it)
+  const int alias_env = (alias_e && atoi(alias_e) == 0) ? 0 : 1;
   auto alias_ok = [&](const double *p, int ldu) {
     return alias_env && p && n % 128 == 0 && ldu == ld && (((size_t)p) & 255) == 0;
   };

@@ -162,3 +162,61 @@ def test_c4_n32768_generalized_full_spectrum(hip, golden_dir):
         # the generator's spectrum: GEP eigenvalues inside [0.38, 2.63]
         assert 0.3 < w[0] < 0.5 and 2.4 < w[-1] < 2.8
         _grid_piece_is_bit_identical(lib, dev, r, True, n, n, (2, 4), (1, 3))
+
+
+@pytest.mark.parametrize("gep,n,n_vec", [(True, 1024, 1024), (False, 1280, 1280), (True, 1024, 200)])
+def test_caller_arrays_used_in_place_change_no_bit(hip, monkeypatch, gep, n, n_vec):
+    """Device arrays that already have the internal layout (order a multiple of 128, ld = order, 256-byte aligned) ARE
+    the work arrays of ek_hip_solve_device (ek_solve.hip, EK_HIP_ALIAS).  The same call with copies forced
+    (EK_HIP_ALIAS=0), with padded leading dimensions (ld = order + 8) and with arrays that start 16 bytes off the
+    alignment must give the same eigenvalues, eigenvectors and in-place lower triangles of A and B bit for bit, and must
+    not write outside the n x n (n x n_vec) windows."""
+    lib = hip.load_library()
+    assert lib.ek_hip_init(0) == 0
+    prob = 1 if gep else 0
+
+    def run(pad, shift, alias):
+        monkeypatch.setenv("EK_HIP_ALIAS", "1" if alias else "0")
+        ld = n + pad
+        with _Dev(lib) as dev:
+            nb = ld * n * 8 + 256
+            bufs = {k: dev.alloc(nb) for k in (("A", "B", "Z") if gep else ("A", "Z"))}
+            dw = dev.alloc(n * 8)
+            host = {}
+            for k, p in bufs.items():
+                h = np.asfortranarray(np.full((ld, n), 9.75))
+                if k != "Z":
+                    src = dev.alloc(n * n * 8)
+                    assert lib.ek_hip_synth_matrix_device(n, 1 if k == "A" else 2, src, n) == 0
+                    h[:n, :] = _d2h(lib, src, (n, n))
+                flat = np.full(nb // 8, 4.5)
+                flat[shift // 8: shift // 8 + ld * n] = h.reshape(-1, order="F")
+                assert lib.ek_hip_memcpy_h2d(p, flat.ctypes.data, flat.nbytes) == 0
+                host[k] = flat
+            ptr = {k: ctypes.c_void_p(p.value + shift) for k, p in bufs.items()}
+            st = np.zeros(8)
+            info = lib.ek_hip_solve_device(prob, n, n_vec, ptr["A"], ld, ptr.get("B"), ld, dw, ptr["Z"], ld,
+                                           st.ctypes.data_as(_dp), 8)
+            assert info == 0
+            out = {}
+            for k, p in bufs.items():
+                flat = np.zeros(nb // 8)
+                assert lib.ek_hip_memcpy_d2h(flat.ctypes.data, p, flat.nbytes) == 0
+                body = flat[shift // 8: shift // 8 + ld * n].reshape((ld, n), order="F")
+                assert (flat[:shift // 8] == 4.5).all() and (flat[shift // 8 + ld * n:] == 4.5).all(), k
+                assert (body[n:] == 9.75).all(), k                     # padding rows
+                if k == "Z":
+                    assert (body[:n, n_vec:] == 9.75).all()            # columns nobody asked for
+                out[k] = body[:n].copy()
+            w = np.zeros(n)
+            assert lib.ek_hip_memcpy_d2h(w.ctypes.data, dw, n * 8) == 0
+            return w, out
+
+    w0, o0 = run(0, 0, True)          # in place
+    for pad, shift, alias in ((0, 0, False), (8, 0, True), (0, 16, True)):
+        w1, o1 = run(pad, shift, alias)
+        assert np.array_equal(w0[:n_vec], w1[:n_vec]), (pad, shift, alias)
+        assert np.array_equal(o0["Z"][:, :n_vec], o1["Z"][:, :n_vec]), (pad, shift, alias)
+        assert np.array_equal(np.tril(o0["A"]), np.tril(o1["A"])), (pad, shift, alias)
+        if gep:
+            assert np.array_equal(np.tril(o0["B"]), np.tril(o1["B"])), (pad, shift, alias)
