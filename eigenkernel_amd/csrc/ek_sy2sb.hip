@@ -968,6 +968,27 @@ __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
   store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
 }
 
+// How many ways the K range of the SYMM is cut.  Rounds 2 - 4 took "as many splits as fill the chip" (ceil(512 / T) for T
+// block rows: two workgroups fit a CU); but the T x nsplit workgroups of a launch all walk the same number of tiles, so a
+// launch of 600 of them ran two rounds of which the second was a sixth full (tools/tail_quant.py put 32 of the kernel's
+// 76 ms per solve at N = 16384 into such tails).  Measured per launch for every cut from 1 to 16 (tools/symm_split_table.sh,
+// one solve each; kernel time summed over the 255 panels, + the partials yred_kernel then reads): at most 4 splits 83.8 ms,
+// 8: 69.5, 12: 65.0, 16: 62.9 (+ 1.9 ms in yred_kernel); the old rule 76.7; the best cut per T picked from the table 61.9.
+// The finer the cut, the better the late workgroups fill the gaps the early ones leave -- so: as fine as the buffer of
+// partial sums allows (maxsplit).  EK_SY2SB_NSPLIT=k: at most k splits; -1: the old rule.
+static void symm_split(int T, int maxsplit, int *nsplit_out, int *tps_out) {
+  static int env = -2;
+  if (env == -2) { const char *e = getenv("EK_SY2SB_NSPLIT"); env = e ? atoi(e) : 0; }
+  if (T < 1) T = 1;
+  int nsplit = maxsplit;
+  if (env > 0 && env < nsplit) nsplit = env;
+  if (env < 0) nsplit = (T >= 256) ? 2 : ceil_div(512, T);
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  if (nsplit > T) nsplit = T;
+  const int tps = ceil_div(T, nsplit);
+  *nsplit_out = ceil_div(T, tps); *tps_out = tps;
+}
+
 // Team form: Y = the sum of the partials symm_lower_kernel<true> wrote for this block row, in a fixed order (the direct
 // chunks that reach it, then -- for a block row with owned rows -- the transposed chunks), Gp as above
 struct YredDistArgs {
@@ -1298,11 +1319,8 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     double *A22 = A + (size_t)r0 + (size_t)r0 * lda;
     const double *V = Vimg + (size_t)SB * ldi;
     const int T = ceil_div(m, 128);
-    int nsplit = (T >= 256) ? 2 : ceil_div(512, T);
-    if (nsplit > L.maxsplit) nsplit = L.maxsplit;
-    if (nsplit > T) nsplit = T;
-    const int tps = ceil_div(T, nsplit);
-    nsplit = ceil_div(T, tps);
+    int nsplit, tps;
+    symm_split(T, L.maxsplit, &nsplit, &tps);
     SymmArgs sy{m, A22, lda, V, ldi, Ypart, L.mpad, (long long)L.mpad * SB, T, tps, 1, 0, 0};
     const bool timed = kprof_enabled() && (p % 8 == 0);          // a uniform sample of the panels
     if (timed) kprof_begin(s, kProfSymm);
