@@ -174,28 +174,29 @@ def host_path_step(lib, solver, problem, n, n_vec):
         #                  page faults inside the timed call, 0.1 - 0.25 s depending on the box)
         if lib.ek_hip_malloc(ctypes.byref(tmp), n * n * 8) != 0:
             return {"error": "ek_hip_malloc"}
-        for seed, M in ((1, A), (2, B)):
-            if M is not None:
-                if lib.ek_hip_synth_matrix_device(n, seed, tmp, n) != 0 or lib.ek_hip_memcpy_d2h(M.ctypes.data, tmp, n * n * 8) != 0:
-                    return {"error": "input generation"}
-        lib.ek_hip_free(tmp); tmp = ctypes.c_void_p()
         desc = dsc.descinit(n, n, 64, 64, 0, 0, 0, n)
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
         st = (ctypes.c_double * 8)()
-        # one small call first: the staging pipeline's pinned ring and worker threads are set up once per process
-        nw = 2048
-        if n > nw:
-            dw_ = dsc.descinit(nw, nw, 64, 64, 0, 0, 0, nw)
-            Aw = np.asfortranarray(A[:nw, :nw]); Bw = np.asfortranarray(B[:nw, :nw]) if problem == 1 else None
-            Zw = np.zeros((nw, nw), order="F"); ww = np.zeros(nw)
-            lib.ek_hip_solve(problem, nw, nw, Aw.ctypes.data_as(dp), dw_.ctypes.data_as(ip),
-                             Bw.ctypes.data_as(dp) if problem == 1 else None, dw_.ctypes.data_as(ip) if problem == 1 else None,
-                             ww.ctypes.data_as(dp), Zw.ctypes.data_as(dp), dw_.ctypes.data_as(ip), 1, 1, 0, 0, None, 0)
-        t0 = time.perf_counter()
-        info = lib.ek_hip_solve(problem, n, n_vec, A.ctypes.data_as(dp), desc.ctypes.data_as(ip),
-                                B.ctypes.data_as(dp) if problem == 1 else None, desc.ctypes.data_as(ip) if problem == 1 else None,
-                                w.ctypes.data_as(dp), Z.ctypes.data_as(dp), desc.ctypes.data_as(ip), 1, 1, 0, 0, st, 8)
-        sec = time.perf_counter() - t0
+        # Two calls at full size, inputs regenerated in front of each (the solve overwrites A and B): the first sets up
+        # what the library keeps between calls (device images of the caller's arrays, the pinned ring and the worker
+        # threads of the staging pipeline) and is reported as first_call_seconds; the second is the figure.  (Until round
+        # 4's last day the first call was a small one, order 2048: the device images then grew inside the timed call --
+        # 6 GiB of hipMalloc, 0.05 - 0.12 s depending on the box.)
+        secs = []
+        for _call in range(2):
+            for seed, M in ((1, A), (2, B)):
+                if M is not None:
+                    if lib.ek_hip_synth_matrix_device(n, seed, tmp, n) != 0 or lib.ek_hip_memcpy_d2h(M.ctypes.data, tmp, n * n * 8) != 0:
+                        return {"error": "input generation"}
+            t0 = time.perf_counter()
+            info = lib.ek_hip_solve(problem, n, n_vec, A.ctypes.data_as(dp), desc.ctypes.data_as(ip),
+                                    B.ctypes.data_as(dp) if problem == 1 else None, desc.ctypes.data_as(ip) if problem == 1 else None,
+                                    w.ctypes.data_as(dp), Z.ctypes.data_as(dp), desc.ctypes.data_as(ip), 1, 1, 0, 0, st, 8)
+            secs.append(time.perf_counter() - t0)
+            if info != 0:
+                break
+        sec = secs[-1]
+        lib.ek_hip_free(tmp); tmp = ctypes.c_void_p()
         if info != 0:
             return {"error": "ek_hip_solve info=%d" % info}
         ps = (ctypes.c_double * 12)()
@@ -204,8 +205,10 @@ def host_path_step(lib, solver, problem, n, n_vec):
                 "bytes_out": ps[3], "out_busy_seconds": ps[5], "main_thread_waited_for_inputs_seconds": ps[6],
                 "main_thread_waited_for_the_drain_seconds": ps[7], "workers_per_direction": int(ps[8]),
                 "pinned_ring_directions": int(ps[9]), "pipeline_seconds": ps[10], "stage_seconds_sum": sum(st[q] for q in range(7))}
-        return {"value": n_vec / sec, "unit": "eigenpairs/s", "seconds": sec, "host_device_copies_seconds": st[7], "pipeline": pipe,
-                "note": "one ek_hip_solve call on pageable host arrays, all mapped before the call (A, B in; Z, A, B, w out)"}
+        return {"value": n_vec / sec, "unit": "eigenpairs/s", "seconds": sec, "first_call_seconds": secs[0],
+                "host_device_copies_seconds": st[7], "pipeline": pipe,
+                "note": "the second of two ek_hip_solve calls on pageable host arrays, all mapped before the calls (A, B in; "
+                        "Z, A, B, w out); the first one allocates what the library keeps between calls"}
     except Exception as exc:      # an optional extra never takes the line down
         return {"error": repr(exc)}
     finally:
