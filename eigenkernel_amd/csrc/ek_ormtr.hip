@@ -192,18 +192,23 @@ void ormtr_apply(hipStream_t s, int n, int ncols, const double *V, int ldv, cons
     const int row0 = c0, m = n - row0;
     const double *Vb = V + (size_t)row0 + (size_t)c0 * ldv;
     double *Zb = Z + row0;
-    const int kc = round_up(ceil_div(m, Smax), 64);      // slices start on even rows (16-byte operand loads)
+    // slices start on even rows (16-byte operand loads).  Equal slices where m allows it (every block of an order that
+    // is a multiple of 512): ONE launch of S x tiles workgroups; with a shorter last slice that slice is a launch of
+    // its own, a few dozen workgroups that last as long as the whole batch before them did (until round 4 the slice
+    // length was rounded up to 64, which left such a launch behind every other block at N = 16384).
+    const int kc = round_up(ceil_div(m, Smax), 2);
     const int S = (Smax > 1 && m >= 4096) ? ceil_div(m, kc) : 1;
     if (S > 1) {
       const size_t cnt = (size_t)KB * ncols;
+      const int klast = m - (S - 1) * kc;
       GemmDesc g{};
       g.M = kb; g.N = ncols; g.K = kc; g.transA = true; g.transB = false; g.alpha = 1.0; g.beta = 0.0;
       g.A = Vb; g.lda = ldv; g.strideA = kc; g.B = Zb; g.ldb = ldz; g.strideB = kc;
-      g.C = Wp; g.ldc = KB; g.strideC = (long long)cnt; g.batch = S - 1;
+      g.C = Wp; g.ldc = KB; g.strideC = (long long)cnt; g.batch = (klast == kc) ? S : S - 1;
       gemm(s, g);
-      const int klast = m - (S - 1) * kc;
-      gemm(s, true, false, kb, ncols, klast, 1.0, Vb + (size_t)(S - 1) * kc, ldv, Zb + (size_t)(S - 1) * kc, ldz, 0.0,
-           Wp + (size_t)(S - 1) * cnt, KB);
+      if (klast != kc)
+        gemm(s, true, false, kb, ncols, klast, 1.0, Vb + (size_t)(S - 1) * kc, ldv, Zb + (size_t)(S - 1) * kc, ldz, 0.0,
+             Wp + (size_t)(S - 1) * cnt, KB);
       hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, cnt, S, Wp, W1);
     } else
     gemm(s, true, false, kb, ncols, m, 1.0, Vb, ldv, Zb, ldz, 0.0, W1, KB);
