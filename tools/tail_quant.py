@@ -22,6 +22,7 @@ if diag:
         else: groups[-1].append(i)
     start = groups[-1][0]
 acc = defaultdict(lambda: [0, 0.0, 0.0])
+top = []
 for r in rows[start:]:
     name = r["Kernel_Name"]
     if "gemm_kernel" not in name and "gemm_small" not in name and "symm_lower" not in name: continue
@@ -29,8 +30,11 @@ for r in rows[start:]:
     wx = int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
     wgs = gx // max(wx, 1)
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    slots = 512
+    # slots: workgroups the chip holds at once (hipcc -Rpass-analysis=kernel-resource-usage: two workgroups per CU for the
+    # 128 x 128 tilings and the SYMM, three for the 64 x 64 tiling; the trace's register columns are in other units)
+    slots = 768 if "gemm_small" in name else 512
     loss = dur * (1.0 - wgs / (slots * math.ceil(wgs / slots))) if wgs > 0 else 0.0
+    if wgs > slots: top.append((loss, dur, wgs, slots, name))
     key = name.replace("ek::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44]
     a = acc[key]; a[0] += 1; a[1] += dur; a[2] += loss
 print("%-46s %6s %10s %10s" % ("kernel", "calls", "ms", "tail ms"))
@@ -38,3 +42,6 @@ tot = 0.0
 for k, (c, d, l) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
     print("%-46s %6d %10.2f %10.2f" % (k, c, d, l)); tot += l
 print("total tail estimate: %.2f ms" % tot)
+print("largest single tails among launches of more than one round (ms lost, ms, workgroups, slots):")
+for loss, dur, wgs, slots, name in sorted(top, reverse=True)[:25]:
+    print("  %6.3f %8.3f %7d %5d  %s" % (loss, dur, wgs, slots, name.replace("ek::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:50]))
