@@ -9,7 +9,13 @@ from collections import defaultdict
 def short(n):
     return n.replace("ek::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
 
-rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(sys.argv[1])))
+def wgs_of(r):
+    g = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+    w = int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
+    return g // max(w, 1)
+
+raw = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), wgs_of(r)) for r in csv.DictReader(open(sys.argv[1])))
+rows = [(s, e, n) for s, e, n, _ in raw]
 # the last solve: from the last launch of maxabs (the solve's first kernel) on, if present; else the whole trace
 starts = [i for i, r in enumerate(rows) if "maxabs" in r[2] or "synth" in r[2]]
 first = 0
@@ -37,3 +43,35 @@ print("span %.1f ms, busy %.1f ms, idle inside (gaps < 20 ms) %.2f ms in %d gaps
 print("%-42s %-42s %6s %9s %8s" % ("after", "before", "gaps", "total us", "mean us"))
 for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:30]:
     print("%-42s %-42s %6d %9.0f %8.1f" % (a, b, c, t, t / c))
+
+# time without a chip-filling kernel: the span minus the union of the launches of >= 256 workgroups; what runs then
+big = [(s, e) for s, e, n, w in raw[first:] if w >= 256]
+big.sort()
+cover, ce, cs = 0, None, None
+merged = []
+for s, e in big:
+    if ce is None or s > ce:
+        if ce is not None: merged.append((cs, ce))
+        cs, ce = s, e
+    elif e > ce: ce = e
+if ce is not None: merged.append((cs, ce))
+cover = sum(e - s for s, e in merged)
+print("\nwithout a launch of >= 256 workgroups in flight: %.1f ms of the span; small launches by their time outside the big ones:" % ((span - cover) / 1e6))
+import bisect
+ms = [m[0] for m in merged]
+out = defaultdict(lambda: [0, 0.0])
+for s, e, n, w in raw[first:]:
+    if w >= 256: continue
+    # part of [s, e) not covered by merged
+    t, i = s, max(bisect.bisect_right(ms, s) - 1, 0)
+    un = 0
+    while t < e and i < len(merged):
+        a, b = merged[i]
+        if b <= t: i += 1; continue
+        if a >= e: break
+        if a > t: un += a - t
+        t = max(t, b); i += 1
+    if t < e: un += e - t
+    if un > 0: o = out[n]; o[0] += 1; o[1] += un / 1e3
+for n, (c, t) in sorted(out.items(), key=lambda kv: -kv[1][1])[:16]:
+    print("  %-42s %6d launches %9.0f us" % (n, c, t))
