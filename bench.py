@@ -36,7 +36,9 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                       (divide & conquer after deflation, counted on the device; both back-transformations);
   "value_incl_copies": the same solve through ek_hip_solve on HOST arrays (PCIe staging of A, B in
                       and Z, A, B, w out included -- SURVEY.md 8(d)'s t_solve; the copies overlap the stages),
-                      one step, outside the timed region;
+                      the second of two calls, outside the timed region, in a child process that loads the library
+                      alone (the system's HIP runtime, as a host of the reference's shape links it) with the same
+                      measurement inside this process (PyTorch's bundled HIP runtime) beside it;
   "other_configs"   : the other BASELINE configurations at full size on this GPU (c2 x10, c5 x5, c4 x2 steps:
                       ms_per_step, parity, the dominant kernel's fraction), after the headline region;
   "cpu_baseline"    : the reference's ScaLAPACK call sequence on the host cores on a bounded sample
@@ -214,6 +216,27 @@ def host_path_step(lib, solver, problem, n, n_vec):
     finally:
         if tmp:
             lib.ek_hip_free(tmp)
+
+
+def host_path_child(problem, n, n_vec, timeout=300.0):
+    """host_path_step in a child process that loads the library alone.  This process has PyTorch in it, and PyTorch ships
+    its own HIP runtime (torch/lib/libamdhip64.so, libhsa-runtime64.so) which, loaded first, serves the library's calls
+    too: its copies into pageable host memory run at 0.8 GB/s per thread beside the kernels where the system's runtime
+    (/opt/rocm: what a host of the reference's shape links -- host/eigenkernel_hip_app does) moves 10 GB/s per thread.
+    The child is the reference-shaped host; the figure measured in this process is reported beside it."""
+    import subprocess
+    code = ("import json, sys; sys.path.insert(0, %r); import bench; from eigenkernel_amd import solver; "
+            "lib = solver.load_library(); assert lib.ek_hip_init(0) == 0; "
+            "print('HOSTPATH ' + json.dumps(bench.host_path_step(lib, solver, %d, %d, %d)))"
+            % (os.path.dirname(os.path.abspath(__file__)), problem, n, n_vec))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout)
+    except Exception as exc:
+        return {"error": repr(exc)}
+    for line in r.stdout.splitlines():
+        if line.startswith("HOSTPATH "):
+            return json.loads(line[len("HOSTPATH "):])
+    return {"error": "child rc=%s: %s" % (r.returncode, (r.stderr or "")[-300:])}
 
 
 def run_other_config(lib, torch, dev, name, steps, warmup):
@@ -812,7 +835,18 @@ def main():
         _pending = out      # the headline exists from here on: none of the extras below can take it down
         if world == 1 and not columns and not args.no_host_path:
             try:
-                out["value_incl_copies"] = host_path_step(lib, solver, problem, n, n_vec)
+                here = host_path_step(lib, solver, problem, n, n_vec)
+                child = host_path_child(problem, n, n_vec)
+                if "error" in child:           # the figure of this process stands alone
+                    here["child_process_error"] = child["error"]
+                    here["process"] = "this process (PyTorch's bundled HIP runtime)"
+                    out["value_incl_copies"] = here
+                else:
+                    child["process"] = ("a child process that loads the library alone: the system's HIP runtime, as a host of "
+                                        "the reference's shape links it")
+                    child["in_this_process_with_pytorchs_bundled_hip_runtime"] = {
+                        k: here.get(k) for k in ("value", "seconds", "first_call_seconds", "host_device_copies_seconds", "error") if k in here}
+                    out["value_incl_copies"] = child
             except Exception as exc:
                 out["value_incl_copies"] = {"error": repr(exc)}
         if world == 1 and not columns and not args.no_other_configs and (n, args.problem, n_vec) == (16384, "gep", 16384):

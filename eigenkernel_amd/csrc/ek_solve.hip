@@ -222,6 +222,10 @@ struct HostPipe {
         fprintf(stderr, "[pipe] main thread waited %.4f s (%s) at t = %.4f\n", r.t1 - r.t0, r.kind == 2 ? "input" : "drain", r.t0);
       }
     }
+    if (getenv("EK_HIP_PIPE_TRACE") && atoi(getenv("EK_HIP_PIPE_TRACE")) >= 2)       // every job
+      for (const auto &r : trace_log)
+        if (r.kind < 2) fprintf(stderr, "[pipe] job %s %8.1f MB  t = %.4f .. %.4f  (%.1f GB/s)\n", r.kind ? "out" : "in ", r.bytes / 1e6, r.t0, r.t1,
+                                r.bytes / 1e9 / (r.t1 - r.t0 > 1e-9 ? r.t1 - r.t0 : 1e-9));
     for (int k = 0; k < 2; ++k)
       if (bytes[k] > 0)
         fprintf(stderr, "[pipe] %s: %.2f GB between t = %.4f and %.4f s (%.1f GB/s over the span), %d threads busy %.3f s in all (%.1f GB/s per busy thread), %s\n",
