@@ -205,7 +205,7 @@ def host_path_step(lib, solver, problem, n, n_vec):
         lib.ek_hip_debug_last_pipe_stats(ps, 12)
         pipe = {"bytes_in": ps[0], "in_span_seconds": ps[1], "in_gb_per_s": ps[0] / ps[1] / 1e9 if ps[1] > 0 else None,
                 "bytes_out": ps[3], "out_busy_seconds": ps[5], "main_thread_waited_for_inputs_seconds": ps[6],
-                "main_thread_waited_for_the_drain_seconds": ps[7], "workers_per_direction": int(ps[8]),
+                "main_thread_waited_for_the_drain_seconds": ps[7], "workers_in": int(ps[8]) // 100, "workers_out": int(ps[8]) % 100,
                 "pinned_ring_directions": int(ps[9]), "pipeline_seconds": ps[10], "stage_seconds_sum": sum(st[q] for q in range(7))}
         return {"value": n_vec / sec, "unit": "eigenpairs/s", "seconds": sec, "first_call_seconds": secs[0],
                 "host_device_copies_seconds": st[7], "pipeline": pipe,

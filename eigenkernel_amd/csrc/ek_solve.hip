@@ -163,6 +163,7 @@ struct HostPipe {
   struct Job { double *dev; int ldd; double *host; int ldh; int m, n; hipEvent_t after; int tag; bool to_host; };
   static constexpr int kMaxThreads = 8;
   int kThreads = 2;                          // per direction (EK_HIP_PIPE_THREADS; default by the cores the process has)
+  int kOutThreads = 2;                       // of them on the way out (see start())
   // which directions go through the pinned ring (EK_HIP_PIPE_PINNED = 0 none: round 3's form, 1 in, 2 out, 3 both).
   // Default: the way in only.  Measured on one pool box (profiles/r04_host_path.txt): in, ring 53 GB/s against 56 for
   // the pageable arrays handed to the runtime there (a box whose runtime stages pageable memory at 27 - 36 GB/s, as
@@ -206,7 +207,7 @@ struct HostPipe {
     for (int k = 0; k < 2; ++k) {
       g_pipe_stats[3 * k] = bytes[k]; g_pipe_stats[3 * k + 1] = bytes[k] > 0 ? last[k] - first[k] : 0.0; g_pipe_stats[3 * k + 2] = busy[k];
     }
-    g_pipe_stats[6] = win; g_pipe_stats[7] = wdrain; g_pipe_stats[8] = kThreads; g_pipe_stats[9] = pinned ? pinned_dirs : 0;
+    g_pipe_stats[6] = win; g_pipe_stats[7] = wdrain; g_pipe_stats[8] = 100.0 * kThreads + kOutThreads; g_pipe_stats[9] = pinned ? pinned_dirs : 0;
     g_pipe_stats[10] = now(); g_pipe_stats[11] = bytes[0] > 0 ? first[0] : 0.0;
   }
   void report() {
@@ -229,7 +230,7 @@ struct HostPipe {
     for (int k = 0; k < 2; ++k)
       if (bytes[k] > 0)
         fprintf(stderr, "[pipe] %s: %.2f GB between t = %.4f and %.4f s (%.1f GB/s over the span), %d threads busy %.3f s in all (%.1f GB/s per busy thread), %s\n",
-                k ? "out" : "in", bytes[k] / 1e9, first[k], last[k], bytes[k] / 1e9 / (last[k] - first[k]), kThreads, busy[k],
+                k ? "out" : "in", bytes[k] / 1e9, first[k], last[k], bytes[k] / 1e9 / (last[k] - first[k]), k ? kOutThreads : kThreads, busy[k],
                 bytes[k] / 1e9 / busy[k], pinned ? "pinned ring" : "pageable");
   }
 
@@ -237,9 +238,13 @@ struct HostPipe {
     device = dev;
     t_origin = std::chrono::steady_clock::now();
     { static int tr = -1; if (tr < 0) { const char *e = getenv("EK_HIP_PIPE_TRACE"); tr = (e && atoi(e) != 0) ? 1 : 0; } trace = tr != 0; }
-    static int env_threads = -2, env_pinned = -1;
+    static int env_threads = -2;
+    int env_pinned = -1;                      // (read per call: the tests switch it)
     if (env_threads == -2) { const char *e = getenv("EK_HIP_PIPE_THREADS"); env_threads = e ? atoi(e) : -1; }
-    if (env_pinned < 0) { const char *e = getenv("EK_HIP_PIPE_PINNED"); env_pinned = e ? (atoi(e) & 3) : 1; }
+    // (default 0 since the end of round 4: on every box met this round the runtime moves pageable memory at link rate,
+    // 57 GB/s in, and the ring's way in made 37 - 51 under the system's runtime, 29 under PyTorch's: N = 16384 GEP 0.876 s
+    // against 0.89 - 0.90 under either; profiles/r04_host_path_runtimes.txt)
+    if (env_pinned < 0) { const char *e = getenv("EK_HIP_PIPE_PINNED"); env_pinned = e ? (atoi(e) & 3) : 0; }
     pinned_dirs = env_pinned;
     { static int lo = -1; if (lo < 0) { const char *e = getenv("EK_HIP_PIPE_LOWER"); lo = (e && atoi(e) == 0) ? 0 : 1; } lower_only = lo != 0; }
     const int cores = usable_cores();
@@ -249,7 +254,15 @@ struct HostPipe {
     { const int rc = g_pipe_streams.ensure(2 * kThreads); if (rc) return rc; }
     for (int i = 0; i < 2 * kThreads; ++i) cs[i] = g_pipe_streams.cs[i];
     for (int i = 0; i < 2; ++i) dma[i] = g_pipe_streams.dma[i];
-    for (int i = 0; i < 2 * kThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i], i); });
+    // The way out hands pageable memory to the runtime (unless the ring serves it): two threads saturate the link (30 GB/s
+    // each), and MORE than two collapse under the HIP runtime PyTorch bundles (2.10: 1.7 GB/s per thread with three, 0.9
+    // with six, beside running kernels; the system's runtime does 10 - 20 with any number) -- which is the runtime that
+    // serves a process that imported torch first.  EK_HIP_PIPE_THREADS_OUT overrides.
+    static int env_out = -2;
+    if (env_out == -2) { const char *e = getenv("EK_HIP_PIPE_THREADS_OUT"); env_out = e ? atoi(e) : -1; }
+    kOutThreads = (pinned && (pinned_dirs & 2)) ? kThreads : (kThreads < 2 ? kThreads : 2);
+    if (env_out >= 1 && env_out <= kThreads) kOutThreads = env_out;
+    for (int i = 0; i < kThreads + kOutThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i], i); });
     return 0;
   }
   // one job through the worker's two pinned slots (m rows of 8 bytes, n columns; a chunk = as many columns as fit a slot)

@@ -657,8 +657,9 @@ def test_no_eigenvectors_requested(hip, oracle):
             assert not ep.Vectors.any()
 
 
+@pytest.mark.parametrize("pinned", ["0", "3"])
 @pytest.mark.parametrize("solver,n,n_vec", [("general_hip", 2304, 2304), ("hip", 2100, 2100), ("general_hip_select", 2304, 300)])
-def test_staging_pipeline_of_the_host_path_changes_no_bit(hip, oracle, monkeypatch, solver, n, n_vec):
+def test_staging_pipeline_of_the_host_path_changes_no_bit(hip, oracle, monkeypatch, solver, n, n_vec, pinned):
     """From order 2048 on ek_hip_solve overlaps its PCIe copies with the stages (B in first, A behind the Cholesky
     factorisation; L, the reflectors and Z out as they become final, Z in column slabs): eigenvalues, eigenvectors and
     the in-place results must be the bits of the serial staging (EK_HIP_PIPE_MIN=0), and pass the acceptance bounds."""
@@ -668,6 +669,7 @@ def test_staging_pipeline_of_the_host_path_changes_no_bit(hip, oracle, monkeypat
     monkeypatch.setenv("EK_HIP_PIPE_MIN", "0")
     ep0, _ = hip.eigen_solver(solver, A, Bm, n_vec=n_vec)
     monkeypatch.setenv("EK_HIP_PIPE_MIN", "1024")
+    monkeypatch.setenv("EK_HIP_PIPE_PINNED", pinned)      # pageable arrays handed to the runtime / the ring of pinned buffers both ways
     ep1, _ = hip.eigen_solver(solver, A, Bm, n_vec=n_vec)
     assert np.array_equal(ep0.values, ep1.values)
     assert np.array_equal(ep0.Vectors[:, :n_vec], ep1.Vectors[:, :n_vec])
