@@ -968,6 +968,45 @@ __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
   store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
 }
 
+// The same with a workgroup per 64 rows AND 16 columns (grid (nch, 4)): a chunk's sixteen partial sums are 0.5 MB, which one
+// workgroup per chunk took ~20 us to read while three quarters of the chip had nothing to do below m = 16384 (53
+// workgroups at m = 3400).  Each element's sum and each entry of the Gram partial are formed as above, bit for bit.
+__global__ __launch_bounds__(256) void yred_q_kernel(YredArgs p) {
+  __shared__ double sYq[SB * 17], sV[IMG];
+  const int t = threadIdx.x, r = t & 63, cg = t >> 6, q = blockIdx.y;
+  const int lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int row0 = blockIdx.x * CH;
+  if (row0 >= p.m) return;
+  const int row = row0 + r;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int lc = 4 * cg + c, col = 16 * q + lc;
+    double y = 0.0;
+    if (row < p.m) {
+      const double *yp = p.Ypart + (size_t)row + (size_t)col * p.ldy;
+      double ys[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) ys[s] = (s < p.nsplit) ? yp[(size_t)s * p.sY] : 0.0;
+      y = ((ys[0] + ys[1]) + (ys[2] + ys[3])) + ((ys[4] + ys[5]) + (ys[6] + ys[7]));
+      if (p.nsplit > 8) y += ((ys[8] + ys[9]) + (ys[10] + ys[11])) + ((ys[12] + ys[13]) + (ys[14] + ys[15]));
+      p.Y[(size_t)row + (size_t)col * (p.ldyo ? p.ldyo : p.ldy)] = y;
+    }
+    sYq[r * 17 + lc] = y;
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int col = 16 * cg + c;
+    sV[r * LD + col] = (row < p.m) ? p.V[(size_t)row + (size_t)col * p.ldv] : 0.0;
+  }
+  __syncthreads();
+  double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < SB; kk += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(kk + l4) * LD + 16 * wave + l15], sYq[(kk + l4) * 17 + l15], acc, 0, 0, 0);
+  double *G = p.Gpart + (size_t)blockIdx.x * SB * SB;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) G[(16 * q + l15) + SB * (16 * wave + l4 + 4 * rr)] = acc[rr];
+}
+
 // How many ways the K range of the SYMM is cut.  Rounds 2 - 4 took "as many splits as fill the chip" (ceil(512 / T) for T
 // block rows: two workgroups fit a CU); but the T x nsplit workgroups of a launch all walk the same number of tiles, so a
 // launch of 600 of them ran two rounds of which the second was a sixth full (tools/tail_quant.py put 32 of the kernel's
@@ -1327,7 +1366,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     hipLaunchKernelGGL(symm_lower_kernel<false>, dim3(T, nsplit), dim3(256), 0, s, sy);
     if (timed) kprof_end(s, kProfSymm);
     YredArgs ya{m, nsplit, Ypart, L.mpad, (long long)L.mpad * SB, Y, V, ldi, Gpart};
-    hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, ya);
+    hipLaunchKernelGGL(yred_q_kernel, dim3(nch, 4), dim3(256), 0, s, ya);      // (C3: stage 0.2297 -> 0.2278 s, C2 39.05 -> 38.55 ms; same bits)
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s, nch, Gpart, Gred);
     WArgs wa{m, Y, L.mpad, V, ldi, Gred, Tm[cur], Vimg, ldi};
     hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
