@@ -104,10 +104,11 @@ void extract_local(int m, int n, const double *M_full, int ldf, const int *desc,
 //        tridiagonalisation, Z in column slabs as the last stage finishes them, w last.
 // The caller's arrays are pageable.  Handed to the runtime as they are, a copy is staged through the runtime's own
 // bounce buffers by the calling thread at a rate that depends on the box's host side (27 - 36 GB/s with two threads per
-// direction on one pool box, a third of that exposed time on another: round 3).  Round 4: the library owns a ring of
-// PINNED bounce buffers (allocated once per process), a worker packs a chunk of columns into its slot with the CPU
-// (memcpy) and hands the slot to the DMA engine (and the reverse on the way out), two slots per worker so that its
-// memcpy and its DMA overlap; the number of workers per direction follows the cores the process may run on.
+// direction on one pool box, a third of that exposed time on another: round 3).  Round 4: the library can own a ring of
+// PINNED bounce buffers (allocated once per process, on first use), a worker packs a chunk of columns into its slot with
+// the CPU (memcpy) and hands the slot to the DMA engine (and the reverse on the way out), two slots per worker so that its
+// memcpy and its DMA overlap; the number of workers on the way in follows the cores the process may run on, the way out
+// has two (HostPipe::start says why).  Off by default (HostPipe::pinned_dirs).
 struct PinRing {
   static constexpr size_t kSlot = (size_t)16 << 20;      // bytes per slot
   static constexpr int kMaxWorkers = 16;
@@ -164,13 +165,13 @@ struct HostPipe {
   static constexpr int kMaxThreads = 8;
   int kThreads = 2;                          // per direction (EK_HIP_PIPE_THREADS; default by the cores the process has)
   int kOutThreads = 2;                       // of them on the way out (see start())
-  // which directions go through the pinned ring (EK_HIP_PIPE_PINNED = 0 none: round 3's form, 1 in, 2 out, 3 both).
-  // Default: the way in only.  Measured on one pool box (profiles/r04_host_path.txt): in, ring 53 GB/s against 56 for
-  // the pageable arrays handed to the runtime there (a box whose runtime stages pageable memory at 27 - 36 GB/s, as
-  // rounds 2 and 3 met, is where the ring pays); out, the transfers into the ring's slots crawl at ~1 GB/s per worker
-  // while the GPU is busy with the stages (the same transfers into pageable memory: 30), so the way out stays as it was.
+  // which directions go through the pinned ring (EK_HIP_PIPE_PINNED = 0 none, 1 in, 2 out, 3 both).  Default: none.
+  // Measured (profiles/r04_host_path.txt, r04_host_path_runtimes.txt): the runtime moves the caller's pageable arrays at
+  // link rate on every box round 4 met (57 GB/s in), the ring's way in made 37 - 51 (29 under the HIP runtime PyTorch
+  // bundles), and transfers into the ring's slots on the way out crawl at ~1 GB/s per worker beside the stages.  The ring
+  // is for a box whose runtime stages pageable memory slowly (27 - 36 GB/s: rounds 2 - 3 met one).
   bool pinned = false;
-  int pinned_dirs = 1;
+  int pinned_dirs = 0;
   bool lower_only = true;                    // EK_HIP_PIPE_LOWER=0: whole matrices both ways, as round 3
   std::mutex mu;
   std::condition_variable cv;
