@@ -1354,7 +1354,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     double *Vimg = img[cur];
     if (!waited) (void)hipStreamWaitEvent(s, evB[cur], 0);
     const int nch = ceil_div(m, CH);
-    // Y = A22 V, split over K so that the launch fills the chip
+    // Y = A22 V, cut over K as finely as the buffer of partial sums allows (symm_split)
     double *A22 = A + (size_t)r0 + (size_t)r0 * lda;
     const double *V = Vimg + (size_t)SB * ldi;
     const int T = ceil_div(m, 128);
