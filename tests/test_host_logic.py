@@ -502,3 +502,23 @@ def test_workspace_of_a_team_member_shrinks_with_the_team():
     # a *_select arm on one GPU keeps the D&C compact too (C5: 1024 of 16384 columns)
     c5, _ = solver.workspace_bytes(1, 16384, 1024, 1)
     assert c5 <= 5.0 * 8 * 16384 * 16384
+
+
+def test_bench_host_path_child_reports_instead_of_raising():
+    """bench.py measures value_incl_copies in a child process that loads the library alone (the system's HIP runtime, not
+    the one PyTorch bundles).  Without a GPU the child cannot initialise the library: the parent must get an error record,
+    never an exception -- an optional extra does not take the bench line down."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ek_bench_child", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    out = bench.host_path_child(1, 256, 256, timeout=120.0)
+    assert isinstance(out, dict)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        assert "error" in out or out.get("seconds", 0) > 0
+    else:
+        assert "error" in out and "child rc=" in out["error"]
