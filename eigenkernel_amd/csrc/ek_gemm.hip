@@ -123,14 +123,33 @@ __device__ __forceinline__ double frag(const double *s, int x, int k) {
   return KCONTIG ? s[x * KC_LD + k] : s[k * MC_LD + x];
 }
 
+// Workgroup -> tile.  Plain: consecutive workgroups walk down M first (they share the B slab in L2); lower_only == 1: the
+// same grid, workgroups of tiles above the diagonal leave at once; lower_only == 2 (square tilings, one product, set by
+// gemm()): the grid holds the tiles on and below the diagonal only, column by column -- a trailing update of 120 x 120
+// tiles no longer dispatches 7140 workgroups that have nothing to do.
+__device__ __forceinline__ bool tile_of(const GemmArgs &p, int tile, int &tm, int &tn) {
+  if (p.lower_only == 2) {
+    const long long T = p.tiles_m, c = tile;
+    int j = (int)(((double)(2 * T + 1) - sqrt((double)((2 * T + 1) * (2 * T + 1) - 8 * c))) * 0.5);
+    if (j < 0) j = 0;
+    if (j > p.tiles_n - 1) j = p.tiles_n - 1;
+    while (j + 1 < p.tiles_n && (long long)(j + 1) * T - (long long)(j + 1) * j / 2 <= c) ++j;
+    while (j > 0 && (long long)j * T - (long long)j * (j - 1) / 2 > c) --j;
+    tn = j; tm = j + (int)(c - ((long long)j * T - (long long)j * (j - 1) / 2));
+    return tm < p.tiles_m;
+  }
+  tm = tile % p.tiles_m; tn = tile / p.tiles_m;
+  return true;
+}
+
 template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) double smem[2 * TILE_DOUBLES];
   double *sA = smem, *sB = smem + TILE_DOUBLES;
 
   // tile index: consecutive workgroups walk down M first (they share the B slab in L2)
-  const int tile = blockIdx.x;
-  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  int tm, tn;
+  if (!tile_of(p, blockIdx.x, tm, tn)) return;
   const int m0 = tm * BM, n0 = tn * BN;
   if (p.lower_only && n0 > m0 + BM - 1) return;
   if (p.dims) {
@@ -291,8 +310,8 @@ template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(512, 4) void gemm_kernel_w8(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) double smem[2 * TILE_DOUBLES];
   double *sA = smem, *sB = smem + TILE_DOUBLES;
-  const int tile = blockIdx.x;
-  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  int tm, tn;
+  if (!tile_of(p, blockIdx.x, tm, tn)) return;
   const int m0 = tm * BM, n0 = tn * BN;
   if (p.lower_only && n0 > m0 + BM - 1) return;
   if (p.dims) {
@@ -451,8 +470,8 @@ template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) double smem[2 * STILE_DOUBLES];
   double *sA = smem, *sB = smem + STILE_DOUBLES;
-  const int tile = blockIdx.x;
-  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  int tm, tn;
+  if (!tile_of(p, blockIdx.x, tm, tn)) return;
   const int m0 = tm * SM, n0 = tn * SN;
   if (p.lower_only && n0 > m0 + SM - 1) return;
   if (p.dims) {
@@ -535,8 +554,8 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(512) void gemm_rankk_kernel(GemmArgs p) {
   extern __shared__ double rk_smem[];
   double *sA = rk_smem, *sB = rk_smem + RK * RK_LD;
-  const int tile = blockIdx.x;
-  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  int tm, tn;
+  if (!tile_of(p, blockIdx.x, tm, tn)) return;
   const int m0 = tm * BM, n0 = tn * BN;
   if (p.lower_only && n0 > m0 + BM - 1) return;
   if (p.dims) {
@@ -654,6 +673,11 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   // lower_only is defined on the 128x128 tiling (callers rely on whole diagonal tiles being
   // written), so the small-grid variant is used for plain products only
   const long long big_tiles = (long long)ceil_div(g.M, BM) * ceil_div(g.N, BN) * g.batch;
+  // lower-only products of one batch entry: a grid of the tiles on and below the diagonal only (EK_GEMM_LOWER_COMPACT=0:
+  // the full grid, whose upper workgroups leave at once)
+  static int compact_env = -1;
+  if (compact_env < 0) { const char *e = getenv("EK_GEMM_LOWER_COMPACT"); compact_env = e ? atoi(e) : 1; }
+  const bool compact = compact_env && g.lower_only && g.batch == 1 && !g.d_dims && !g.d_offs;
   // 16-byte operand fetch: every slab start must be 16-byte aligned -- even leading dimensions, aligned bases,
   // even batch strides, no per-batch offsets from device memory (EK_GEMM_VEC=0 turns the variants off)
   static int vec_env = -1;
@@ -663,6 +687,10 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   if ((big_tiles < 256 && !g.lower_only) || (g.lower_only && g.small_tiles)) {
     p.tiles_m = ceil_div(g.M, SM); p.tiles_n = ceil_div(g.N, SN);
     dim3 sgrid(p.tiles_m * p.tiles_n, g.batch), sblock(256);
+    if (compact && p.tiles_n <= p.tiles_m) {
+      p.lower_only = 2;
+      sgrid.x = (unsigned)((long long)p.tiles_n * p.tiles_m - (long long)p.tiles_n * (p.tiles_n - 1) / 2);
+    }
     static int svec = -1;
     if (svec < 0) { const char *e = getenv("EK_GEMM_SMALL_VEC"); svec = e ? atoi(e) : 1; }
     if (vec && svec) {
@@ -680,6 +708,10 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   }
   p.tiles_m = ceil_div(g.M, BM); p.tiles_n = ceil_div(g.N, BN);
   dim3 grid(p.tiles_m * p.tiles_n, g.batch), block(256);
+  if (compact && p.tiles_n <= p.tiles_m) {
+    p.lower_only = 2;
+    grid.x = (unsigned)((long long)p.tiles_n * p.tiles_m - (long long)p.tiles_n * (p.tiles_n - 1) / 2);
+  }
   // Rank-k updates (short K, C read-modify-write) run on the 8-wave variant: twice the resident
   // waves hide the operand and C latency that the 4-wave kernel exposes when there are only a few
   // k-steps per tile (measured: SYR2K of the tridiagonalisation -25 %); long-K products stay on
