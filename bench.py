@@ -10,7 +10,9 @@ timed region, because the solve overwrites A and B as the reference does).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--order 16384] [--problem gep|sep]
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run.  By default
+For N > 1 there is one rank per GPU: either the driver launches them with torch.distributed.run, or --
+when no RANK is in the environment -- `python bench.py --gpus N` starts them itself as fresh child
+processes (self_launch(): the parent makes no GPU call and relays the ranks' line and exit code).  By default
 (`--distribution auto`) the ranks first solve one problem each (replicas: no data-path collective;
 the safe measurement, kept in the line as "replicas"), then ONE problem on the 1 x N process grid
 with the library's RCCL communicator attached -- Cholesky factor, reduction and the dense -> band stage of
@@ -529,6 +531,44 @@ def promote_grid_mode(out, probe, world):
     out["headline_mode"] = mode
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks (one per GPU) with
+    torch.distributed.run as FRESH child processes -- this parent has made no GPU call and makes none,
+    and nothing is re-executed in place -- pass the ranks' output through and return their exit code.
+    Under an existing launcher (RANK in the environment) this function is not reached."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_ranks,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n_ranks, " ".join(cmd)))
+    sys.stderr.flush()
+    # stdout and stderr are inherited: rank 0's JSON line is this run's line.  cwd = the repo root: `python -m`
+    # puts the working directory first on sys.path, and a stray module there must not shadow the launcher's imports
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def dry_launch(rank, world):
+    """The launch path without a GPU: every rank joins a gloo group, the ranks are counted by an
+    all-reduce, rank 0 prints a line whose n_gpus is that count."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    one = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(one)
+    assert int(one) == world == dist.get_world_size()
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry launch (no measurement)", "value": None, "n_gpus": int(one),
+                          "dry_launch": True}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -583,13 +623,25 @@ def main():
                          "ranks on one device).  Exercises the whole N>1 control flow; the timings mean nothing")
     ap.add_argument("--grid-probe-timeout", type=float, default=240.0,
                     help="seconds after which a stuck grid probe is abandoned (the main line is still printed)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, join them in a gloo group, count them and print a line with n_gpus = the "
+                         "number of ranks that answered -- no GPU call anywhere (the CPU test of the self-launch)")
     args = ap.parse_args()
     if args.config:
         args.n, args.problem, args.n_vec = CONFIGS[args.config]
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process makes no GPU call (it has not even imported torch);
+        # it starts the N ranks as fresh children and leaves with their exit code
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks: reporting n_gpus = %d\n"
+                         % (args.gpus, world, world))
+    if args.dry_launch:
+        return dry_launch(rank, world)
     n, problem = args.n, (1 if args.problem == "gep" else 0)
     n_vec = args.n_vec if 0 < args.n_vec < n else n
 
@@ -597,6 +649,9 @@ def main():
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the product path has no CPU fallback")
     rehearse = args.rehearse_on_one_gpu
+    if world > 1 and not rehearse and torch.cuda.device_count() < world:
+        raise RuntimeError("bench.py: %d ranks but %d GPUs visible (one rank per GPU; --rehearse-on-one-gpu shares GPU 0 "
+                           "through the host communicator)" % (world, torch.cuda.device_count()))
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -687,3 +687,25 @@ def test_fortran_mpi_host_on_a_process_grid(tmp_path, nranks, solver, n, extra, 
     log = json.load(open(tmp_path / "log_mpi.json"))
     assert log["n_procs"] == nranks and log["grid"] == [nprow, nranks // nprow] and log["comm"] == comm
     assert {"eigen_solver", "eigen_solver_scalapack_all:pdsytrd"} <= {e["name"] for e in log["events"]}
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_rehearsed_on_one_gpu(hip):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks itself (fresh children,
+    no GPU call in the parent), the ranks share GPU 0 through the host communicator (--rehearse-on-one-gpu), the
+    line says n_gpus = 2 and carries both the replicas measurement and the grid probe with its parity check."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(["timeout", "-k", "10", "420", sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--rehearse-on-one-gpu", "--order", "1536", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-host-path", "--no-other-configs"],
+                         capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 1
+    assert line["parity"]["residual_norm_max"] <= line["parity"]["bounds"]["residual_norm_max"]
+    probe = line.get("grid_probe")
+    assert probe is not None and not probe.get("error"), probe

@@ -3,6 +3,8 @@ MatrixMarket I/O, result file format, verifier), the C-ABI export check and the 
 aggregation under gloo.  No GPU, no compute calls into libek_hip.so."""
 import ctypes
 import os
+import json
+import sys
 import re
 
 import numpy as np
@@ -522,3 +524,28 @@ def test_bench_host_path_child_reports_instead_of_raising():
         assert "error" in out or out.get("seconds", 0) > 0
     else:
         assert "error" in out and "child rc=" in out["error"]
+
+
+def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher (no RANK in the environment) starts two ranks itself as fresh
+    child processes and relays rank 0's line: n_gpus is the number of ranks that answered, not the flag echoed
+    (--dry-launch: gloo, no GPU call anywhere).  Run from a directory that holds a stray module named like one
+    of the standard library's: the launcher's imports must not pick it up."""
+    import subprocess
+    (tmp_path / "bisect.py").write_text("raise SystemExit('a stray module shadowed the standard library')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_launch"] is True
+    assert "starting 2 ranks" in out.stderr
+    # under a launcher the flag does not start a second generation of ranks
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "starting" not in out.stderr and "the launcher started 1 ranks" in out.stderr
+    assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
