@@ -182,7 +182,7 @@ def host_path_step(lib, solver, problem, n, n_vec):
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
         st = (ctypes.c_double * 8)()
         # Two calls at full size, inputs regenerated in front of each (the solve overwrites A and B): the first sets up
-        # what the library keeps between calls (device images of the caller's arrays, the pinned ring and the worker
+        # what the library keeps between calls (device images of the caller's arrays and the worker
         # threads of the staging pipeline) and is reported as first_call_seconds; the second is the figure.  (Until round
         # 4's last day the first call was a small one, order 2048: the device images then grew inside the timed call --
         # 6 GiB of hipMalloc, 0.05 - 0.12 s depending on the box.)
@@ -208,7 +208,7 @@ def host_path_step(lib, solver, problem, n, n_vec):
         pipe = {"bytes_in": ps[0], "in_span_seconds": ps[1], "in_gb_per_s": ps[0] / ps[1] / 1e9 if ps[1] > 0 else None,
                 "bytes_out": ps[3], "out_busy_seconds": ps[5], "main_thread_waited_for_inputs_seconds": ps[6],
                 "main_thread_waited_for_the_drain_seconds": ps[7], "workers_in": int(ps[8]) // 100, "workers_out": int(ps[8]) % 100,
-                "pinned_ring_directions": int(ps[9]), "pipeline_seconds": ps[10], "stage_seconds_sum": sum(st[q] for q in range(7))}
+                "pipeline_seconds": ps[10], "stage_seconds_sum": sum(st[q] for q in range(7))}
         return {"value": n_vec / sec, "unit": "eigenpairs/s", "seconds": sec, "first_call_seconds": secs[0],
                 "host_device_copies_seconds": st[7], "pipeline": pipe,
                 "note": "the second of two ek_hip_solve calls on pageable host arrays, all mapped before the calls (A, B in; "

@@ -257,6 +257,7 @@ int ek_hip_finalize(void) {
   g_ctx.ws = nullptr; g_ctx.ws_alloc = nullptr; g_ctx.ws_bytes = 0;
   release_scratch_choice();
   release_user_images();
+  release_pipe_streams();
   // a communicator does not outlive the library's device state
   comm_teardown();
   return 0;

@@ -56,6 +56,7 @@ inline size_t al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 void release_scratch_choice();
 int user_images(size_t bytes, void **p);   // device images of host arrays, kept between calls (ek_api.hip)
 void release_user_images();
+void release_pipe_streams();       // the staging pipeline's copy streams (ek_solve.hip)
 void *choose_sytrd_scratch(int n, int ld, double *wA, void *arena_work, double *vecs, size_t need);
 
 // device buffers of one host-array call: released on every exit path

@@ -102,52 +102,26 @@ void extract_local(int m, int n, const double *M_full, int ldf, const int *desc,
 //   in : B, then A (B is needed first: the Cholesky factorisation runs while A is still on its way);
 //   out: L as soon as it is final (it leaves during the reduction), the reflectors / band of A after the
 //        tridiagonalisation, Z in column slabs as the last stage finishes them, w last.
-// The caller's arrays are pageable.  Handed to the runtime as they are, a copy is staged through the runtime's own
-// bounce buffers by the calling thread at a rate that depends on the box's host side (27 - 36 GB/s with two threads per
-// direction on one pool box, a third of that exposed time on another: round 3).  Round 4: the library can own a ring of
-// PINNED bounce buffers (allocated once per process, on first use), a worker packs a chunk of columns into its slot with
-// the CPU (memcpy) and hands the slot to the DMA engine (and the reverse on the way out), two slots per worker so that its
-// memcpy and its DMA overlap; the number of workers on the way in follows the cores the process may run on, the way out
-// has two (HostPipe::start says why).  Off by default (HostPipe::pinned_dirs).
-struct PinRing {
-  static constexpr size_t kSlot = (size_t)16 << 20;      // bytes per slot
-  static constexpr int kMaxWorkers = 16;
-  char *base = nullptr;
-  int nslots = 0;
-  hipEvent_t ev[2 * kMaxWorkers] = {};
-  // (called under g_mu; the ring lives until the process ends: pinning 16 MiB per worker costs more than a solve's copies
-  // may lose)
-  bool ensure(int workers) {
-    const int want = 2 * workers;
-    if (base && nslots >= want) return true;
-    release();
-    if (hipHostMalloc((void **)&base, kSlot * want, hipHostMallocDefault) != hipSuccess) { base = nullptr; (void)hipGetLastError(); return false; }
-    for (int i = 0; i < want; ++i)
-      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { release(); return false; }
-    nslots = want;
-    return true;
-  }
-  void release() {
-    for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    if (base) (void)hipHostFree(base);
-    base = nullptr; nslots = 0;
-  }
-  char *slot(int i) const { return base + kSlot * (size_t)i; }
-};
-PinRing g_pin;
+// The caller's arrays are pageable and handed to the runtime as they are: on every box met since round 4 it moves them at
+// link rate (57 GB/s in).  Round 4's ring of pinned bounce buffers was measured slower under every runtime met (37 - 51
+// GB/s in, ~1 GB/s per worker out beside running kernels; profiles/r04_host_path.txt) and is gone (round 5).  The number
+// of workers on the way in follows the cores the process may run on, the way out has two (HostPipe::start says why).
 // what the last staging pipeline did (ek_hip_debug_last_pipe_stats): [0] bytes in, [1] span of the input transfers (s),
 // [2] busy seconds of the input workers, [3..5] the same on the way out, [6] seconds the main thread waited for inputs,
-// [7] for the drain at the end, [8] workers per direction, [9] directions through the pinned ring, [10] seconds from the
+// [7] for the drain at the end, [8] workers per direction, [9] 0 (round 4: directions through a pinned ring), [10] seconds from the
 // start of the pipeline to its end, [11] seconds before the first input job started
 double g_pipe_stats[12] = {0};
 // the pipeline's streams live as long as the process (creating its 14 streams took a call ~25 ms)
 struct PipeStreams {
-  hipStream_t cs[2 * 8] = {}, dma[2] = {};
+  hipStream_t cs[2 * 8] = {};
   int made = 0;
   int ensure(int n) {
     for (; made < n; ++made) EK_HIP_CHECK(hipStreamCreateWithFlags(&cs[made], hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) if (!dma[i]) EK_HIP_CHECK(hipStreamCreateWithFlags(&dma[i], hipStreamNonBlocking));
     return 0;
+  }
+  void release() {          // ek_hip_finalize: they come back with the next call that needs them
+    for (int i = 0; i < made; ++i) { (void)hipStreamDestroy(cs[i]); cs[i] = nullptr; }
+    made = 0;
   }
 };
 PipeStreams g_pipe_streams;
@@ -161,17 +135,12 @@ int usable_cores() {
 }
 
 struct HostPipe {
-  struct Job { double *dev; int ldd; double *host; int ldh; int m, n; hipEvent_t after; int tag; bool to_host; };
+  // tri: a square diagonal block on the way out of which only the lower triangle may reach the caller's array (m == n)
+  struct Job { double *dev; int ldd; double *host; int ldh; int m, n; hipEvent_t after; int tag; bool to_host; bool tri = false; };
   static constexpr int kMaxThreads = 8;
+  static constexpr int kTri = 512;           // columns of a diagonal block on the way out (2 MiB of scratch per worker)
   int kThreads = 2;                          // per direction (EK_HIP_PIPE_THREADS; default by the cores the process has)
   int kOutThreads = 2;                       // of them on the way out (see start())
-  // which directions go through the pinned ring (EK_HIP_PIPE_PINNED = 0 none, 1 in, 2 out, 3 both).  Default: none.
-  // Measured (profiles/r04_host_path.txt, r04_host_path_runtimes.txt): the runtime moves the caller's pageable arrays at
-  // link rate on every box round 4 met (57 GB/s in), the ring's way in made 37 - 51 (29 under the HIP runtime PyTorch
-  // bundles), and transfers into the ring's slots on the way out crawl at ~1 GB/s per worker beside the stages.  The ring
-  // is for a box whose runtime stages pageable memory slowly (27 - 36 GB/s: rounds 2 - 3 met one).
-  bool pinned = false;
-  int pinned_dirs = 0;
   bool lower_only = true;                    // EK_HIP_PIPE_LOWER=0: whole matrices both ways, as round 3
   std::mutex mu;
   std::condition_variable cv;
@@ -182,11 +151,6 @@ struct HostPipe {
   int err = 0;
   std::vector<std::thread> th;
   hipStream_t cs[2 * kMaxThreads] = {};
-  // pinned ring: ALL transfers of a direction are issued on ONE stream (dma[0] in, dma[1] out), one after the other at
-  // the link's rate, whichever worker packed the slot -- six workers with a stream each shared the DMA engines at 33 GB/s
-  // in all on a box whose single transfers run at 57 (profiles/r04_pcie_probe.txt)
-  hipStream_t dma[2] = {};
-  std::mutex dma_mu[2];
   int device = 0;
   int z_slab = 2048;
   // EK_HIP_PIPE_TRACE=1: what every copy job and every wait of the main thread took (stderr, at the end of the call)
@@ -208,7 +172,7 @@ struct HostPipe {
     for (int k = 0; k < 2; ++k) {
       g_pipe_stats[3 * k] = bytes[k]; g_pipe_stats[3 * k + 1] = bytes[k] > 0 ? last[k] - first[k] : 0.0; g_pipe_stats[3 * k + 2] = busy[k];
     }
-    g_pipe_stats[6] = win; g_pipe_stats[7] = wdrain; g_pipe_stats[8] = 100.0 * kThreads + kOutThreads; g_pipe_stats[9] = pinned ? pinned_dirs : 0;
+    g_pipe_stats[6] = win; g_pipe_stats[7] = wdrain; g_pipe_stats[8] = 100.0 * kThreads + kOutThreads; g_pipe_stats[9] = 0;
     g_pipe_stats[10] = now(); g_pipe_stats[11] = bytes[0] > 0 ? first[0] : 0.0;
   }
   void report() {
@@ -232,7 +196,7 @@ struct HostPipe {
       if (bytes[k] > 0)
         fprintf(stderr, "[pipe] %s: %.2f GB between t = %.4f and %.4f s (%.1f GB/s over the span), %d threads busy %.3f s in all (%.1f GB/s per busy thread), %s\n",
                 k ? "out" : "in", bytes[k] / 1e9, first[k], last[k], bytes[k] / 1e9 / (last[k] - first[k]), k ? kOutThreads : kThreads, busy[k],
-                bytes[k] / 1e9 / busy[k], pinned ? "pinned ring" : "pageable");
+                bytes[k] / 1e9 / busy[k], "pageable");
   }
 
   int start(int dev) {
@@ -240,94 +204,24 @@ struct HostPipe {
     t_origin = std::chrono::steady_clock::now();
     { static int tr = -1; if (tr < 0) { const char *e = getenv("EK_HIP_PIPE_TRACE"); tr = (e && atoi(e) != 0) ? 1 : 0; } trace = tr != 0; }
     static int env_threads = -2;
-    int env_pinned = -1;                      // (read per call: the tests switch it)
-    if (env_threads == -2) { const char *e = getenv("EK_HIP_PIPE_THREADS"); env_threads = e ? atoi(e) : -1; }
-    // (default 0 since the end of round 4: on every box met this round the runtime moves pageable memory at link rate,
-    // 57 GB/s in, and the ring's way in made 37 - 51 under the system's runtime, 29 under PyTorch's: N = 16384 GEP 0.876 s
-    // against 0.89 - 0.90 under either; profiles/r04_host_path_runtimes.txt)
-    if (env_pinned < 0) { const char *e = getenv("EK_HIP_PIPE_PINNED"); env_pinned = e ? (atoi(e) & 3) : 0; }
-    pinned_dirs = env_pinned;
     { static int lo = -1; if (lo < 0) { const char *e = getenv("EK_HIP_PIPE_LOWER"); lo = (e && atoi(e) == 0) ? 0 : 1; } lower_only = lo != 0; }
     const int cores = usable_cores();
     kThreads = cores >= 16 ? 6 : cores >= 8 ? 4 : 2;      // (both directions are rarely busy at once)
     if (env_threads >= 1 && env_threads <= kMaxThreads) kThreads = env_threads;
-    pinned = env_pinned != 0 && g_pin.ensure(2 * kThreads);
     { const int rc = g_pipe_streams.ensure(2 * kThreads); if (rc) return rc; }
     for (int i = 0; i < 2 * kThreads; ++i) cs[i] = g_pipe_streams.cs[i];
-    for (int i = 0; i < 2; ++i) dma[i] = g_pipe_streams.dma[i];
-    // The way out hands pageable memory to the runtime (unless the ring serves it): two threads saturate the link (30 GB/s
+    // The way out hands pageable memory to the runtime: two threads saturate the link (30 GB/s
     // each), and MORE than two collapse under the HIP runtime PyTorch bundles (2.10: 1.7 GB/s per thread with three, 0.9
     // with six, beside running kernels; the system's runtime does 10 - 20 with any number) -- which is the runtime that
     // serves a process that imported torch first.  EK_HIP_PIPE_THREADS_OUT overrides.
     static int env_out = -2;
     if (env_out == -2) { const char *e = getenv("EK_HIP_PIPE_THREADS_OUT"); env_out = e ? atoi(e) : -1; }
-    kOutThreads = (pinned && (pinned_dirs & 2)) ? kThreads : (kThreads < 2 ? kThreads : 2);
+    kOutThreads = kThreads < 2 ? kThreads : 2;
     if (env_out >= 1 && env_out <= kThreads) kOutThreads = env_out;
-    for (int i = 0; i < kThreads + kOutThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i], i); });
+    for (int i = 0; i < kThreads + kOutThreads; ++i) th.emplace_back([this, i]() { run(i < kThreads, cs[i]); });
     return 0;
   }
-  // one job through the worker's two pinned slots (m rows of 8 bytes, n columns; a chunk = as many columns as fit a slot)
-  // completion of a slot's transfer by POLLING: hipEventSynchronize sleeps, and a worker that waits for every 16 MiB chunk
-  // of the way out that way moved ~1 GB/s (round 4's first ring)
-  static hipError_t wait_event(hipEvent_t e) {
-    for (unsigned spins = 0;; ++spins) {
-      const hipError_t q = hipEventQuery(e);
-      if (q != hipErrorNotReady) return q;
-      if ((spins & 63u) == 63u) std::this_thread::yield();
-    }
-  }
-  hipError_t copy_pinned(const Job &j, hipStream_t c, int worker) {
-    const size_t col_bytes = (size_t)j.m * 8;
-    if (col_bytes > PinRing::kSlot) return hipErrorInvalidValue;      // (orders beyond a million)
-    const int cpc = (int)(PinRing::kSlot / col_bytes);
-    const int nchunk = ceil_div(j.n, cpc);
-    char *slot[2] = {g_pin.slot(2 * worker), g_pin.slot(2 * worker + 1)};
-    hipEvent_t ev[2] = {g_pin.ev[2 * worker], g_pin.ev[2 * worker + 1]};
-    hipError_t e = hipSuccess;
-    auto cols = [&](int q) { const int c0 = q * cpc; return (j.n - c0 < cpc) ? j.n - c0 : cpc; };
-    if (!j.to_host) {
-      for (int q = 0; q < nchunk && e == hipSuccess; ++q) {
-        const int k = q & 1, c0 = q * cpc, nc = cols(q);
-        if (q >= 2) e = wait_event(ev[k]);                            // the slot's previous DMA has read it
-        if (e != hipSuccess) break;
-        const double *src = j.host + (size_t)c0 * j.ldh;
-        if (j.ldh == j.m) memcpy(slot[k], src, col_bytes * nc);
-        else for (int cc = 0; cc < nc; ++cc) memcpy(slot[k] + col_bytes * cc, src + (size_t)cc * j.ldh, col_bytes);
-        {
-          std::lock_guard<std::mutex> lk(dma_mu[0]);
-          // (a contiguous device image -- the n x n user-side arrays of ek_hip_solve -- as ONE linear transfer: the
-          // 2-D form is not guaranteed the DMA engines)
-          if (j.ldd == j.m) e = hipMemcpyAsync(j.dev + (size_t)c0 * j.ldd, slot[k], col_bytes * nc, hipMemcpyHostToDevice, dma[0]);
-          else e = hipMemcpy2DAsync(j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, slot[k], col_bytes, col_bytes, nc, hipMemcpyHostToDevice, dma[0]);
-          if (e == hipSuccess) e = hipEventRecord(ev[k], dma[0]);
-        }
-      }
-      for (int k = 0; k < 2 && k < nchunk; ++k) { const hipError_t e2 = wait_event(ev[k]); if (e == hipSuccess) e = e2; }
-      return e;
-    }
-    auto fetch = [&](int q) {
-      const int k = q & 1, c0 = q * cpc, nc = cols(q);
-      std::lock_guard<std::mutex> lk(dma_mu[1]);
-      hipError_t f = (j.ldd == j.m)
-          ? hipMemcpyAsync(slot[k], j.dev + (size_t)c0 * j.ldd, col_bytes * nc, hipMemcpyDeviceToHost, dma[1])
-          : hipMemcpy2DAsync(slot[k], col_bytes, j.dev + (size_t)c0 * j.ldd, (size_t)j.ldd * 8, col_bytes, nc, hipMemcpyDeviceToHost, dma[1]);
-      if (f == hipSuccess) f = hipEventRecord(ev[k], dma[1]);
-      return f;
-    };
-    e = fetch(0);
-    for (int q = 0; q < nchunk && e == hipSuccess; ++q) {
-      const int k = q & 1, c0 = q * cpc, nc = cols(q);
-      if (q + 1 < nchunk) e = fetch(q + 1);                           // (its slot was emptied by this thread one round ago)
-      if (e == hipSuccess) e = wait_event(ev[k]);
-      if (e != hipSuccess) break;
-      double *dst = j.host + (size_t)c0 * j.ldh;
-      if (j.ldh == j.m) memcpy(dst, slot[k], col_bytes * nc);
-      else for (int cc = 0; cc < nc; ++cc) memcpy(dst + (size_t)cc * j.ldh, slot[k] + col_bytes * cc, col_bytes);
-    }
-    (void)c;
-    return e;
-  }
-  void run(bool input, hipStream_t c, int worker) {
+  void run(bool input, hipStream_t c) {
     (void)hipSetDevice(device);
     std::deque<Job> &q = input ? in_q : out_q;
     while (true) {
@@ -341,15 +235,21 @@ struct HostPipe {
       hipError_t e = hipSuccess;
       if (j.after) e = hipEventSynchronize(j.after);
       const double tj0 = now();
-      if (e == hipSuccess && j.m > 0 && j.n > 0) {
-        if (pinned && (pinned_dirs & (j.to_host ? 2 : 1)) && (size_t)j.m * 8 <= PinRing::kSlot) e = copy_pinned(j, c, worker);
-        else {
-          if (j.to_host)
-            e = hipMemcpy2DAsync(j.host, (size_t)j.ldh * 8, j.dev, (size_t)j.ldd * 8, (size_t)j.m * 8, j.n, hipMemcpyDeviceToHost, c);
-          else
-            e = hipMemcpy2DAsync(j.dev, (size_t)j.ldd * 8, j.host, (size_t)j.ldh * 8, (size_t)j.m * 8, j.n, hipMemcpyHostToDevice, c);
-          if (e == hipSuccess) e = hipStreamSynchronize(c);
-        }
+      if (e == hipSuccess && j.m > 0 && j.n > 0 && j.tri) {
+        // the block crosses into a scratch of this thread; the caller's array receives the entries on and below the
+        // diagonal only (its strictly upper triangle is neither read nor written: PDPOTRF / PDSYTRD with uplo = 'L')
+        std::vector<double> tmp((size_t)j.n * j.n);
+        e = hipMemcpy2DAsync(tmp.data(), (size_t)j.n * 8, j.dev, (size_t)j.ldd * 8, (size_t)j.n * 8, j.n, hipMemcpyDeviceToHost, c);
+        if (e == hipSuccess) e = hipStreamSynchronize(c);
+        if (e == hipSuccess)
+          for (int cc = 0; cc < j.n; ++cc)
+            memcpy(j.host + (size_t)cc * j.ldh + cc, tmp.data() + (size_t)cc * j.n + cc, (size_t)(j.n - cc) * 8);
+      } else if (e == hipSuccess && j.m > 0 && j.n > 0) {
+        if (j.to_host)
+          e = hipMemcpy2DAsync(j.host, (size_t)j.ldh * 8, j.dev, (size_t)j.ldd * 8, (size_t)j.m * 8, j.n, hipMemcpyDeviceToHost, c);
+        else
+          e = hipMemcpy2DAsync(j.dev, (size_t)j.ldd * 8, j.host, (size_t)j.ldh * 8, (size_t)j.m * 8, j.n, hipMemcpyHostToDevice, c);
+        if (e == hipSuccess) e = hipStreamSynchronize(c);
       }
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -377,6 +277,21 @@ struct HostPipe {
         int c1 = (int)((long long)n * (p + 1) / pieces);
         if (lower) c1 = (p + 1 == pieces) ? n : (int)((double)n * (1.0 - sqrt(1.0 - (double)(p + 1) / pieces)));
         if (c1 < c0) c1 = c0;
+        if (lower && to_host) {
+          // on the way out a piece is cut into chunks of at most kTri columns: the rows below a chunk's diagonal block as
+          // one 2-D copy, the diagonal block as a `tri` job -- nothing above the diagonal of the caller's array is written
+          for (int a = c0; a < c1; a += kTri) {
+            const int b = (c1 - a < kTri) ? c1 : a + kTri;
+            Job t{dev + (size_t)a * ldd + a, ldd, host + (size_t)a * ldh + a, ldh, b - a, b - a, after, tag, true, true};
+            out_q.push_back(t); ++pending_out;
+            if (b < m) {
+              Job r{dev + (size_t)a * ldd + b, ldd, host + (size_t)a * ldh + b, ldh, m - b, b - a, after, tag, true};
+              out_q.push_back(r); ++pending_out;
+            }
+          }
+          c0 = c1;
+          continue;
+        }
         const int r0 = lower ? (c0 & ~1) : 0;                          // (even: 16-byte aligned rows)
         Job j{dev + (size_t)c0 * ldd + r0, ldd, host + (size_t)c0 * ldh + r0, ldh, m - r0, c1 - c0, after, tag, to_host};
         if (to_host) { out_q.push_back(j); ++pending_out; } else { in_q.push_back(j); ++pending_in[tag]; }
@@ -404,7 +319,6 @@ struct HostPipe {
     for (auto &t : th) t.join();
     th.clear();
     for (auto &c : cs) c = nullptr;              // (the streams belong to the process-wide pool)
-    for (auto &c : dma) c = nullptr;
     for (auto &e : evs) (void)hipEventDestroy(e);
     evs.clear();
     report();
@@ -859,6 +773,8 @@ int replicated_host_locked(int problem, int n, int n_vec, double *A, int lda, do
 
 }  // namespace
 
+namespace ek { namespace api { void release_pipe_streams() { g_pipe_streams.release(); } } }
+
 extern "C" {
 
 int ek_hip_solve_device(int problem, int n, int n_vec, double *dA, int lda, double *dB, int ldb,
@@ -1180,8 +1096,17 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
   if (info >= 0 || info > -1000) {
     // results travel back even when info > 0 so the host can inspect them, as with ScaLAPACK
     int rc2 = d2h_matrix(n, n_vec, uZ, n, Z_loc, desc_Z[8], s);
-    if (!rc2) rc2 = d2h_matrix(n, n, uA, n, A_loc, desc_A[8], s);
-    if (!rc2 && problem == 1) rc2 = d2h_matrix(n, n, uB, n, B_loc, desc_B[8], s);
+    // A and B go back as uplo = 'L' arrays: through a scratch, of which the caller's array receives the entries on and
+    // below the diagonal only (orders below the pipeline's: at most 32 MiB)
+    std::vector<double> tmp((size_t)n * n);
+    auto d2h_lower = [&](const double *u, double *M_loc, int ldm) -> int {
+      int r = d2h_matrix(n, n, u, n, tmp.data(), n, s);
+      if (!r) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = -1000 - (int)e; }
+      if (!r) for (int c = 0; c < n; ++c) memcpy(M_loc + (size_t)c * ldm + c, tmp.data() + (size_t)c * n + c, (size_t)(n - c) * 8);
+      return r;
+    };
+    if (!rc2) rc2 = d2h_lower(uA, A_loc, desc_A[8]);
+    if (!rc2 && problem == 1) rc2 = d2h_lower(uB, B_loc, desc_B[8]);
     if (!rc2) { hipError_t e = hipMemcpyAsync(w, uw, (size_t)n * 8, hipMemcpyDeviceToHost, s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
     if (!rc2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) rc2 = -1000 - (int)e; }
     if (rc2 && info == 0) info = rc2;

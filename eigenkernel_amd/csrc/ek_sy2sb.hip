@@ -1474,8 +1474,8 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
     }
     evs = true;
   }
-  static int la_env = -2;
-  if (la_env == -2) { const char *e = getenv("EK_SY2SB_DIST_LOOKAHEAD_MIN"); la_env = e ? atoi(e) : -1; }
+  int la_env = -1;      // (read per call: the multi-process test compares both forms inside one process group)
+  { const char *e = getenv("EK_SY2SB_DIST_LOOKAHEAD_MIN"); if (e) la_env = atoi(e); }
   const int la_min = g_dist_la_min >= 0 ? g_dist_la_min : (la_env >= 0 ? la_env : 1024);
   const bool la_on = s2 != nullptr && la_min > 0;
   const int P = x.nranks;

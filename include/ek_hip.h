@@ -75,8 +75,10 @@ const char *ek_hip_stage_name(int stage);       /* reference event name of a sta
  *             reduction: the band and the first stage's R factors -- INTEGRATION.md)
  *   B_loc   : in: SPD, lower; out: Cholesky factor L (needed by recovery); NULL if problem==0
  *             (uplo = 'L' as everywhere in the reference: the strictly upper triangles of A_loc
- *             and B_loc are neither read nor, on a 1 x 1 grid from order 2048 on, written --
- *             only the lower triangles cross PCIe, as PDPOTRF / PDSYTRD leave the upper ones alone)
+ *             and B_loc are never referenced and, on a 1 x 1 grid, never written -- the caller
+ *             finds there what it left there, as after PDPOTRF / PDSYTRD; from order 2048 on only
+ *             the lower triangles cross PCIe.  On larger grids the local block-cyclic pieces are
+ *             written whole.)
  *   w       : out: n doubles, ascending, first n_vec valid (eigenpairs%blacs%values)
  *   Z_loc   : out: eigenvectors (eigenpairs%blacs%Vectors), N x N descriptor, same NB as A;
  *             B-orthonormal (generalized) / orthonormal (standard)

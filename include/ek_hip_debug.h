@@ -84,8 +84,7 @@ int ek_hip_debug_fail_next_chase(int times);
 
 /* what the staging pipeline of the last ek_hip_solve on host arrays did: out[0] bytes in, [1] span of the input transfers
    (s), [2] busy seconds of the input workers, [3..5] the same on the way out, [6] seconds the main thread waited for
-   inputs, [7] for the drain at the end, [8] 100 x workers on the way in + workers on the way out, [9] directions through the pinned ring (bit 0 in,
-   bit 1 out), [10] seconds from the start of the pipeline to its end, [11] seconds before the first input transfer */
+   inputs, [7] for the drain at the end, [8] 100 x workers on the way in + workers on the way out, [9] 0 (round 4: directions through a pinned ring, removed), [10] seconds from the start of the pipeline to its end, [11] seconds before the first input transfer */
 int ek_hip_debug_last_pipe_stats(double *out, int count);
 
 #ifdef __cplusplus

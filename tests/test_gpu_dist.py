@@ -407,6 +407,23 @@ def _mp_worker(rank, world, port, q):
             res[solver_name] = (ep.values.copy(), cols, ep.Vectors[:, :len(cols)].copy())
             say(solver_name + " done")
         out["solve"] = res
+        # (3b) the two-stream look-ahead of the team's dense -> band stage (panel chain + broadcast on a second stream beside
+        # the update: from 1024 rows on) across real processes through the host communicator: same bits as without it
+        n2 = 1500
+        A2 = ek_oracle.synth_matrix(n2, 1)
+        proc = sv.Process(rank, world, 0, 1, world, 0, rank)
+        la = {}
+        for key, val in (("on", None), ("off", "0")):
+            if val is None:
+                os.environ.pop("EK_SY2SB_DIST_LOOKAHEAD_MIN", None)
+            else:
+                os.environ["EK_SY2SB_DIST_LOOKAHEAD_MIN"] = val
+            ep, _ = sv.eigen_solver("hip", A2, None, proc=proc)
+            cols = d.local_indices(n2, int(ep.desc[d.BLOCK_ROW_]), rank, world)
+            la[key] = (ep.values.copy(), ep.Vectors[:, :len(cols)].copy())
+        os.environ.pop("EK_SY2SB_DIST_LOOKAHEAD_MIN", None)
+        out["lookahead"] = la
+        say("look-ahead on / off done")
         # (4) an exchange that fails on ONE rank in the middle of a solve (here: rank 1's hook reports a failure of its
         # 12th exchange from now, inside the dense -> band stage at this order) ends the call on EVERY rank with -996: the sticky
         # record travels in the team's votes (ek_comm.hip comm_vote); the next call starts clean
@@ -501,6 +518,13 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
         assert np.array_equal(o["w_after_exchange_failure"], outs[0]["solve"]["general_hip"][0])
         assert o["info_bad_B"] == 151 and o["info_nan_A"] == -4
         assert np.array_equal(o["w_after"], outs[0]["solve"]["hip"][0])
+    # the team's two-stream look-ahead changes no bit, on any process
+    for o in outs:
+        assert np.array_equal(o["lookahead"]["on"][0], o["lookahead"]["off"][0])
+        assert np.array_equal(o["lookahead"]["on"][1], o["lookahead"]["off"][1])
+        assert np.array_equal(o["lookahead"]["on"][0], outs[0]["lookahead"]["on"][0])
+    w2 = np.linalg.eigvalsh(oracle.synth_matrix(1500, 1))
+    assert np.abs(outs[0]["lookahead"]["on"][0] - w2).max() <= 4 * 1500 * EPS * np.abs(w2).max()
     # potrf: the complete factor on every process
     for o in outs[1:]:
         assert np.array_equal(outs[0]["potrf"], o["potrf"])

@@ -657,9 +657,8 @@ def test_no_eigenvectors_requested(hip, oracle):
             assert not ep.Vectors.any()
 
 
-@pytest.mark.parametrize("pinned", ["0", "3"])
 @pytest.mark.parametrize("solver,n,n_vec", [("general_hip", 2304, 2304), ("hip", 2100, 2100), ("general_hip_select", 2304, 300)])
-def test_staging_pipeline_of_the_host_path_changes_no_bit(hip, oracle, monkeypatch, solver, n, n_vec, pinned):
+def test_staging_pipeline_of_the_host_path_changes_no_bit(hip, oracle, monkeypatch, solver, n, n_vec):
     """From order 2048 on ek_hip_solve overlaps its PCIe copies with the stages (B in first, A behind the Cholesky
     factorisation; L, the reflectors and Z out as they become final, Z in column slabs): eigenvalues, eigenvectors and
     the in-place results must be the bits of the serial staging (EK_HIP_PIPE_MIN=0), and pass the acceptance bounds."""
@@ -669,7 +668,6 @@ def test_staging_pipeline_of_the_host_path_changes_no_bit(hip, oracle, monkeypat
     monkeypatch.setenv("EK_HIP_PIPE_MIN", "0")
     ep0, _ = hip.eigen_solver(solver, A, Bm, n_vec=n_vec)
     monkeypatch.setenv("EK_HIP_PIPE_MIN", "1024")
-    monkeypatch.setenv("EK_HIP_PIPE_PINNED", pinned)      # pageable arrays handed to the runtime / the ring of pinned buffers both ways
     ep1, _ = hip.eigen_solver(solver, A, Bm, n_vec=n_vec)
     assert np.array_equal(ep0.values, ep1.values)
     assert np.array_equal(ep0.Vectors[:, :n_vec], ep1.Vectors[:, :n_vec])
@@ -713,3 +711,50 @@ def test_caller_leading_dimensions_larger_than_the_order(hip, oracle, monkeypatc
     if B is not None:
         assert np.array_equal(np.tril(B0), np.tril(B1[:n]))
         assert (B1[n:] == -3.25).all()
+
+
+@pytest.mark.parametrize("problem,n,pad,pipe_min", [(1, 2304, 0, "1024"), (1, 2100, 3, "1024"), (0, 3000, 0, "1024"),
+                                                    (1, 2304, 0, "0"), (1, 700, 5, "0"), (0, 384, 0, "0")])
+def test_upper_triangles_of_the_callers_arrays_are_left_alone(hip, oracle, monkeypatch, problem, n, pad, pipe_min):
+    """uplo = 'L' (generalized_to_standard.f90:24,37, solver_scalapack_all.f90:59): PDPOTRF / PDSYTRD neither reference nor
+    write the strictly upper triangles of A and B.  Here they hold a sentinel (a NaN with a payload) on entry; on a 1 x 1
+    grid it must still be there, bit for bit, after ek_hip_solve -- through the pipeline (whose pieces are cut across the
+    diagonal: the diagonal blocks of the way out go through a scratch) and through the serial staging -- and the
+    results are those of clean symmetric inputs."""
+    from eigenkernel_amd import descriptor as d
+    lib = hip.load_library()
+    monkeypatch.setenv("EK_HIP_PIPE_MIN", pipe_min)
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2) if problem == 1 else None
+    sentinel = np.frombuffer(np.uint64(0x7FF8DEADBEEF1234).tobytes(), dtype=np.float64)[0]
+    iu = np.triu_indices(n, 1)
+
+    def call(marked):
+        la = n + pad
+        Al = np.asfortranarray(np.full((la, n), 7.5)); Al[:n, :] = A
+        Bl = None
+        if B is not None:
+            Bl = np.asfortranarray(np.full((la, n), -3.25)); Bl[:n, :] = B
+        if marked:
+            Al[:n][iu] = sentinel
+            if Bl is not None:
+                Bl[:n][iu] = sentinel
+        Z = np.asfortranarray(np.zeros((n, n)))
+        w = np.zeros(n)
+        da, dz = d.descinit(n, n, n, n, 0, 0, 0, la), d.descinit(n, n, n, n, 0, 0, 0, n)
+        rc = lib.ek_hip_solve(problem, n, n, hip._P(Al), hip._I(da), hip._P(Bl) if Bl is not None else None,
+                              hip._I(da) if Bl is not None else None, hip._P(w), hip._P(Z), hip._I(dz), 1, 1, 0, 0, None, 0)
+        assert rc == 0
+        return Al, Bl, Z, w
+
+    A0, B0, Z0, w0 = call(False)
+    A1, B1, Z1, w1 = call(True)
+    assert np.array_equal(w0, w1) and np.array_equal(Z0, Z1)
+    assert np.array_equal(np.tril(A0[:n]), np.tril(A1[:n]))
+    want = np.full(len(iu[0]), sentinel).view(np.uint64)
+    assert np.array_equal(A1[:n][iu].view(np.uint64), want)
+    assert np.array_equal(A0[:n][iu], A[iu])                       # (clean inputs: the upper triangle is still the input's)
+    if B is not None:
+        assert np.array_equal(np.tril(B0[:n]), np.tril(B1[:n]))
+        assert np.array_equal(B1[:n][iu].view(np.uint64), want)
+        assert np.array_equal(B0[:n][iu], B[iu])
