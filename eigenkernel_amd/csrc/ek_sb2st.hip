@@ -946,14 +946,17 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
     if (pass >= p.npass) break;
     const int bundle = p.npair - 1 - pass / p.nslab, slab = pass % p.nslab;      // (npair: number of bundles)
     const int S = NBLK * bundle;                         // lowest block of the bundle
-    int KSb[NBLK];
-    unsigned offb[NBLK];                                 // first record of each block of the bundle
-#pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
-      KSb[b] = (S + b < p.g.nS) ? q2_groups_of_block(n, S + b) : 0;
-      offb[b] = (S + b < p.g.nS) ? p.g.offS[S + b] : 0u;
-    }
-    const int KS = KSb[0];
+    // groups and first record of each block of the bundle: wave-uniform scalars with names of their own (as the arrays
+    // KSb[NBLK], offb[NBLK] of round 4 they were indexed with the block a step starts at, so the compiler kept them in
+    // scratch memory -- 32 bytes per lane, a scratch load in front of every group's record address)
+    auto ks_of = [&](int b) -> int { return (S + b < p.g.nS) ? q2_groups_of_block(n, S + b) : 0; };
+    auto off_of = [&](int b) -> unsigned {
+      return (S + b < p.g.nS) ? (unsigned)__builtin_amdgcn_readfirstlane((int)p.g.offS[S + b]) : 0u;
+    };
+    const int KS0 = ks_of(0), KS1 = NBLK > 1 ? ks_of(1) : 0, KS2 = NBLK > 2 ? ks_of(2) : 0, KS3 = NBLK > 3 ? ks_of(3) : 0;
+    const unsigned of0 = off_of(0), of1 = NBLK > 1 ? off_of(1) : 0u, of2 = NBLK > 2 ? off_of(2) : 0u, of3 = NBLK > 3 ? off_of(3) : 0u;
+    auto KSb = [&](int b) -> int { return b == 0 ? KS0 : (b == 1 ? KS1 : (b == 2 ? KS2 : KS3)); };
+    const int KS = KS0;
     const int colw = slab * QNC + 16 * wave;
     const unsigned *pprog = (bundle + 1 < p.npair) ? p.prog + (size_t)(pass - p.nslab) : nullptr;   // the bundle above, same slab
     unsigned *myprog = p.prog + pass;
@@ -983,10 +986,8 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
     const int obase_v = (t >> 4) * QVS + ((2 * (t & 15) + 16 * ((t >> 4) & 1)) & 31);   // (odd rows: halves swapped)
     const int obase_t = (t >> 4) * QTS + 2 * (t & 15);
     const int vsw = 16 * (l4 & 1);                        // first product: the column half this lane finds columns 0..15 of its row in
-    auto rec_of = [&](int b, int k) -> const d2_t * {     // block b of the bundle, group k (no memory access: offb)
-      unsigned o = offb[0];
-#pragma unroll
-      for (int q = 1; q < NBLK; ++q) if (b == q) o = offb[q];
+    auto rec_of = [&](int b, int k) -> const d2_t * {     // block b of the bundle, group k (no memory access)
+      const unsigned o = b == 0 ? of0 : (b == 1 ? of1 : (b == 2 ? of2 : of3));
       return reinterpret_cast<const d2_t *>(p.Rec + ((size_t)o + k) * QREC) + t;
     };
     auto fetch_v = [&](const d2_t *rec) {
@@ -1114,13 +1115,13 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
     auto first_block = [&](int k) -> int {               // highest block that has a group k (block 0 has: k < KS)
       int b = 0;
 #pragma unroll
-      for (int q = 1; q < NBLK; ++q) if (k < KSb[q]) b = q;
+      for (int q = 1; q < NBLK; ++q) if (k < KSb(q)) b = q;
       return b;
     };
     auto next_group = [&](int k, int b) -> const d2_t * {      // record of the group after (b, k); its own if it is the last
       int nb = -1, nk = k;
 #pragma unroll
-      for (int q = NBLK - 1; q >= 0; --q) if (q < b && nb < 0 && k < KSb[q]) nb = q;
+      for (int q = NBLK - 1; q >= 0; --q) if (q < b && nb < 0 && k < KSb(q)) nb = q;
       if (nb < 0) { nk = k + 1; if (nk < KS) nb = first_block(nk); }
       if (nb < 0) { nb = b; nk = k; }
       return rec_of(nb, nk);
@@ -1157,7 +1158,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_nb_kernel(Q2ApplyArgs p) {
       const int bfirst = first_block(k);
       auto do_group = [&](auto b_c) {
         constexpr int B = decltype(b_c)::value;
-        if (k >= KSb[B]) return;                         // (uniform)
+        if (k >= KSb(B)) return;                         // (uniform)
         // (here: the V image of this group is in LDS and visible, its -(V T) half is on its way into registers)
         if (B == bfirst && t == 0 && pprog) early = __hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         apply_group(std::integral_constant<int, 2 * B>(), next_group(k, B),
