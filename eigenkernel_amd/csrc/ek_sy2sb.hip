@@ -59,7 +59,7 @@ struct PanelArgs {
   const double *Rband;      // S R, upper triangular (column-major, ld 64)
   double *Vall; int ldv;    // explicit reflector matrix of the back-transformation, at (r0, c0)
   double *Apanel; int lda;  // the panel inside A, at (r0, c0)
-  double *Vimg; int ldi;    // [W | V | W] image: V goes to columns 64..127
+  double *Vd1, *Vd2; int ldi;   // where V goes in the update's operand images (column 0 of the panel's block; Vd2 may be null)
   const int *pflag;         // FINAL pass: non-zero = this panel goes to the rescue: leave it untouched
   int *nz;                  // MODE 0: *nz = 1 + the last 64-row chunk of the panel that is not all zeros (atomic max)
 };
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p) {
           a = (r <= col) ? p.Rband[r + SB * col] : 0.0;
         }
         p.Vall[(size_t)row + (size_t)col * p.ldv] = v;
-        p.Vimg[(size_t)row + (size_t)(SB + col) * p.ldi] = v;
+        p.Vd1[(size_t)row + (size_t)col * p.ldi] = v;
+        if (p.Vd2) p.Vd2[(size_t)row + (size_t)col * p.ldi] = v;
         p.Apanel[(size_t)row + (size_t)col * p.lda] = a;
       }
     }
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
 // QR inside one workgroup (any rank, any m <= 256).  Same outputs as the CholeskyQR2 chain.
 struct SmallArgs {
   int m;
-  double *Apanel; int lda; double *Vall; int ldv; double *Vimg; int ldi;
+  double *Apanel; int lda; double *Vall; int ldv; double *Vd1, *Vd2; int ldi;
   double *T, *tau;
 };
 constexpr int SMALL_MAX = 127;              // panels of 128 rows and more go through the CholeskyQR2 chain
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(256) void house_small_kernel(SmallArgs p) {
     const int r = idx % m, c = idx / m;
     const double v = sP[r * LD + c];
     p.Vall[(size_t)r + (size_t)c * p.ldv] = v;
-    p.Vimg[(size_t)r + (size_t)(SB + c) * p.ldi] = v;
+    p.Vd1[(size_t)r + (size_t)c * p.ldi] = v;
+    if (p.Vd2) p.Vd2[(size_t)r + (size_t)c * p.ldi] = v;
   }
 }
 
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(HT) void house_tall_kernel(int m_full, double *__re
 // the outputs of a rescued panel: V into the image and the reflector matrix, R alone left in the panel, Gram partials
 // of V for its T factor
 struct TallFinishArgs {
-  int m; double *Apanel; int lda; double *Vall; int ldv; double *Vimg; int ldi; double *Gpart; const int *pflag;
+  int m; double *Apanel; int lda; double *Vall; int ldv; double *Vd1, *Vd2; int ldi; double *Gpart; const int *pflag;
 };
 __global__ __launch_bounds__(256) void tall_finish_kernel(TallFinishArgs p) {
   __shared__ double sV[IMG];
@@ -675,7 +677,8 @@ __global__ __launch_bounds__(256) void tall_finish_kernel(TallFinishArgs p) {
         v = (row > col) ? x : (row == col ? 1.0 : 0.0);
         p.Apanel[(size_t)row + (size_t)col * p.lda] = (row <= col) ? x : 0.0;
         p.Vall[(size_t)row + (size_t)col * p.ldv] = v;
-        p.Vimg[(size_t)row + (size_t)(SB + col) * p.ldi] = v;
+        p.Vd1[(size_t)row + (size_t)col * p.ldi] = v;
+        if (p.Vd2) p.Vd2[(size_t)row + (size_t)col * p.ldi] = v;
       }
       sV[r * LD + col] = v;
     }
@@ -932,6 +935,11 @@ struct YredArgs {
   const double *V; int ldv;
   double *Gpart;
   int ldyo = 0;
+  // second panel of a pair (yred_q_kernel): Ypart is A_stale V2 for a trailing matrix that the first panel has not
+  // updated yet; Y = the sum - Wp (Vp^T V2) - Vp (Wp^T V2) with the first panel's W, V (rows of this trailing matrix, ld
+  // ldc) and the two 64 x 64 products cG1 = Vp^T V2, cG2 = Wp^T V2 (stored (j + 64 i) = G(i, j)).  cW == null: none.
+  const double *cW = nullptr, *cV = nullptr; int ldc = 0;
+  const double *cG1 = nullptr, *cG2 = nullptr;
 };
 __global__ __launch_bounds__(256) void yred_kernel(YredArgs p) {
   __shared__ double sY[IMG], sV[IMG];
@@ -989,9 +997,34 @@ __global__ __launch_bounds__(256) void yred_q_kernel(YredArgs p) {
       for (int s = 0; s < 16; ++s) ys[s] = (s < p.nsplit) ? yp[(size_t)s * p.sY] : 0.0;
       y = ((ys[0] + ys[1]) + (ys[2] + ys[3])) + ((ys[4] + ys[5]) + (ys[6] + ys[7]));
       if (p.nsplit > 8) y += ((ys[8] + ys[9]) + (ys[10] + ys[11])) + ((ys[12] + ys[13]) + (ys[14] + ys[15]));
-      p.Y[(size_t)row + (size_t)col * (p.ldyo ? p.ldyo : p.ldy)] = y;
+      if (!p.cW) p.Y[(size_t)row + (size_t)col * (p.ldyo ? p.ldyo : p.ldy)] = y;
     }
     sYq[r * 17 + lc] = y;
+  }
+  if (p.cW) {                                           // (uniform) the pending update of the pair's first panel
+    double4_t cacc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int pass = 0; pass < 2; ++pass) {
+      const double *src = pass ? p.cV : p.cW, *G = pass ? p.cG2 : p.cG1;     // Wp G1, then Vp G2
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int col = 16 * cg + c;
+        sV[r * LD + col] = (row < p.m) ? src[(size_t)row + (size_t)col * p.ldc] : 0.0;
+      }
+      __syncthreads();
+      for (int kk = 0; kk < SB; kk += 4)
+        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(16 * wave + l15) * LD + kk + l4], G[(16 * q + l15) + SB * (kk + l4)], cacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) sYq[(16 * wave + l4 + 4 * rr) * 17 + l15] -= cacc[rr];
+    __syncthreads();
+    if (row < p.m) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int lc = 4 * cg + c;
+        p.Y[(size_t)row + (size_t)(16 * q + lc) * (p.ldyo ? p.ldyo : p.ldy)] = sYq[r * 17 + lc];
+      }
+    }
   }
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
@@ -1007,22 +1040,44 @@ __global__ __launch_bounds__(256) void yred_q_kernel(YredArgs p) {
   for (int rr = 0; rr < 4; ++rr) G[(16 * q + l15) + SB * (16 * wave + l4 + 4 * rr)] = acc[rr];
 }
 
+// Second panel of a pair: per 64-row chunk the partial products Vp^T V2 and Wp^T V2 (the first panel's V and W against the
+// second panel's V, rows of the second panel's trailing matrix); reduce_parts_kernel sums them
+struct CorrGramArgs { int m; const double *Vp, *Wp, *V2; int ld; double *G1part, *G2part; };
+__global__ __launch_bounds__(256) void corr_gram_kernel(CorrGramArgs p) {
+  __shared__ double sX[IMG], sW[IMG], sY[IMG];
+  const int t = threadIdx.x, r = t & 63, cg = t >> 6;
+  const int row = blockIdx.x * CH + r;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int col = 16 * cg + c;
+    const size_t o = (size_t)row + (size_t)col * p.ld;
+    const bool in = row < p.m;
+    sX[r * LD + col] = in ? p.Vp[o] : 0.0; sW[r * LD + col] = in ? p.Wp[o] : 0.0; sY[r * LD + col] = in ? p.V2[o] : 0.0;
+  }
+  __syncthreads();
+  double4_t a1[4], a2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a1[j] = (double4_t){0.0, 0.0, 0.0, 0.0}; a2[j] = (double4_t){0.0, 0.0, 0.0, 0.0}; }
+  slab_gram(sX, sY, a1);
+  slab_gram(sW, sY, a2);
+  store_gram(a1, p.G1part + (size_t)blockIdx.x * SB * SB);
+  store_gram(a2, p.G2part + (size_t)blockIdx.x * SB * SB);
+}
+
 // How many ways the K range of the SYMM is cut.  Rounds 2 - 4 took "as many splits as fill the chip" (ceil(512 / T) for T
 // block rows: two workgroups fit a CU); but the T x nsplit workgroups of a launch all walk the same number of tiles, so a
 // launch of 600 of them ran two rounds of which the second was a sixth full (tools/tail_quant.py put 32 of the kernel's
-// 76 ms per solve at N = 16384 into such tails).  Measured per launch for every cut from 1 to 16 (tools/symm_split_table.sh,
+// 76 ms per solve at N = 16384 into such tails).  Measured per launch for every cut from 1 to 16 (round 4, profiles/r04_symm_split_table.csv;
 // one solve each; kernel time summed over the 255 panels, + the partials yred_kernel then reads): at most 4 splits 83.8 ms,
 // 8: 69.5, 12: 65.0, 16: 62.9 (+ 1.9 ms in yred_kernel); the old rule 76.7; the best cut per T picked from the table 61.9.
 // The finer the cut, the better the late workgroups fill the gaps the early ones leave -- so: as fine as the buffer of
-// partial sums allows (maxsplit).  EK_SY2SB_NSPLIT=k: at most k splits; -1: the old rule.
+// partial sums allows (maxsplit).  Round 5 measured the other end too: the whole product as a list of (block row, K slab)
+// units cut into 512 EQUAL consecutive ranges, one per resident workgroup, at most two partial block rows each
+// ("stream-K": no tail at all, a third of the partial sums) -- 283 us per sampled launch against 269 at N = 16384 on one
+// box, C2 38.8 against 38.4 ms: workgroups that all start together and walk in step lose more than the tails cost.
 static void symm_split(int T, int maxsplit, int *nsplit_out, int *tps_out) {
-  static int env = -2;
-  if (env == -2) { const char *e = getenv("EK_SY2SB_NSPLIT"); env = e ? atoi(e) : 0; }
   if (T < 1) T = 1;
   int nsplit = maxsplit;
-  if (env > 0 && env < nsplit) nsplit = env;
-  if (env < 0) nsplit = (T >= 256) ? 2 : ceil_div(512, T);
-  if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit > T) nsplit = T;
   const int tps = ceil_div(T, nsplit);
   *nsplit_out = ceil_div(T, tps); *tps_out = tps;
@@ -1092,7 +1147,7 @@ struct WArgs {
   const double *Y; int ldy; const double *V; int ldv;
   const double *Gred;        // G, stored (j + 64 i) = G(i, j)
   const double *T;           // column-major, ld 64
-  double *Vimg; int ldi;
+  double *W1, *W2; int ldi;  // the two places W goes to in the update's operand images
 };
 __global__ __launch_bounds__(256) void w_kernel(WArgs p) {
   __shared__ double sS[IMG], sM1[IMG], sM2[IMG];
@@ -1157,8 +1212,8 @@ __global__ __launch_bounds__(256) void w_kernel(WArgs p) {
       for (int c = 0; c < 16; ++c) {
         const int col = 16 * cg + c;
         const double w = sS[r * LD + col];
-        p.Vimg[(size_t)row + (size_t)col * p.ldi] = w;
-        p.Vimg[(size_t)row + (size_t)(2 * SB + col) * p.ldi] = w;
+        p.W1[(size_t)row + (size_t)col * p.ldi] = w;
+        p.W2[(size_t)row + (size_t)col * p.ldi] = w;
       }
     }
   }
@@ -1169,6 +1224,7 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 struct Layout {
   int mpad, nparts, maxsplit;
   size_t off_img, off_img2, off_qt, off_y, off_ypart, off_gpart, off_gpart2, off_small, total;
+  size_t off_opa[2] = {0, 0}, off_opb[2] = {0, 0}, off_cg1 = 0, off_cg2 = 0;   // one GPU: operand images of a pair of panels
   // team form (P > 0): the panel message [V | T | tau], the table of the strip updates
   int maxb = 0, npanels = 0;
   size_t off_msg = 0, off_offs = 0, off_dims = 0, off_offs2 = 0, off_dims2 = 0, msg_doubles = 0;
@@ -1177,14 +1233,21 @@ struct Layout {
     nparts = mpad / CH + 1;
     maxsplit = P > 0 ? 56 : 16;          // (team form: up to 8 direct + 48 transposed chunks per block row)
     size_t o = 0;
-    off_img = o; o += al256((size_t)mpad * 3 * SB * 8);
-    off_img2 = o; o += al256((size_t)mpad * 3 * SB * 8);
+    off_img = o; o += (P > 0) ? al256((size_t)mpad * 3 * SB * 8) : 0;      // team form: the [W | V | W] images
+    off_img2 = o; o += (P > 0) ? al256((size_t)mpad * 3 * SB * 8) : 0;
     off_qt = o; o += al256((size_t)mpad * SB * 8);
     off_y = o; o += al256((size_t)mpad * SB * 8);
     off_ypart = o; o += al256((size_t)maxsplit * mpad * SB * 8);
     off_gpart = o; o += al256((size_t)nparts * SB * SB * 8);
     off_gpart2 = o; o += al256((size_t)nparts * SB * SB * 8);
-    off_small = o; o += al256((size_t)16 * SB * SB * 8);   // [10 * 4096 ..): profile counters
+    off_small = o; o += al256((size_t)24 * SB * SB * 8);   // [10 * 4096 ..): profile counters
+    if (P == 0) {
+      // the trailing update's operands for up to two pending panels: A-operand [W1 | V1 | W2 | V2], B-operand
+      // [V1 | W1 | V2 | W2], double-buffered for the look-ahead (in place of the two [W | V | W] images)
+      for (int q = 0; q < 2; ++q) { off_opa[q] = o; o += al256((size_t)mpad * 4 * SB * 8); off_opb[q] = o; o += al256((size_t)mpad * 4 * SB * 8); }
+      off_cg1 = o; o += al256((size_t)nparts * SB * SB * 8);
+      off_cg2 = o; o += al256((size_t)nparts * SB * SB * 8);
+    }
     if (P > 0) {
       maxb = ceil_div(ceil_div(mpad, 128), P) + 1;
       npanels = ceil_div(n > 0 ? n : 1, SB);
@@ -1218,17 +1281,17 @@ void ensure_attrs() {
   attr = true;
 }
 
-// factorisation of the panel at column c0 of A into the image Vimg (V in its columns 64..127), T into Tp, the
-// reflectors into Vall, tau into tau1, issued on stream st
+// factorisation of the panel at column c0 of A: V into the update's operand images at Vd1 and (if not null) Vd2
+// (leading dimension mpad), T into Tp, the reflectors into Vall, tau into tau1, issued on stream st
 void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double *Vall, int ldv, double *tau1, int *d_flag,
-                 int c0, double *Vimg, double *Tp) {
+                 int c0, double *Vd1, double *Vd2, double *Tp) {
   const int n = b.n, ldi = b.mpad;
   const int r0 = c0 + SB, m = n - r0;
   double *Ap = A + (size_t)r0 + (size_t)c0 * lda;
   double *Vp = Vall + (size_t)r0 + (size_t)c0 * ldv;
   const int nch = ceil_div(m, CH);
   if (m <= SMALL_MAX) {
-    SmallArgs sa{m, Ap, lda, Vp, ldv, Vimg, ldi, Tp, tau1 + c0};
+    SmallArgs sa{m, Ap, lda, Vp, ldv, Vd1, Vd2, ldi, Tp, tau1 + c0};
     hipLaunchKernelGGL(house_small_kernel, dim3(1), dim3(256), (SMALL_ROWS * LD + 2 * IMG) * sizeof(double), st, sa);
     return;
   }
@@ -1244,12 +1307,12 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
   hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), st, ha);
   PanelArgs pf{};
   pf.m = m; pf.src = b.Qt; pf.lds_ = b.mpad; pf.M = b.M2; pf.L1 = b.L1; pf.Rband = b.Rband;
-  pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vimg = Vimg; pf.ldi = ldi; pf.pflag = b.pflag;
+  pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vd1 = Vd1; pf.Vd2 = Vd2; pf.ldi = ldi; pf.pflag = b.pflag;
   hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, st, pf);
   // the rescue of a panel CholeskyQR2 could not factor (the four kernels leave at once otherwise)
   hipLaunchKernelGGL(house_tall_kernel, dim3(1), dim3(HT), 0, st, m, Ap, lda, tau1 + c0, b.pflag, d_flag,
                      b.nzrows ? b.nzrows + c0 / SB : nullptr);
-  TallFinishArgs tf{m, Ap, lda, Vp, ldv, Vimg, ldi, b.Gpart2, b.pflag};
+  TallFinishArgs tf{m, Ap, lda, Vp, ldv, Vd1, Vd2, ldi, b.Gpart2, b.pflag};
   hipLaunchKernelGGL(tall_finish_kernel, dim3(nch), dim3(256), 0, st, tf);
   hipLaunchKernelGGL(t_from_gram_kernel, dim3(1), dim3(256), 0, st, nch, b.Gpart2, tau1 + c0, Tp, b.pflag);
 }
@@ -1300,27 +1363,45 @@ int g_dist_la_min = -1;            // rows from which the team form looks ahead 
 
 size_t sy2sb_work_bytes(int n) { return Layout(n).total; }
 
+// Two panels per trailing update (round 5).  The rank-128 update of the trailing matrix reads and writes 16 bytes of it per
+// 128 flops and runs at 37 TFLOP/s; with K = 256 the same kernel does 55 (tools/gemm_shapes.py).  So panels go in PAIRS
+// while the trailing matrix is tall enough for that to matter (pair_min rows):
+//   first panel p : Y = A22 V as before, W; ONLY the next panel's 64 columns are updated (K = 128);
+//   second panel  : factored at once (its chain is exposed: nothing else can run), Y2 = A_stale V2 - W1 (V1^T V2) -
+//                   V1 (W1^T V2) -- the SYMM on the matrix the first panel has NOT updated plus two 64-wide corrections
+//                   (DLATRD's rule; corr_gram_kernel on the second stream beside the SYMM, applied in yred_q_kernel) --, W2;
+//   then ONE update A22' -= [W1 V1 W2 V2] [V1 W1 V2 W2]^T with K = 256, the panel after the pair factored beside it
+//   on the second stream (look-ahead) as before.
+// The operands of the update live in two images per pair (A-operand [W1 | V1 | W2 | V2], B-operand [V1 | W1 | V2 | W2],
+// rows relative to the first panel's trailing matrix, the second panel's blocks 64 rows down), double-buffered over pairs.
+// A panel without a partner (short trailing matrices, the last panel) uses the first two blocks with K = 128: the flow of
+// rounds 2 - 4.
 void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, double *Vall, int ldv, double *tau1,
                  int *d_flag, void *work) {
   if (n <= 2) return;
   ensure_attrs();
   static bool evs = false;
-  static hipEvent_t evA[2], evB[2];
+  static hipEvent_t evA[2], evB[2], evC, evD;
   if (!evs) {
     for (int q = 0; q < 2; ++q) {
       (void)hipEventCreateWithFlags(&evA[q], hipEventDisableTiming);
       (void)hipEventCreateWithFlags(&evB[q], hipEventDisableTiming);
     }
+    (void)hipEventCreateWithFlags(&evC, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&evD, hipEventDisableTiming);
     evs = true;
   }
   const Layout L(n);
   char *w = (char *)work;
-  double *img[2] = {(double *)(w + L.off_img), (double *)(w + L.off_img2)};
+  double *opA[2] = {(double *)(w + L.off_opa[0]), (double *)(w + L.off_opa[1])};
+  double *opB[2] = {(double *)(w + L.off_opb[0]), (double *)(w + L.off_opb[1])};
   double *Qt = (double *)(w + L.off_qt), *Y = (double *)(w + L.off_y);
   double *Ypart = (double *)(w + L.off_ypart), *Gpart = (double *)(w + L.off_gpart);
+  double *Cg1 = (double *)(w + L.off_cg1), *Cg2 = (double *)(w + L.off_cg2);
   double *sm = (double *)(w + L.off_small);
-  double *Gred = sm, *R1 = sm + 4096, *R1inv = sm + 2 * 4096, *M2 = sm + 3 * 4096, *Tm[2] = {sm + 4 * 4096, sm + 9 * 4096},
-         *L1 = sm + 5 * 4096, *Rband = sm + 6 * 4096;
+  double *Gred = sm, *R1 = sm + 4096, *R1inv = sm + 2 * 4096, *M2 = sm + 3 * 4096, *L1 = sm + 5 * 4096, *Rband = sm + 6 * 4096;
+  double *Tm[2][2] = {{sm + 4 * 4096, sm + 7 * 4096}, {sm + 9 * 4096, sm + 8 * 4096}};     // [pair buffer][panel of the pair]
+  double *G1 = sm + 14 * 4096, *G2 = sm + 15 * 4096;
   // panel-chain scratch of the look-ahead stream (its Gram partials must not meet those of yred)
   double *Gpart2 = (double *)(w + L.off_gpart2), *Gred2 = sm + 11 * 4096;
   const int ldi = L.mpad;
@@ -1335,28 +1416,26 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 5120; }
   static int small_max = -1;
   if (small_max < 0) { const char *e = getenv("EK_SY2SB_SMALL_MAX"); small_max = e ? atoi(e) : 4096; }   // N = 4096: stage 14.6 -> 13.9 ms
+  int pair_min = 5120;             // rows of the first panel's trailing matrix from which panels go in pairs (0: never)
+  { const char *e = getenv("EK_SY2SB_PAIR_MIN"); if (e) pair_min = atoi(e); }      // (read per call: the tests force pairs at small orders)
 
   int *nzrows = (int *)(sm + 13 * 4096);               // one word per panel (room for 8192)
   (void)hipMemsetAsync(nzrows, 0, (size_t)ceil_div(n, SB) * sizeof(int), s);
   const ChainBufs cb{n, L.mpad, Qt, Gpart2, Gred2, R1, R1inv, M2, L1, Rband, prof ? (long long *)(sm + 10 * 4096) : nullptr,
                      (int *)(sm + 12 * 4096), nzrows};
-  auto panel_chain = [&](hipStream_t st, int c0, double *Vimg, double *Tp) {
-    ek::panel_chain(st, cb, A, lda, Vall, ldv, tau1, d_flag, c0, Vimg, Tp);
+  // block j (0..3) of an operand image, from image row `row` on
+  auto blk = [&](double *img, int j, int row) -> double * { return img + (size_t)row + (size_t)j * SB * ldi; };
+  // chain of the panel at column c0 as panel q (0 / 1) of the pair held in buffer pb
+  auto chain = [&](hipStream_t st, int c0, int pb, int q) {
+    ek::panel_chain(st, cb, A, lda, Vall, ldv, tau1, d_flag, c0, blk(opA[pb], 2 * q + 1, SB * q), blk(opB[pb], 2 * q, SB * q),
+                    Tm[pb][q]);
   };
-
-  panel_chain(s, 0, img[0], Tm[0]);
-  bool waited = true;        // whether stream s already follows the chain of the current panel
-  int p = 0;
-  for (int c0 = 0; ; c0 += SB, ++p) {
-    const int r0 = c0 + SB, m = n - r0;
-    if (m < 2) break;
-    const int cur = p & 1;
-    double *Vimg = img[cur];
-    if (!waited) (void)hipStreamWaitEvent(s, evB[cur], 0);
+  // Y = A22 V for the trailing matrix at r0 (m rows), V = panel q of buffer pb; then W into the images.  corr: the
+  // matrix is stale by the pair's first panel (q == 1)
+  auto symm_and_w = [&](int p, int r0, int m, int pb, int q, bool corr) {
     const int nch = ceil_div(m, CH);
-    // Y = A22 V, cut over K as finely as the buffer of partial sums allows (symm_split)
     double *A22 = A + (size_t)r0 + (size_t)r0 * lda;
-    const double *V = Vimg + (size_t)SB * ldi;
+    const double *V = blk(opA[pb], 2 * q + 1, SB * q);
     const int T = ceil_div(m, 128);
     int nsplit, tps;
     symm_split(T, L.maxsplit, &nsplit, &tps);
@@ -1366,36 +1445,71 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
     hipLaunchKernelGGL(symm_lower_kernel<false>, dim3(T, nsplit), dim3(256), 0, s, sy);
     if (timed) kprof_end(s, kProfSymm);
     YredArgs ya{m, nsplit, Ypart, L.mpad, (long long)L.mpad * SB, Y, V, ldi, Gpart};
-    hipLaunchKernelGGL(yred_q_kernel, dim3(nch, 4), dim3(256), 0, s, ya);      // (C3: stage 0.2297 -> 0.2278 s, C2 39.05 -> 38.55 ms; same bits)
+    if (corr) {
+      ya.cW = blk(opA[pb], 0, SB); ya.cV = blk(opA[pb], 1, SB); ya.ldc = ldi; ya.cG1 = G1; ya.cG2 = G2;
+      (void)hipStreamWaitEvent(s, evD, 0);
+    }
+    hipLaunchKernelGGL(yred_q_kernel, dim3(nch, 4), dim3(256), 0, s, ya);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s, nch, Gpart, Gred);
-    WArgs wa{m, Y, L.mpad, V, ldi, Gred, Tm[cur], Vimg, ldi};
+    WArgs wa{m, Y, L.mpad, V, ldi, Gred, Tm[pb][q], blk(opA[pb], 2 * q, SB * q), blk(opB[pb], 2 * q + 1, SB * q), ldi};
     hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
-    // A22 -= W V^T + V W^T = [W | V] [V | W]^T, lower triangle.  With look-ahead the first block column is
-    // updated first and the NEXT panel is factored on the second stream while the rest is updated.
+  };
+  // A(r0.., r0..) -= opA(rows off.., K columns) opB(rows off.., K columns)^T on the lower triangle, with the look-ahead:
+  // the next panel's 64 columns first, then its chain on the second stream beside the rest
+  bool waited = true;        // whether stream s already follows the chain of the panel it is about to use
+  auto update = [&](int r0, int m, int pb, int off, int K, int next_pb) {
+    double *A22 = A + (size_t)r0 + (size_t)r0 * lda;
+    const double *P1 = opA[pb] + off, *P2 = opB[pb] + off;
     const bool has_next = m - SB >= 2;
-    const double *P1 = Vimg, *P2 = Vimg + (size_t)SB * ldi;
     if (has_next && m >= la_min) {
-      static int fc_small = -1;
-      if (fc_small < 0) { const char *e = getenv("EK_SY2SB_FIRSTCOL_SMALL"); fc_small = e ? atoi(e) : 1; }
-      // (the next panel's 64 columns: m / 64 workgroups of the 64 x 64 tiling instead of m / 128 of the 128 x 128 one, whose
-      // launch lasts a whole tile time however narrow the product)
-      gemm(s, false, true, m, SB, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true, false, /*small_tiles=*/fc_small != 0);
-      (void)hipEventRecord(evA[cur], s);
-      // (host order: the rest of the update first, then the eleven launches of the chain -- submitted behind them the
+      gemm(s, false, true, m, SB, K, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true, false, /*small_tiles=*/true);
+      (void)hipEventRecord(evA[pb], s);
+      // (host order: the rest of the update first, then the launches of the chain -- submitted behind them the
       // update would start ~70 us late on every panel)
-      gemm(s, false, true, m - SB, m - SB, 2 * SB, -1.0, P1 + SB, ldi, P2 + SB, ldi, 1.0,
+      gemm(s, false, true, m - SB, m - SB, K, -1.0, P1 + SB, ldi, P2 + SB, ldi, 1.0,
            A22 + (size_t)SB + (size_t)SB * lda, lda, true, /*staged_rank_k=*/m < staged_max);
-      (void)hipStreamWaitEvent(s2, evA[cur], 0);
-      panel_chain(s2, r0, img[cur ^ 1], Tm[cur ^ 1]);
-      (void)hipEventRecord(evB[cur ^ 1], s2);
+      (void)hipStreamWaitEvent(s2, evA[pb], 0);
+      chain(s2, r0, next_pb, 0);
+      (void)hipEventRecord(evB[next_pb], s2);
       waited = false;
     } else {
       // (short trailing matrices: the 64 x 64 tiling -- a launch of the 128 x 128 one lasts one tile time, 44 us, however
       // few tiles there are)
-      gemm(s, false, true, m, m, 2 * SB, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true, false, /*small_tiles=*/m <= small_max);
-      if (has_next) panel_chain(s, r0, img[cur ^ 1], Tm[cur ^ 1]);
+      gemm(s, false, true, m, m, K, -1.0, P1, ldi, P2, ldi, 1.0, A22, lda, true, false, /*small_tiles=*/m <= small_max);
+      if (has_next) chain(s, r0, next_pb, 0);
       waited = true;
     }
+  };
+
+  chain(s, 0, 0, 0);
+  int p = 0, pb = 0;
+  for (int c0 = 0; ; ) {
+    const int r0 = c0 + SB, m = n - r0;
+    if (m < 2) break;
+    if (!waited) (void)hipStreamWaitEvent(s, evB[pb], 0);
+    symm_and_w(p, r0, m, pb, 0, false);
+    const int m2 = m - SB;                        // the second panel's trailing matrix
+    if (pair_min > 0 && m >= pair_min && m2 >= 2) {
+      // the second panel's 64 columns alone, its chain, the products of the correction beside its SYMM
+      double *A22 = A + (size_t)r0 + (size_t)r0 * lda;
+      gemm(s, false, true, m, SB, 2 * SB, -1.0, opA[pb], ldi, opB[pb], ldi, 1.0, A22, lda, true, false, /*small_tiles=*/true);
+      chain(s, r0, pb, 1);
+      (void)hipEventRecord(evC, s);
+      (void)hipStreamWaitEvent(s2, evC, 0);
+      const int nch2 = ceil_div(m2, CH);
+      CorrGramArgs cg{m2, blk(opA[pb], 1, SB), blk(opA[pb], 0, SB), blk(opA[pb], 3, SB), ldi, Cg1, Cg2};
+      hipLaunchKernelGGL(corr_gram_kernel, dim3(nch2), dim3(256), 0, s2, cg);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s2, nch2, Cg1, G1);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s2, nch2, Cg2, G2);
+      (void)hipEventRecord(evD, s2);
+      symm_and_w(p + 1, r0 + SB, m2, pb, 1, true);
+      update(r0 + SB, m2, pb, SB, 4 * SB, pb ^ 1);
+      c0 += 2 * SB; p += 2;
+    } else {
+      update(r0, m, pb, 0, 2 * SB, pb ^ 1);
+      c0 += SB; p += 1;
+    }
+    pb ^= 1;
   }
   if (getenv("EK_SY2SB_PROF")) {
     long long h[10];
@@ -1516,7 +1630,8 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
       if (mem[q].rank != owner) continue;
       St &M = st[q];
       hipEvent_t e0 = g_dprof.on ? g_dprof.mark(sp) : nullptr;
-      panel_chain(sp, M.cb, mem[q].A, mem[q].lda, mem[q].Vall, mem[q].ldv, mem[q].tau1, mem[q].d_flag, c0, M.img[buf], M.Tm[buf]);
+      panel_chain(sp, M.cb, mem[q].A, mem[q].lda, mem[q].Vall, mem[q].ldv, mem[q].tau1, mem[q].d_flag, c0,
+                  M.img[buf] + (size_t)SB * ldi, nullptr, M.Tm[buf]);
       if (P > 1) {                      // (only the m rows of the panel travel: V is packed with leading dimension ldy)
         copy_matrix(sp, m, SB, M.img[buf] + (size_t)SB * ldi, ldi, M.msg, ldy);
         (void)hipMemcpyAsync(M.msg + vcount, M.Tm[buf], (size_t)SB * SB * 8, hipMemcpyDeviceToDevice, sp);
@@ -1596,7 +1711,7 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
         hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, yb);
       }
       hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s, nch, M.Gpart, M.sm);
-      WArgs wa{m, M.Y, ldy, V, ldi, M.sm, M.Tm[cur], M.img[cur], ldi};
+      WArgs wa{m, M.Y, ldy, V, ldi, M.sm, M.Tm[cur], M.img[cur], M.img[cur] + (size_t)2 * SB * ldi, ldi};
       hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
     }
     const bool has_next = m - SB >= 2;

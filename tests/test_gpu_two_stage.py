@@ -58,6 +58,43 @@ def test_dense_to_band_is_an_orthogonal_similarity(hip, oracle, n):
         assert np.all(V[:j + B, j] == 0.0) and (tau[j] == 0.0 or V[j + B, j] == 1.0)
 
 
+@pytest.mark.parametrize("n,kind", [(n, k) for k in ("synth", "graded", "band65", "parallel_columns") for n in (130, 193, 194, 257, 449)]
+                         + [(1000, "synth"), (1000, "band65"), (1345, "synth")])
+def test_dense_to_band_with_panels_in_pairs(hip, oracle, monkeypatch, n, kind):
+    """From 5120 rows on the stage takes its panels in pairs: the second panel's Y = A V comes from the matrix the first
+    panel has NOT yet updated plus two 64-wide corrections (DLATRD's rule), and one rank-256 update serves both.  Forced
+    at every order here (EK_SY2SB_PAIR_MIN=1: every panel that has a successor is the first of a pair, so pairs also end
+    on the in-LDS panels, on rescued panels and on the last panel): the same identities as the one-panel flow, and its
+    spectrum."""
+    rng = np.random.default_rng(n)
+    A = oracle.synth_matrix(n, 1)
+    if kind == "graded":
+        s = 10.0 ** (-6.0 * np.arange(n) / n)
+        A = A * s[:, None] * s[None, :]
+    elif kind == "band65":
+        M = np.tril(rng.standard_normal((n, n))); M = M - np.tril(M, -66); A = M + np.tril(M, -1).T
+    elif kind == "parallel_columns":
+        A[64:, 5] = A[64:, 4] * (1.0 + 1e-7); A[5, 64:] = A[64:, 5]
+        if n > 200:
+            A[140:, 70] = A[140:, 69] + 1e-6 * rng.standard_normal(n - 140); A[70, 140:] = A[140:, 70]
+    monkeypatch.setenv("EK_SY2SB_PAIR_MIN", "0")
+    Ab0, V0, tau0, flag0 = hip.sy2sb(A)
+    monkeypatch.setenv("EK_SY2SB_PAIR_MIN", "1")
+    Ab, V, tau, flag = hip.sy2sb(A)
+    assert flag & 0xff == 0 and flag0 & 0xff == 0
+    assert np.abs(np.tril(Ab, -(B + 1))).max() == 0.0
+    Bd = _band_of(Ab)
+    Q = _q_from_reflectors(V, tau)
+    nrm = np.linalg.norm(A)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 64 * n * EPS
+    assert np.linalg.norm(Q.T @ A @ Q - Bd) <= 32 * n * EPS * nrm
+    w0, w1, w2 = np.linalg.eigvalsh(A), np.linalg.eigvalsh(Bd), np.linalg.eigvalsh(_band_of(Ab0))
+    assert np.abs(w0 - w1).max() <= 4 * n * EPS * np.abs(w0).max()
+    assert np.abs(w2 - w1).max() <= 4 * n * EPS * np.abs(w0).max()
+    # the first panel of the stage is factored before anything is pending: same bits in both flows
+    assert np.array_equal(V[:, :B], V0[:, :B]) and np.array_equal(tau[:B], tau0[:B])
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 65, 66, 100, 129, 200, 321, 640, 1000])
 def test_band_to_tridiagonal_by_bulge_chasing(hip, n):
     Bd = _random_band(n, n)
