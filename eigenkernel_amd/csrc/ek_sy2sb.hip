@@ -519,8 +519,14 @@ __device__ __forceinline__ void ht_reduce(double (&a)[K], double *s_part /* [HT 
 // nz: 1 + the last 64-row chunk of the panel with a non-zero entry (panel_kernel<0>): the rows below are exactly zero and
 // stay zero under every reflector, so the walk stops there -- the panels of a matrix that is nearly a band (the
 // reference's sparse Hamiltonians) cost a few hundred rows each instead of the full height.
+// The outputs of a rescued panel (round 5: by the same single workgroup, behind the factorisation -- until round 4 two more
+// predicated launches, tall_finish_kernel over the chunks and t_from_gram_kernel, which cost EVERY panel of every matrix
+// two empty launches, 10 us of a chain that is 120 - 200 us long): V into the update's operand images and the reflector
+// matrix, R alone left in the panel, T (column-major, ld 64) from G = V^T V by DLARFT's forward columnwise recurrence.
+struct TallOut { double *Vall; int ldv; double *Vd1, *Vd2; int ldi; double *T; };
 __global__ __launch_bounds__(HT) void house_tall_kernel(int m_full, double *__restrict__ P, int ldp, double *__restrict__ tau_out,
-                                                        const int *pflag, int *d_flag, const int *nz) {
+                                                        const int *pflag, int *d_flag, const int *nz, TallOut out) {
+  extern __shared__ double ht_smem[];                      // two 64 x 64 images (the finish): sV / sT, sG
   __shared__ double s_part[(HT / 64) * HB * HB], s_out[HB * HB];
   __shared__ double s_T[HB * HB], s_X[HB * HB], s_tau[SB];
   if (!*pflag) return;
@@ -528,10 +534,10 @@ __global__ __launch_bounds__(HT) void house_tall_kernel(int m_full, double *__re
   int m = m_full;
   if (nz) { const int me = *nz * SB; if (me < m) m = (me > SB + 1) ? me : ((SB + 1 < m) ? SB + 1 : m); }
   if (t == 0) atomicAdd(d_flag, 256);                      // bits 8..: panels that took this path (informational)
-  if (*pflag & 4) {                                        // the panel is exactly zero: R = 0, H = I
-    if (t < SB) tau_out[t] = 0.0;
-    return;
-  }
+  const bool zero_panel = (*pflag & 4) != 0;               // the panel is exactly zero: R = 0, H = I
+  if (t < SB) { s_tau[t] = 0.0; if (zero_panel) tau_out[t] = 0.0; }
+  __syncthreads();
+  if (!zero_panel) {
   auto vget = [&](int r, int j) -> double {                // entry (r, j) of the unit lower trapezoidal V
     return (r > j) ? P[(size_t)r + (size_t)j * ldp] : (r == j ? 1.0 : 0.0);
   };
@@ -649,77 +655,59 @@ __global__ __launch_bounds__(HT) void house_tall_kernel(int m_full, double *__re
       __syncthreads();
     }
   }
-}
-
-// the outputs of a rescued panel: V into the image and the reflector matrix, R alone left in the panel, Gram partials
-// of V for its T factor
-struct TallFinishArgs {
-  int m; double *Apanel; int lda; double *Vall; int ldv; double *Vd1, *Vd2; int ldi; double *Gpart; const int *pflag;
-};
-__global__ __launch_bounds__(256) void tall_finish_kernel(TallFinishArgs p) {
-  __shared__ double sV[IMG];
-  if (!*p.pflag) return;
-  const int t = threadIdx.x, r = t & 63, cg = t >> 6;
-  double4_t acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  for (int slab = 0; slab < CH / SB; ++slab) {
-    const int row0 = blockIdx.x * CH + slab * SB;
-    if (row0 >= p.m) break;
-    const int row = row0 + r;
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const int col = 16 * cg + c;
-      double v = 0.0;
-      if (row < p.m) {
-        const double x = p.Apanel[(size_t)row + (size_t)col * p.lda];
-        v = (row > col) ? x : (row == col ? 1.0 : 0.0);
-        p.Apanel[(size_t)row + (size_t)col * p.lda] = (row <= col) ? x : 0.0;
-        p.Vall[(size_t)row + (size_t)col * p.ldv] = v;
-        p.Vd1[(size_t)row + (size_t)col * p.ldi] = v;
-        if (p.Vd2) p.Vd2[(size_t)row + (size_t)col * p.ldi] = v;
-      }
-      sV[r * LD + col] = v;
-    }
-    __syncthreads();
-    slab_gram(sV, sV, acc);
-  }
-  store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
-}
-
-// T (column-major, ld 64) of a rescued panel from G = V^T V -- the sum, in a fixed order, of the npart partial Gram
-// matrices tall_finish_kernel left (this one workgroup adds them itself: a launch of reduce_parts_kernel in front of it
-// cost every panel of every matrix 4.7 us to save the rare rescued panel ~0.1 ms) -- and tau (DLARFT, forward columnwise)
-__global__ __launch_bounds__(256) void t_from_gram_kernel(int npart, const double *__restrict__ Gpart, const double *__restrict__ tau,
-                                                          double *__restrict__ T, const int *pflag) {
-  __shared__ double sG[IMG], sT[IMG], s_tau[SB];
-  if (!*pflag) return;
-  const int t = threadIdx.x;
-  for (int idx = t; idx < SB * SB; idx += 256) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int q = 0;
-    for (; q + 4 <= npart; q += 4) {
-      a0 += Gpart[(size_t)q * 4096 + idx]; a1 += Gpart[(size_t)(q + 1) * 4096 + idx];
-      a2 += Gpart[(size_t)(q + 2) * 4096 + idx]; a3 += Gpart[(size_t)(q + 3) * 4096 + idx];
-    }
-    for (; q < npart; ++q) a0 += Gpart[(size_t)q * 4096 + idx];
-    sG[(idx >> 6) * LD + (idx & 63)] = (a0 + a1) + (a2 + a3); sT[(idx >> 6) * LD + (idx & 63)] = 0.0;
-  }
-  if (t < SB) s_tau[t] = tau[t];
+  }   // (!zero_panel)
   __syncthreads();
-  for (int i = 0; i < SB; ++i) {
-    const double ti = s_tau[i];
-    if (t < i) {
-      double a = 0.0;
-      for (int l = t; l < i; ++l) a += sT[t * LD + l] * sG[l * LD + i];
-      sT[t * LD + i] = -ti * a;
-    } else if (t == i) sT[i * LD + i] = ti;
+  // ---- the finish: chunk by chunk over ALL rows of the panel (the images may hold an earlier panel's numbers below m)
+  double *sV = ht_smem, *sG = ht_smem + IMG;
+  {
+    const int r = t & 63, cg = t >> 6;                     // eight waves: row r, columns 8 cg .. 8 cg + 7
+    double4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int row0 = 0; row0 < m_full; row0 += SB) {
+      const int row = row0 + r;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int col = 8 * cg + c;
+        double v = 0.0;
+        if (row < m_full) {
+          const double x = P[(size_t)row + (size_t)col * ldp];
+          v = (row > col) ? x : (row == col ? 1.0 : 0.0);
+          P[(size_t)row + (size_t)col * ldp] = (row <= col) ? x : 0.0;
+          out.Vall[(size_t)row + (size_t)col * out.ldv] = v;
+          out.Vd1[(size_t)row + (size_t)col * out.ldi] = v;
+          if (out.Vd2) out.Vd2[(size_t)row + (size_t)col * out.ldi] = v;
+        }
+        sV[r * LD + col] = v;
+      }
+      __syncthreads();
+      if (t < 256) slab_gram(sV, sV, acc);
+    }
     __syncthreads();
-  }
-  for (int idx = t; idx < SB * SB; idx += 256) {
-    const int i = idx & 63, j = idx >> 6;
-    T[idx] = sT[i * LD + j];
+    if (t < 256) {
+      const int lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sG[(16 * wave + l4 + 4 * q) * LD + 16 * jt + l15] = acc[jt][q];
+    }
+    double *sT = sV;
+    for (int idx = t; idx < IMG; idx += HT) sT[idx] = 0.0;
+    __syncthreads();
+    for (int i = 0; i < SB; ++i) {
+      const double ti = s_tau[i];
+      if (t < i) {
+        double a = 0.0;
+        for (int l = t; l < i; ++l) a += sT[t * LD + l] * sG[l * LD + i];
+        sT[t * LD + i] = -ti * a;
+      } else if (t == i) sT[i * LD + i] = ti;
+      __syncthreads();
+    }
+    for (int idx = t; idx < SB * SB; idx += HT) {
+      const int i = idx & 63, j = idx >> 6;
+      out.T[idx] = sT[i * LD + j];
+    }
   }
 }
 
@@ -1278,6 +1266,8 @@ void ensure_attrs() {
                             4 * IMG * (int)sizeof(double));
   (void)hipFuncSetAttribute((const void *)house_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (SMALL_ROWS * LD + 2 * IMG) * (int)sizeof(double));
+  (void)hipFuncSetAttribute((const void *)house_tall_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * IMG * (int)sizeof(double));
   attr = true;
 }
 
@@ -1309,12 +1299,10 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
   pf.m = m; pf.src = b.Qt; pf.lds_ = b.mpad; pf.M = b.M2; pf.L1 = b.L1; pf.Rband = b.Rband;
   pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vd1 = Vd1; pf.Vd2 = Vd2; pf.ldi = ldi; pf.pflag = b.pflag;
   hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, st, pf);
-  // the rescue of a panel CholeskyQR2 could not factor (the four kernels leave at once otherwise)
-  hipLaunchKernelGGL(house_tall_kernel, dim3(1), dim3(HT), 0, st, m, Ap, lda, tau1 + c0, b.pflag, d_flag,
-                     b.nzrows ? b.nzrows + c0 / SB : nullptr);
-  TallFinishArgs tf{m, Ap, lda, Vp, ldv, Vd1, Vd2, ldi, b.Gpart2, b.pflag};
-  hipLaunchKernelGGL(tall_finish_kernel, dim3(nch), dim3(256), 0, st, tf);
-  hipLaunchKernelGGL(t_from_gram_kernel, dim3(1), dim3(256), 0, st, nch, b.Gpart2, tau1 + c0, Tp, b.pflag);
+  // the rescue of a panel CholeskyQR2 could not factor (one workgroup; it leaves at once otherwise)
+  const TallOut to{Vp, ldv, Vd1, Vd2, ldi, Tp};
+  hipLaunchKernelGGL(house_tall_kernel, dim3(1), dim3(HT), 2 * IMG * sizeof(double), st, m, Ap, lda, tau1 + c0, b.pflag, d_flag,
+                     b.nzrows ? b.nzrows + c0 / SB : nullptr, to);
 }
 
 // team form: the strips a member updates after panel p (batched GEMM: one problem per owned strip that still has
