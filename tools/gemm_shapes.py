@@ -18,6 +18,10 @@ h = n // 2
 shapes = [
     ("SYR2K of a panel, one stage (K=128, lower)          C(n,n) -= P1 P2^T", 0, 1, n, n, 128, 1.0, 1, 0.5),
     ("SYR2K of the dense->band stage at m = n/2           C(m,m) -= [W|V][V|W]^T", 0, 1, h, h, 128, 1.0, 1, 0.5),
+    ("the same update for TWO panels at once (K = 256)     C(n,n) -= [W1 V1 W2 V2][V1 W1 V2 W2]^T", 0, 1, n, n, 256, 1.0, 1, 0.5),
+    ("... K = 512                                          (four panels)", 0, 1, n, n, 512, 1.0, 1, 0.5),
+    ("... K = 128 without reading C (beta = 0)             what the read of C costs", 0, 1, n, n, 128, 0.0, 1, 0.5),
+    ("... K = 64                                           the floor of a pass over the triangle", 0, 1, n, n, 64, 1.0, 1, 0.5),
     ("back-transformation, W1 = V_b^T Z                   (512 x n) = (n x 512)^T (n x n)", 1, 0, 512, n, n, 0.0, 0, 1.0),
     ("back-transformation, Z -= V_b W2                     (n x n) -= (n x 512)(512 x n)", 0, 0, n, n, 512, 1.0, 0, 1.0),
     ("triangular solve / Cholesky update, half size        (n/2)^3, C -= A B", 0, 0, h, h, h, 1.0, 0, 1.0),
