@@ -61,7 +61,10 @@ struct PanelArgs {
   double *Vall; int ldv;    // explicit reflector matrix of the back-transformation, at (r0, c0)
   double *Apanel; int lda;  // the panel inside A, at (r0, c0)
   double *Vd1, *Vd2; int ldi;   // where V goes in the update's operand images (column 0 of the panel's block; Vd2 may be null)
-  const int *pflag;         // FINAL pass: non-zero = this panel goes to the rescue: leave it untouched
+  const int *pflag;         // FINAL pass: non-zero = this panel was factored by the rescue (house_tall_kernel): its outputs
+  const double *tau;        //   are V (from the panel's storage), R alone left in the panel, and T from tau and V^T V (the last
+  double *Tout;             //   workgroup to finish sums the chunks' partial products in a fixed order)
+  unsigned *arrived;        //   (a counter that is zero between launches)
   int *nz;                  // MODE 0: *nz = 1 + the last 64-row chunk of the panel that is not all zeros (atomic max)
 };
 
@@ -153,7 +156,73 @@ template <int MODE>
 __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p) {
   __shared__ double sS[IMG], sO[IMG], sMT[MODE ? IMG : 1], s_rd[MODE == 1 ? SB : 1];
   const int t = threadIdx.x, r = t & 63, cg = t >> 6;
-  if (MODE == 2 && p.pflag && *p.pflag) return;
+  if (MODE == 2 && p.pflag && *p.pflag) {
+    // ---- the outputs of a rescued panel (DGEQR2's storage in the panel, tau)
+    double4_t ga[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ga[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int slab = 0; slab < CH / SB; ++slab) {
+      const int row0 = blockIdx.x * CH + slab * SB;
+      if (row0 >= p.m) break;
+      const int row = row0 + r;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int col = 16 * cg + c;
+        double v = 0.0;
+        if (row < p.m) {
+          const double x = p.Apanel[(size_t)row + (size_t)col * p.lda];
+          v = (row > col) ? x : (row == col ? 1.0 : 0.0);
+          p.Apanel[(size_t)row + (size_t)col * p.lda] = (row <= col) ? x : 0.0;
+          p.Vall[(size_t)row + (size_t)col * p.ldv] = v;
+          p.Vd1[(size_t)row + (size_t)col * p.ldi] = v;
+          if (p.Vd2) p.Vd2[(size_t)row + (size_t)col * p.ldi] = v;
+        }
+        sS[r * LD + col] = v;
+      }
+      __syncthreads();
+      slab_gram(sS, sS, ga);
+    }
+    store_gram(ga, p.Gpart + (size_t)blockIdx.x * SB * SB);
+    // the last workgroup to arrive forms T = DLARFT(V, tau) from the sum of the partial products
+    __shared__ unsigned s_last;
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_last = (atomicAdd(p.arrived, 1u) + 1u == gridDim.x) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (t == 0) *p.arrived = 0u;
+    double *sG = sO, *sT = sMT;
+    __shared__ double s_tau[SB];
+    const int npart = (int)gridDim.x;
+    for (int idx = t; idx < SB * SB; idx += 256) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int q = 0;
+      for (; q + 4 <= npart; q += 4) {
+        a0 += p.Gpart[(size_t)q * 4096 + idx]; a1 += p.Gpart[(size_t)(q + 1) * 4096 + idx];
+        a2 += p.Gpart[(size_t)(q + 2) * 4096 + idx]; a3 += p.Gpart[(size_t)(q + 3) * 4096 + idx];
+      }
+      for (; q < npart; ++q) a0 += p.Gpart[(size_t)q * 4096 + idx];
+      sG[(idx >> 6) * LD + (idx & 63)] = (a0 + a1) + (a2 + a3); sT[(idx >> 6) * LD + (idx & 63)] = 0.0;
+    }
+    if (t < SB) s_tau[t] = p.tau[t];
+    __syncthreads();
+    for (int i = 0; i < SB; ++i) {
+      const double ti = s_tau[i];
+      if (t < i) {
+        double a = 0.0;
+        for (int l = t; l < i; ++l) a += sT[t * LD + l] * sG[l * LD + i];
+        sT[t * LD + i] = -ti * a;
+      } else if (t == i) sT[i * LD + i] = ti;
+      __syncthreads();
+    }
+    for (int idx = t; idx < SB * SB; idx += 256) {
+      const int i = idx & 63, j = idx >> 6;
+      p.Tout[idx] = sT[i * LD + j];
+    }
+    return;
+  }
   if (MODE == 1) {                                   // sMT(i, j) = R1(i, j) as stored (column-major in memory), 1 / diagonal
     for (int idx = t; idx < SB * SB; idx += 256) sMT[(idx & 63) * LD + (idx >> 6)] = p.M[idx];
     if (t < SB) s_rd[t] = 1.0 / p.M[t + SB * t];
@@ -244,7 +313,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(int npart, const doub
 // cannot factor goes to the Householder rescue below)
 __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G, double *__restrict__ R,
                                                    double *__restrict__ Rinv, int *pflag, const int *nz) {
-  __shared__ double sA[IMG], sB[IMG];
+  __shared__ double sA[IMG];                               // (one image: 42 KB fit beside both workgroups of an update)
   __shared__ double s_inv[kScratch];
   const int t = threadIdx.x;
   double gv[16];
@@ -264,7 +333,7 @@ __global__ __launch_bounds__(256) void chol_kernel(const double *__restrict__ G,
   const int zero_panel = !s_nz;
   const int bad = chol64_upper_wg(sA, s_inv);
   if (t == 0) *pflag = zero_panel ? 4 : ((bad >= 0) ? 1 : 0);
-  (void)Rinv; (void)sB;                                    // (no explicit inverse: the panel is divided by R1 by substitution)
+  (void)Rinv;                                              // (no explicit inverse: the panel is divided by R1 by substitution)
   __syncthreads();
   for (int idx = t; idx < SB * SB; idx += 256) {
     const int i = idx & 63, j = idx >> 6;
@@ -280,9 +349,16 @@ struct HrArgs {
   int *flag;
   long long *prof;   // optional: shader cycles per phase
 };
-__global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
+// LDS: THREE 64 x 64 images (round 5; four until round 4).  With 135 KB the workgroup could only start on a CU that BOTH
+// resident workgroups of a trailing update had left, and a freed slot went to the update's next workgroup first: beside
+// an 8-wave update the launch lasted until the update's grid had drained (trace: 475 us against 44 alone), so the chain
+// of the look-ahead ended AFTER the update it was to hide behind.  110 KB fit a CU as soon as one of the two has left.
+// And 256 registers instead of 357 (the four waves of an update's workgroup leave 256 per SIMD lane).  What made room: Q top
+// passes through the accumulators, R1 arrives late, and R2 R1 is formed early and waits in its place in memory for the
+// signs.  The same operations on the same operands: same bits.
+__global__ __launch_bounds__(256, 2) void hr_kernel(HrArgs p) {
   extern __shared__ double smem[];
-  double *sA = smem, *sB = smem + IMG, *sC = smem + 2 * IMG, *sD = smem + 3 * IMG;
+  double *sA = smem, *sB = smem + IMG, *sC = smem + 2 * IMG;
   __shared__ double s_sign[SB];
   __shared__ double s_red[4];
   __shared__ double s_inv[kScratch];
@@ -292,13 +368,12 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   if (prof) tc[nt++] = clock64();
   // G2 and its distance from the identity: the loss of orthogonality of the first pass
   double dev = 0.0;
-  double gv[16], qv[16], r1v[16];               // all loads of the kernel in flight at once; R1 is used last
+  double gv[16], qv[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int idx = t + 256 * k;
     gv[k] = p.G2[idx];
     qv[k] = p.Qt[(size_t)(idx & 63) + (size_t)(idx >> 6) * p.ldq];
-    r1v[k] = p.R1[idx];
   }
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
@@ -340,7 +415,31 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
     triinv64_upper_wg(sA, sB, s_inv);                                    // sB = R2^-1
     if (prof) tc[nt++] = clock64();
   }
-  mm64(sC, false, sB, false, sD);                                       // sD = Q top = Qt_top R2^-1
+  // Q top = Qt_top R2^-1 into the accumulators; then R1 takes the place of Qt's top block and R2 R1 is formed while R2
+  // is still there (the signs it is scaled by come from the LU below); then Q top takes R2's place
+  double r1v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) r1v[k] = p.R1[t + 256 * k];               // (in flight during the first product)
+  double4_t qacc[4], rr[4];
+  mm64_acc(sC, false, sB, false, qacc);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {                                        // sC = R1
+    const int idx = t + 256 * k;
+    sC[(idx & 63) * LD + (idx >> 6)] = r1v[k];
+  }
+  __syncthreads();
+  mm64_acc(sA, false, sC, false, rr);                                   // R2 R1
+  {                                                                     // (parked where it belongs; this thread scales its
+    const int l15 = lane & 15, l4 = lane >> 4, i0 = 16 * wave;          // own entries once the signs are known)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p.Rband[(i0 + l4 + 4 * r) + SB * (16 * jt + l15)] = rr[jt][r];
+  }
+  __syncthreads();
+  double *sD = sA;                                                       // (R2 has served)
+  mm64_store(qacc, sD);                                                 // sD = Q top
   __syncthreads();
   if (prof) tc[nt++] = clock64();
   lu64_signed_wg(sD, s_sign, s_inv);                               // sD = L1 \ U of (Q_top - S)
@@ -358,16 +457,19 @@ __global__ __launch_bounds__(256) void hr_kernel(HrArgs p) {
   }
   __syncthreads();
   triinv64_upper_wg(sD, sC, s_inv);                                      // sC = U^-1
-  if (prof) tc[nt++] = clock64();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {                                        // sD = R1
-    const int idx = t + 256 * k;
-    sD[(idx & 63) * LD + (idx >> 6)] = r1v[k];
-  }
-  if (prof) tc[nt++] = clock64();
+  if (prof) { tc[nt++] = clock64(); tc[nt++] = clock64(); }
   __syncthreads();
   mm64(sB, false, sC, false, nullptr, p.M2);                            // M2 = R2^-1 U^-1
-  mm64(sA, false, sD, false, nullptr, p.Rband, s_sign);                 // S R2 R1
+  {                                                                     // S R2 R1
+    const int l15 = lane & 15, l4 = lane >> 4, i0 = 16 * wave;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + l4 + 4 * r, j = 16 * jt + l15;
+        p.Rband[i + SB * j] = s_sign[i] * p.Rband[i + SB * j];
+      }
+  }
   if (prof) { tc[nt++] = clock64(); for (int q = 0; q + 1 < nt; ++q) p.prof[q] += tc[q + 1] - tc[q]; p.prof[9] += 1; }
 }
 
@@ -494,7 +596,7 @@ __global__ __launch_bounds__(256) void house_small_kernel(SmallArgs p) {
 // a time (two passes).  About 15 passes of the panel's bytes through one compute unit: 1 - 3 ms for the largest
 // panels, paid only by the panels that need it (the kernels below leave at once when the panel's flag is clear).
 // In place: R in the upper triangle, the reflectors below the diagonal (DGEQR2's storage), tau.
-constexpr int HT = 512;                 // threads of the rescue workgroup
+constexpr int HT = 256;                 // threads of the rescue workgroup (see house_tall_kernel)
 constexpr int HB = 8;                   // columns per block
 template <int K>
 __device__ __forceinline__ void ht_reduce(double (&a)[K], double *s_part /* [HT / 64][K] */, double *s_out /* [K] */) {
@@ -520,14 +622,15 @@ __device__ __forceinline__ void ht_reduce(double (&a)[K], double *s_part /* [HT 
 // nz: 1 + the last 64-row chunk of the panel with a non-zero entry (panel_kernel<0>): the rows below are exactly zero and
 // stay zero under every reflector, so the walk stops there -- the panels of a matrix that is nearly a band (the
 // reference's sparse Hamiltonians) cost a few hundred rows each instead of the full height.
-// The outputs of a rescued panel (round 5: by the same single workgroup, behind the factorisation -- until round 4 two more
-// predicated launches, tall_finish_kernel over the chunks and t_from_gram_kernel, which cost EVERY panel of every matrix
-// two empty launches, 10 us of a chain that is 120 - 200 us long): V into the update's operand images and the reflector
-// matrix, R alone left in the panel, T (column-major, ld 64) from G = V^T V by DLARFT's forward columnwise recurrence.
-struct TallOut { double *Vall; int ldv; double *Vd1, *Vd2; int ldi; double *T; };
-__global__ __launch_bounds__(HT) void house_tall_kernel(int m_full, double *__restrict__ P, int ldp, double *__restrict__ tau_out,
-                                                        const int *pflag, int *d_flag, const int *nz, TallOut out) {
-  extern __shared__ double ht_smem[];                      // two 64 x 64 images (the finish): sV / sT, sG
+// (Round 5: ONE predicated launch in the chain instead of three.  Until round 4 two more -- tall_finish_kernel over the
+// chunks and t_from_gram_kernel -- cost EVERY panel of every matrix two empty launches; the rescued panel's outputs are now
+// written by the chain's last pass, panel_kernel<2>, which runs anyway: chunk by chunk on all its workgroups, the last one
+// to finish forms T.  And the workgroup has four waves of at most 256 registers, not eight: eight needed a CU that BOTH
+// workgroups of a trailing update had left, so beside an update the EMPTY launch lasted until the update's grid had
+// drained (trace: 219 us); four fit as soon as one has left (15 us), and the factorisation itself is no slower -- it is
+// bound by one CU's memory pipe (band of half width 65 at N = 16384, 70 panels rescued: 1.13 x the dense solve, as before).)
+__global__ __launch_bounds__(HT, 2) void house_tall_kernel(int m_full, double *__restrict__ P, int ldp, double *__restrict__ tau_out,
+                                                           const int *pflag, int *d_flag, const int *nz) {
   __shared__ double s_part[(HT / 64) * HB * HB], s_out[HB * HB];
   __shared__ double s_T[HB * HB], s_X[HB * HB], s_tau[SB];
   if (!*pflag) return;
@@ -535,10 +638,10 @@ __global__ __launch_bounds__(HT) void house_tall_kernel(int m_full, double *__re
   int m = m_full;
   if (nz) { const int me = *nz * SB; if (me < m) m = (me > SB + 1) ? me : ((SB + 1 < m) ? SB + 1 : m); }
   if (t == 0) atomicAdd(d_flag, 256);                      // bits 8..: panels that took this path (informational)
-  const bool zero_panel = (*pflag & 4) != 0;               // the panel is exactly zero: R = 0, H = I
-  if (t < SB) { s_tau[t] = 0.0; if (zero_panel) tau_out[t] = 0.0; }
-  __syncthreads();
-  if (!zero_panel) {
+  if (*pflag & 4) {                                        // the panel is exactly zero: R = 0, H = I
+    if (t < SB) tau_out[t] = 0.0;
+    return;
+  }
   auto vget = [&](int r, int j) -> double {                // entry (r, j) of the unit lower trapezoidal V
     return (r > j) ? P[(size_t)r + (size_t)j * ldp] : (r == j ? 1.0 : 0.0);
   };
@@ -654,60 +757,6 @@ __global__ __launch_bounds__(HT) void house_tall_kernel(int m_full, double *__re
         }
       }
       __syncthreads();
-    }
-  }
-  }   // (!zero_panel)
-  __syncthreads();
-  // ---- the finish: chunk by chunk over ALL rows of the panel (the images may hold an earlier panel's numbers below m)
-  double *sV = ht_smem, *sG = ht_smem + IMG;
-  {
-    const int r = t & 63, cg = t >> 6;                     // eight waves: row r, columns 8 cg .. 8 cg + 7
-    double4_t acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    for (int row0 = 0; row0 < m_full; row0 += SB) {
-      const int row = row0 + r;
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int col = 8 * cg + c;
-        double v = 0.0;
-        if (row < m_full) {
-          const double x = P[(size_t)row + (size_t)col * ldp];
-          v = (row > col) ? x : (row == col ? 1.0 : 0.0);
-          P[(size_t)row + (size_t)col * ldp] = (row <= col) ? x : 0.0;
-          out.Vall[(size_t)row + (size_t)col * out.ldv] = v;
-          out.Vd1[(size_t)row + (size_t)col * out.ldi] = v;
-          if (out.Vd2) out.Vd2[(size_t)row + (size_t)col * out.ldi] = v;
-        }
-        sV[r * LD + col] = v;
-      }
-      __syncthreads();
-      if (t < 256) slab_gram(sV, sV, acc);
-    }
-    __syncthreads();
-    if (t < 256) {
-      const int lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sG[(16 * wave + l4 + 4 * q) * LD + 16 * jt + l15] = acc[jt][q];
-    }
-    double *sT = sV;
-    for (int idx = t; idx < IMG; idx += HT) sT[idx] = 0.0;
-    __syncthreads();
-    for (int i = 0; i < SB; ++i) {
-      const double ti = s_tau[i];
-      if (t < i) {
-        double a = 0.0;
-        for (int l = t; l < i; ++l) a += sT[t * LD + l] * sG[l * LD + i];
-        sT[t * LD + i] = -ti * a;
-      } else if (t == i) sT[i * LD + i] = ti;
-      __syncthreads();
-    }
-    for (int idx = t; idx < SB * SB; idx += HT) {
-      const int i = idx & 63, j = idx >> 6;
-      out.T[idx] = sT[i * LD + j];
     }
   }
 }
@@ -1264,11 +1313,9 @@ void ensure_attrs() {
   static bool attr = false;
   if (attr) return;
   (void)hipFuncSetAttribute((const void *)hr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            4 * IMG * (int)sizeof(double));
+                            3 * IMG * (int)sizeof(double));
   (void)hipFuncSetAttribute((const void *)house_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (SMALL_ROWS * LD + 2 * IMG) * (int)sizeof(double));
-  (void)hipFuncSetAttribute((const void *)house_tall_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * IMG * (int)sizeof(double));
   attr = true;
 }
 
@@ -1295,15 +1342,15 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
   hipLaunchKernelGGL(panel_kernel<1>, dim3(nch), dim3(256), 0, st, pa);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, st, nch, b.Gpart2, b.Gred2);
   HrArgs ha{b.Gred2, b.Qt, b.mpad, b.R1, b.M2, Tp, b.L1, b.Rband, tau1 + c0, b.pflag, b.prof};
-  hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 4 * IMG * sizeof(double), st, ha);
+  hipLaunchKernelGGL(hr_kernel, dim3(1), dim3(256), 3 * IMG * sizeof(double), st, ha);
+  // the rescue of a panel CholeskyQR2 could not factor (one workgroup; it leaves at once otherwise), then the final pass
+  hipLaunchKernelGGL(house_tall_kernel, dim3(1), dim3(HT), 0, st, m, Ap, lda, tau1 + c0, b.pflag, d_flag,
+                     b.nzrows ? b.nzrows + c0 / SB : nullptr);
   PanelArgs pf{};
   pf.m = m; pf.src = b.Qt; pf.lds_ = b.mpad; pf.M = b.M2; pf.L1 = b.L1; pf.Rband = b.Rband;
   pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vd1 = Vd1; pf.Vd2 = Vd2; pf.ldi = ldi; pf.pflag = b.pflag;
+  pf.Gpart = b.Gpart2; pf.tau = tau1 + c0; pf.Tout = Tp; pf.arrived = (unsigned *)(b.pflag + 16);
   hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, st, pf);
-  // the rescue of a panel CholeskyQR2 could not factor (one workgroup; it leaves at once otherwise)
-  const TallOut to{Vp, ldv, Vd1, Vd2, ldi, Tp};
-  hipLaunchKernelGGL(house_tall_kernel, dim3(1), dim3(HT), 2 * IMG * sizeof(double), st, m, Ap, lda, tau1 + c0, b.pflag, d_flag,
-                     b.nzrows ? b.nzrows + c0 / SB : nullptr, to);
 }
 
 // team form: the strips a member updates after panel p (batched GEMM: one problem per owned strip that still has
@@ -1410,6 +1457,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
 
   int *nzrows = (int *)(sm + 13 * 4096);               // one word per panel (room for 8192)
   (void)hipMemsetAsync(nzrows, 0, (size_t)ceil_div(n, SB) * sizeof(int), s);
+  (void)hipMemsetAsync(sm + 12 * 4096, 0, 128, s);      // the panel's flag and the arrival counter of a rescued panel's outputs
   const ChainBufs cb{n, L.mpad, Qt, Gpart2, Gred2, R1, R1inv, M2, L1, Rband, prof ? (long long *)(sm + 10 * 4096) : nullptr,
                      (int *)(sm + 12 * 4096), nzrows};
   // block j (0..3) of an operand image, from image row `row` on
@@ -1629,6 +1677,7 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
     m.cb = ChainBufs{n, L.mpad, m.Qt, (double *)(w + L.off_gpart2), sm + 11 * 4096, sm + 4096, sm + 2 * 4096, sm + 3 * 4096,
                      sm + 5 * 4096, sm + 6 * 4096, nullptr, (int *)(sm + 12 * 4096), (int *)(sm + 13 * 4096)};
     (void)hipMemsetAsync(sm + 13 * 4096, 0, (size_t)ceil_div(n, SB) * sizeof(int), s);
+    (void)hipMemsetAsync(sm + 12 * 4096, 0, 128, s);
     msgs[q] = m.msg; ys[q] = m.Y;
     hipLaunchKernelGGL(strip_table_kernel, dim3(L.npanels), dim3(round_up(L.maxb, 64)), 0, s, n, mem[q].lda, P, mem[q].rank,
                        L.maxb, m.offs, m.dims, 0);
