@@ -353,16 +353,16 @@ def q2_traffic_record(n, ncols):
     """HBM bytes per q2_apply_nb_kernel launch from the committed PMC measurement -- only while the kernel's source is
     the file the measurement was taken from (the record carries its sha256); a stale record is not reported."""
     import hashlib
-    tpath = os.path.join(ROOT, "profiles", "r04_q2_apply_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r05_q2_apply_traffic.json")
     src = os.path.join(ROOT, "eigenkernel_amd", "csrc", "ek_sb2st.hip")
     try:
         tj = json.load(open(tpath))
         sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
         if tj.get("n") != n or tj.get("ncols") != int(ncols):
-            return None, "profiles/r04_q2_apply_traffic.json is for another shape"
+            return None, "profiles/r05_q2_apply_traffic.json is for another shape"
         if tj.get("source_sha256") != sha:
-            return None, "profiles/r04_q2_apply_traffic.json is stale: ek_sb2st.hip has changed since it was measured"
-        return tj.get("hbm_bytes_per_launch"), ("profiles/r04_q2_apply_traffic.json (rocprofv3 --pmc at git %s, not live)"
+            return None, "profiles/r05_q2_apply_traffic.json is stale: ek_sb2st.hip has changed since it was measured"
+        return tj.get("hbm_bytes_per_launch"), ("profiles/r05_q2_apply_traffic.json (rocprofv3 --pmc at git %s, not live)"
                                                 % tj.get("git", "?"))
     except Exception as exc:
         return None, "no PMC record (%r)" % (exc,)

@@ -239,7 +239,7 @@ using namespace ek::api;
 
 extern "C" {
 
-int ek_hip_version(void) { return 1; }
+int ek_hip_version(void) { return 2; }
 
 int ek_hip_init(int device) {
   std::lock_guard<std::mutex> lk(g_mu);

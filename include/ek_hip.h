@@ -60,7 +60,9 @@ extern "C" {
 #define EK_STAGE_COPY    7  /* host<->device staging (not in the reference) */
 
 /* Library / device management ---------------------------------------------------------- */
-int ek_hip_version(void);                       /* 100*major + minor                        */
+int ek_hip_version(void);                       /* 100*major + minor.  2: round 5 (version 1's
+                                                 * ek_hip_comm_peer_enable / _disable are gone since
+                                                 * round 4: INTEGRATION.md 5) */
 int ek_hip_init(int device);                    /* bind this process (rank) to a GPU        */
 int ek_hip_finalize(void);                      /* release cached workspaces / device images */
 const char *ek_hip_stage_name(int stage);       /* reference event name of a stage index    */
@@ -94,7 +96,17 @@ int ek_hip_solve(int problem, int n, int n_vec,
 
 /* Same computation on arrays that already live in device memory (HBM) of the bound GPU:
  * dA (lda), dB (ldb), dZ (ldz) column-major n x n, dw n doubles.  This is what bench.py
- * times.  Asynchronous errors are reported by the return value (the call synchronises). */
+ * times.  Asynchronous errors are reported by the return value (the call synchronises).
+ * IN PLACE: the call owns dA, dB and dZ for its duration.  Arrays that already have the
+ * library's internal layout (n a multiple of 128, leading dimension n, 256-byte aligned base)
+ * ARE its work arrays, any other is copied in and out -- either way, on return: dA = what the
+ * tridiagonalisation leaves (lower triangle: reflectors / band and R factors), dB = L (lower
+ * triangle), dZ = the eigenvectors; the strictly UPPER triangles of dA and dB hold scratch of
+ * the stages (they are not referenced as inputs and not restored).  After an error return
+ * (info != 0: a failing pivot, -4, -992 ...) dA, dB and dZ hold intermediate state -- as A and
+ * B do after a failed PDPOTRF / PDSYGST: a caller that needs its inputs again keeps a copy.
+ * (EK_HIP_ALIAS=0: always through internal copies; the inputs are then overwritten only by
+ * the final copy-out.) */
 int ek_hip_solve_device(int problem, int n, int n_vec,
                         double *dA, int lda, double *dB, int ldb,
                         double *dw, double *dZ, int ldz,

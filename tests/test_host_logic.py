@@ -468,7 +468,7 @@ def test_bench_reports_no_traffic_from_a_stale_pmc_record(tmp_path, monkeypatch)
     src.write_text("// kernel source, version 1\n")
     sha = hashlib.sha256(src.read_bytes()).hexdigest()
     rec = {"n": 16384, "ncols": 16384, "hbm_bytes_per_launch": 1.0e12, "source_sha256": sha, "git": "abc1234"}
-    (root / "profiles" / "r04_q2_apply_traffic.json").write_text(json.dumps(rec))
+    (root / "profiles" / "r05_q2_apply_traffic.json").write_text(json.dumps(rec))
     monkeypatch.setattr(bench, "ROOT", str(root))
     t, why = bench.q2_traffic_record(16384, 16384)
     assert t == 1.0e12 and "abc1234" in why
