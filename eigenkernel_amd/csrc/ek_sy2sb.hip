@@ -1130,51 +1130,56 @@ struct YredDistArgs {
   const double *V; int ldv;
   double *Gpart;
 };
+// (a workgroup per 64 rows and 16 columns, grid (nch, 4), since round 5 -- as yred_q_kernel: with a workgroup per chunk a
+// member's reduction took 58 us per panel at N = 16384 reading up to 56 partial sums one batch of eight after the other)
 __global__ __launch_bounds__(256) void yred_dist_kernel(YredDistArgs p) {
-  __shared__ double sY[IMG], sV[IMG];
-  const int t = threadIdx.x, r = t & 63, cg = t >> 6;
-  double4_t acc[4];
+  __shared__ double sYq[SB * 17], sV[IMG];
+  const int t = threadIdx.x, r = t & 63, cg = t >> 6, q = blockIdx.y;
+  const int lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int row0 = blockIdx.x * CH;
+  if (row0 >= p.m) return;
+  const int row = row0 + r;
+  const int rb = row0 >> 7, m0 = rb * 128;
+  const bool heavy = ((((p.r0 + m0) >> 7) % p.P) == p.rank) || ((((p.r0 + m0 + 64) >> 7) % p.P) == p.rank);
+  const int td = symm_dist_chunk(p.T, p.SD);
+  int nd = rb / td + 1; if (nd > p.SD) nd = p.SD;                    // direct chunks with kt0 <= rb
+  const int cnt = p.T - rb - 1, len = symm_dist_chunk(cnt > 0 ? cnt : 1, p.ST);
+  const int nt = (heavy && cnt > 0) ? symm_dist_chunk(cnt, len) : 0;  // transposed chunks with kt0 < T
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  for (int slab = 0; slab < CH / SB; ++slab) {
-    const int row0 = blockIdx.x * CH + slab * SB;
-    if (row0 >= p.m) break;
-    const int row = row0 + r;
-    const int rb = row0 >> 7, m0 = rb * 128;
-    const bool heavy = ((((p.r0 + m0) >> 7) % p.P) == p.rank) || ((((p.r0 + m0 + 64) >> 7) % p.P) == p.rank);
-    const int td = symm_dist_chunk(p.T, p.SD);
-    int nd = rb / td + 1; if (nd > p.SD) nd = p.SD;                    // direct chunks with kt0 <= rb
-    const int cnt = p.T - rb - 1, len = symm_dist_chunk(cnt > 0 ? cnt : 1, p.ST);
-    const int nt = (heavy && cnt > 0) ? symm_dist_chunk(cnt, len) : 0;  // transposed chunks with kt0 < T
-    __syncthreads();
+  for (int c = 0; c < 4; ++c) {
+    const int lc = 4 * cg + c, col = 16 * q + lc;
+    double y = 0.0;
+    if (row < p.m) {
+      const double *yp = p.Ypart + (size_t)row + (size_t)col * p.ldy;
+      // (fixed order: direct chunks ascending, then transposed chunks ascending; eight loads in flight at a time)
+      auto sum_run = [&](const double *base, int count) {
+        int u0 = 0;
+        for (; u0 + 8 <= count; u0 += 8) {
+          double a[8];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const int col = 16 * cg + c;
-      double y = 0.0, v = 0.0;
-      if (row < p.m) {
-        const double *yp = p.Ypart + (size_t)row + (size_t)col * p.ldy;
-        // (fixed order: direct chunks ascending, then transposed chunks ascending; four loads in flight at a time)
-        auto sum_run = [&](const double *base, int cnt) {      // (eight loads in flight; the order of the sum is fixed)
-          int q = 0;
-          for (; q + 8 <= cnt; q += 8) {
-            double a[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = base[(size_t)(q + u) * p.sY];
-            y += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-          }
-          for (; q < cnt; ++q) y += base[(size_t)q * p.sY];
-        };
-        sum_run(yp, nd);
-        sum_run(yp + (size_t)p.SD * p.sY, nt);
-        p.Y[(size_t)row + (size_t)col * p.ldyo] = y;
-        v = p.V[(size_t)row + (size_t)col * p.ldv];
-      }
-      sY[r * LD + col] = y; sV[r * LD + col] = v;
+          for (int u = 0; u < 8; ++u) a[u] = base[(size_t)(u0 + u) * p.sY];
+          y += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        }
+        for (; u0 < count; ++u0) y += base[(size_t)u0 * p.sY];
+      };
+      sum_run(yp, nd);
+      sum_run(yp + (size_t)p.SD * p.sY, nt);
+      p.Y[(size_t)row + (size_t)col * p.ldyo] = y;
     }
-    __syncthreads();
-    slab_gram(sV, sY, acc);
+    sYq[r * 17 + lc] = y;
   }
-  store_gram(acc, p.Gpart + (size_t)blockIdx.x * SB * SB);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int col = 16 * cg + c;
+    sV[r * LD + col] = (row < p.m) ? p.V[(size_t)row + (size_t)col * p.ldv] : 0.0;
+  }
+  __syncthreads();
+  double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < SB; kk += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(kk + l4) * LD + 16 * wave + l15], sYq[(kk + l4) * 17 + l15], acc, 0, 0, 0);
+  double *G = p.Gpart + (size_t)blockIdx.x * SB * SB;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) G[(16 * q + l15) + SB * (16 * wave + l4 + 4 * rr)] = acc[rr];
 }
 
 // W = [Y | V] [T ; -1/2 T^T G T], G = V^T Y (the sum of yred_kernel's partials), written to columns 0..63 and
@@ -1351,6 +1356,36 @@ void panel_chain(hipStream_t st, const ChainBufs &b, double *A, int lda, double 
   pf.Vall = Vp; pf.ldv = ldv; pf.Apanel = Ap; pf.lda = lda; pf.Vd1 = Vd1; pf.Vd2 = Vd2; pf.ldi = ldi; pf.pflag = b.pflag;
   pf.Gpart = b.Gpart2; pf.tau = tau1 + c0; pf.Tout = Tp; pf.arrived = (unsigned *)(b.pflag + 16);
   hipLaunchKernelGGL(panel_kernel<2>, dim3(nch), dim3(256), 0, st, pf);
+}
+
+// team form: a panel's message [V (m x 64, ld ldy) | T (64 x 64) | tau (64)] in ONE launch each way (round 5; until
+// round 4 three launches on the owner and four on every other member, 6 - 9 us each: 9 ms per rank at N = 16384).
+// Grid: ceil(m / 256) x 64 for V plus one row of blocks (blockIdx.x == gridDim.x - 1) for T and tau.
+struct PanelMsgArgs {
+  int m, ldy;
+  double *msg;               // the message
+  double *V1; int ld1;       // V in the operand image
+  double *V2; int ld2;       // unpack only: V in the reflector matrix (may be null)
+  double *T; double *tau;
+};
+template <bool PACK>
+__global__ __launch_bounds__(256) void panel_msg_kernel(PanelMsgArgs p) {
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x == (int)gridDim.x - 1) {          // T and tau: 4096 + 64 doubles over the 64 blocks of this row
+    const size_t vcount = (size_t)p.ldy * SB;
+    const int i = blockIdx.y * 256 + t;                 // 0 .. 16383: the first 4160 are used
+    if (i < SB * SB) { if (PACK) p.msg[vcount + i] = p.T[i]; else p.T[i] = p.msg[vcount + i]; }
+    else if (i < SB * SB + SB) { if (PACK) p.msg[vcount + i] = p.tau[i - SB * SB]; else p.tau[i - SB * SB] = p.msg[vcount + i]; }
+    return;
+  }
+  const int r = blockIdx.x * 256 + t, c = blockIdx.y;
+  if (r >= p.m) return;
+  if (PACK) p.msg[(size_t)r + (size_t)c * p.ldy] = p.V1[(size_t)r + (size_t)c * p.ld1];
+  else {
+    const double v = p.msg[(size_t)r + (size_t)c * p.ldy];
+    p.V1[(size_t)r + (size_t)c * p.ld1] = v;
+    if (p.V2) p.V2[(size_t)r + (size_t)c * p.ld2] = v;
+  }
 }
 
 // team form: the strips a member updates after panel p (batched GEMM: one problem per owned strip that still has
@@ -1700,9 +1735,8 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
       panel_chain(sp, M.cb, mem[q].A, mem[q].lda, mem[q].Vall, mem[q].ldv, mem[q].tau1, mem[q].d_flag, c0,
                   M.img[buf] + (size_t)SB * ldi, nullptr, M.Tm[buf]);
       if (P > 1) {                      // (only the m rows of the panel travel: V is packed with leading dimension ldy)
-        copy_matrix(sp, m, SB, M.img[buf] + (size_t)SB * ldi, ldi, M.msg, ldy);
-        (void)hipMemcpyAsync(M.msg + vcount, M.Tm[buf], (size_t)SB * SB * 8, hipMemcpyDeviceToDevice, sp);
-        (void)hipMemcpyAsync(M.msg + vcount + SB * SB, mem[q].tau1 + c0, (size_t)SB * 8, hipMemcpyDeviceToDevice, sp);
+        PanelMsgArgs pm{m, ldy, M.msg, M.img[buf] + (size_t)SB * ldi, ldi, nullptr, 0, M.Tm[buf], mem[q].tau1 + c0};
+        hipLaunchKernelGGL(panel_msg_kernel<true>, dim3(ceil_div(m, 256) + 1, SB), dim3(256), 0, sp, pm);
       }
       if (e0) { g_dprof.mark(sp); g_dprof.kind.push_back(0); }
     }
@@ -1714,10 +1748,9 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
     for (int q = 0; q < nmem; ++q) {
       if (mem[q].rank == owner) continue;
       St &M = st[q];
-      copy_matrix(sp, m, SB, M.msg, ldy, M.img[buf] + (size_t)SB * ldi, ldi);
-      (void)hipMemcpyAsync(M.Tm[buf], M.msg + vcount, (size_t)SB * SB * 8, hipMemcpyDeviceToDevice, sp);
-      (void)hipMemcpyAsync(mem[q].tau1 + c0, M.msg + vcount + SB * SB, (size_t)SB * 8, hipMemcpyDeviceToDevice, sp);
-      copy_matrix(sp, m, SB, M.msg, ldy, mem[q].Vall + (size_t)r0 + (size_t)c0 * mem[q].ldv, mem[q].ldv);
+      PanelMsgArgs pm{m, ldy, M.msg, M.img[buf] + (size_t)SB * ldi, ldi, mem[q].Vall + (size_t)r0 + (size_t)c0 * mem[q].ldv,
+                      mem[q].ldv, M.Tm[buf], mem[q].tau1 + c0};
+      hipLaunchKernelGGL(panel_msg_kernel<false>, dim3(ceil_div(m, 256) + 1, SB), dim3(256), 0, sp, pm);
     }
   };
   // A(:, own strips) -= [W | V] [V | W]^T rows of the strip: the member's strips from column r0 + skip on
@@ -1733,6 +1766,7 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
     g.A = M.img[buf]; g.lda = ldi; g.strideA = 0; g.B = M.img[buf] + (size_t)SB * ldi; g.ldb = ldi; g.strideB = 0;
     g.C = mem[q].A; g.ldc = mem[q].lda; g.strideC = 0; g.batch = nb; g.lower_only = true;
     g.d_offs = (skip ? M.offs2 : M.offs) + (size_t)p * L.maxb * 3; g.d_dims = (skip ? M.dims2 : M.dims) + (size_t)p * L.maxb * 3;
+    g.even_offs = true;          // (operand offsets c0 - r0: strips start on multiples of 128, panels on multiples of 64)
     gemm(s, g);
   };
 
@@ -1766,7 +1800,7 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
       const int NH = (P == 1) ? T : (((r0 & 127) == 0) ? nown : 2 * nown);
       hipLaunchKernelGGL(symm_lower_kernel<true>, dim3(T * SD + NH * ST), dim3(256), 0, s, sy);
       YredDistArgs ya{m, T, SD, ST, P, mem[q].rank, r0, M.Ypart, L.mpad, (long long)L.mpad * SB, M.Y, ldy, V, ldi, M.Gpart};
-      hipLaunchKernelGGL(yred_dist_kernel, dim3(nch), dim3(256), 0, s, ya);
+      hipLaunchKernelGGL(yred_dist_kernel, dim3(nch, 4), dim3(256), 0, s, ya);
     }
     if (P > 1) x.allreduce(s, nmem, ys, (size_t)ldy * SB, x.user);
     for (int q = 0; q < nmem; ++q) {
