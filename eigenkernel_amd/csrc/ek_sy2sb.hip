@@ -1786,7 +1786,7 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
     // tile takes a workgroup ~14 us, and the launch lasts as long as its longest workgroup): SD chunks of a block row's
     // owned direct slabs (every P-th strip of its up to T tiles), ST chunks of the up to T transposed tiles of an
     // owning block row
-    int SD = ceil_div(T, 3 * P), ST = ceil_div(T, 3);
+    int SD = ceil_div(T, 3 * P), ST = ceil_div(T, 3);      // (2 ties, 1 / 4 / 6 lose 2 - 7 % of a rank's stage: round 5)
     if (SD < 1) SD = 1; if (SD > 8) SD = 8;
     if (ST < 1) ST = 1; if (ST > 48) ST = 48;
     for (int q = 0; q < nmem; ++q) {
@@ -1802,17 +1802,16 @@ void sy2sb_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const Sy2s
       YredDistArgs ya{m, T, SD, ST, P, mem[q].rank, r0, M.Ypart, L.mpad, (long long)L.mpad * SB, M.Y, ldy, V, ldi, M.Gpart};
       hipLaunchKernelGGL(yred_dist_kernel, dim3(nch, 4), dim3(256), 0, s, ya);
     }
-    if (P > 1) x.allreduce(s, nmem, ys, (size_t)ldy * SB, x.user);
+    // G = V^T Y travels WITH Y (round 5): every member's V^T (its part of Y) -- yred_dist_kernel's partial products, summed
+    // here -- rides behind the 64 m doubles of its Y in the same all-reduce, 4096 doubles more; until round 4 every
+    // member formed G from the summed Y again (yred_kernel: one more launch per panel on every rank)
+    for (int q = 0; q < nmem; ++q)
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s, nch, st[q].Gpart, st[q].Y + (size_t)ldy * SB);
+    if (P > 1) x.allreduce(s, nmem, ys, (size_t)ldy * SB + SB * SB, x.user);
     for (int q = 0; q < nmem; ++q) {
       St &M = st[q];
       const double *V = M.img[cur] + (size_t)SB * ldi;
-      if (P > 1) {    // G = V^T Y of the summed Y
-        YredArgs yb{m, 1, M.Y, ldy, 0, M.Y, V, ldi, M.Gpart};
-        yb.ldyo = ldy;
-        hipLaunchKernelGGL(yred_kernel, dim3(nch), dim3(256), 0, s, yb);
-      }
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3(128), dim3(256), 0, s, nch, M.Gpart, M.sm);
-      WArgs wa{m, M.Y, ldy, V, ldi, M.sm, M.Tm[cur], M.img[cur], M.img[cur] + (size_t)2 * SB * ldi, ldi};
+      WArgs wa{m, M.Y, ldy, V, ldi, M.Y + (size_t)ldy * SB, M.Tm[cur], M.img[cur], M.img[cur] + (size_t)2 * SB * ldi, ldi};
       hipLaunchKernelGGL(w_kernel, dim3(nch), dim3(256), 0, s, wa);
     }
     const bool has_next = m - SB >= 2;
