@@ -220,3 +220,16 @@ def test_caller_arrays_used_in_place_change_no_bit(hip, monkeypatch, gep, n, n_v
         assert np.array_equal(np.tril(o0["A"]), np.tril(o1["A"])), (pad, shift, alias)
         if gep:
             assert np.array_equal(np.tril(o0["B"]), np.tril(o1["B"])), (pad, shift, alias)
+
+
+@pytest.mark.parametrize("gep,n,n_vec", [(False, 5699, 300), (True, 6401, 6401)])
+def test_ragged_orders_where_the_panels_go_in_pairs(hip, gep, n, n_vec):
+    """Odd orders just above 5120 + 512: the first panels of the dense -> band stage go in pairs (rank-256 updates, the second
+    panel's SYMM on the not yet updated matrix), the trailing matrices are no multiples of 64, and the flow switches to single
+    panels on the way: the reference's acceptance quantities on the GPU (tools/sanity_ragged.py is the manual sweep up to
+    20011)."""
+    lib = hip.load_library()
+    with _Dev(lib) as dev:
+        r = _solve_1x1(lib, dev, gep, n, n_vec)
+        assert (np.diff(r["w"][:n_vec]) >= 0).all()
+        _acceptance(lib, gep, n, n_vec, r["dA0"], r["dB0"] if gep else None, r["dw"], r["dZ"])
