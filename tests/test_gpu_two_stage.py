@@ -392,10 +392,13 @@ def test_panels_cholesky_qr_cannot_factor_are_rescued_inside_the_stage(hip, orac
     assert st[1] == 1.0 and st[3] == 0.0            # the solve stayed on the two-stage path, first stage included
 
 
-def test_reference_matrix_through_two_stages(hip, golden_dir, forced_two_stage):
+@pytest.mark.parametrize("pairs", ["0", "1"])
+def test_reference_matrix_through_two_stages(hip, golden_dir, forced_two_stage, monkeypatch, pairs):
     """The reference's own sparse Hamiltonian (VCNT400std, 8 200 non-zeros of 160 000) with the two-stage form forced on:
-    its first panels are rank deficient; eigenvalues against the reference's golden file (12 digits)."""
+    its first panels are rank deficient; eigenvalues against the reference's golden file (12 digits) -- with the panels of
+    the dense -> band stage one by one and in pairs (rescued panels inside pairs)."""
     from eigenkernel_amd import matrix_io
+    monkeypatch.setenv("EK_SY2SB_PAIR_MIN", pairs)
     A = matrix_io.read_matrix_file(os.path.join(golden_dir, "ELSES_MATRIX_VCNT400std_A.mtx")).to_dense()
     w_ref = np.loadtxt(os.path.join(golden_dir, "ELSES_MATRIX_VCNT400std_E.txt"))[:, 1]
     ep, _ = hip.eigen_solver("hip", A)
