@@ -202,7 +202,6 @@ void symv_profile_collect(double *seconds, long long *launches, double *bytes);
 // call for large orders in place of sytrd_lower + ormtr_lower; the results contract is the same.
 constexpr int kBandW = 64;
 size_t sy2sb_work_bytes(int n);
-void sy2sb_corun_probe(hipStream_t sa, hipStream_t sb, int m, double *A, int lda, double *C2, int ldc, void *work, double *sec);   // EXPERIMENT
 // A (lower, lda multiple of 128, zero padded) -> band in the lower band of A (A(i,j), 0 <= i-j <= 64;
 // the rest of the lower triangle is zeroed except the R factors' upper triangles inside the band).
 // Vall (n x n, ldv; must be zero on entry): explicit reflectors, column j = v_j with its unit entry

@@ -688,17 +688,6 @@ int ek_hip_debug_gemm_at(int transa, int transb, int m, int n, int k, const doub
   return 0;
 }
 
-int ek_hip_debug_corun(int m, double *dA, int lda, double *dC, int ldc, int swap, double *sec) {
-  int rc = ensure_init(); if (rc) return rc;
-  std::lock_guard<std::mutex> lk(g_mu);
-  void *work = nullptr;
-  EK_HIP_CHECK(hipMalloc(&work, ek::sy2sb_work_bytes(m + 64)));
-  if (swap) ek::sy2sb_corun_probe(g_ctx.stream, g_ctx.stream2, m, dA, lda, dC, ldc, work, sec);
-  else ek::sy2sb_corun_probe(g_ctx.stream2, g_ctx.stream, m, dA, lda, dC, ldc, work, sec);
-  (void)hipFree(work);
-  return 0;
-}
-
 int ek_hip_debug_sytrd_split(void *alt, int mask) {
   std::lock_guard<std::mutex> lk(g_mu);
   sytrd_debug_split(alt, mask);

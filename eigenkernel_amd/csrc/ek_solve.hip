@@ -6,6 +6,8 @@
 #include <condition_variable>
 #include <sched.h>
 #include <deque>
+#include <memory>
+#include <new>
 #include <thread>
 
 namespace ek {
@@ -1096,14 +1098,24 @@ int ek_hip_solve(int problem, int n, int n_vec, double *A_loc, const int desc_A[
   if (info >= 0 || info > -1000) {
     // results travel back even when info > 0 so the host can inspect them, as with ScaLAPACK
     int rc2 = d2h_matrix(n, n_vec, uZ, n, Z_loc, desc_Z[8], s);
-    // A and B go back as uplo = 'L' arrays: through a scratch, of which the caller's array receives the entries on and
-    // below the diagonal only (orders below the pipeline's: at most 32 MiB)
-    std::vector<double> tmp((size_t)n * n);
+    // A and B go back as uplo = 'L' arrays, in chunks of at most kTri columns as the pipeline's way out cuts them: the rows
+    // below a chunk's diagonal block straight into the caller's array (one 2-D copy), the diagonal block through a scratch
+    // of kTri x kTri doubles (2 MiB whatever the order -- EK_HIP_PIPE_MIN=0 sends N = 16384 down this path too), of which
+    // the caller's array receives the entries on and below the diagonal only.  No allocation that can throw across the C ABI.
+    constexpr int kTri = HostPipe::kTri;
+    std::unique_ptr<double[]> tri(new (std::nothrow) double[(size_t)kTri * kTri]);
     auto d2h_lower = [&](const double *u, double *M_loc, int ldm) -> int {
-      int r = d2h_matrix(n, n, u, n, tmp.data(), n, s);
-      if (!r) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = -1000 - (int)e; }
-      if (!r) for (int c = 0; c < n; ++c) memcpy(M_loc + (size_t)c * ldm + c, tmp.data() + (size_t)c * n + c, (size_t)(n - c) * 8);
-      return r;
+      if (!tri) return -1000 - (int)hipErrorOutOfMemory;
+      for (int a = 0; a < n; a += kTri) {
+        const int b = (n - a < kTri) ? n : a + kTri, wdt = b - a;
+        int r = d2h_matrix(wdt, wdt, u + (size_t)a * n + a, n, tri.get(), wdt, s);
+        if (!r && b < n) r = d2h_matrix(n - b, wdt, u + (size_t)a * n + b, n, M_loc + (size_t)a * ldm + b, ldm, s);
+        if (!r) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = -1000 - (int)e; }
+        if (r) return r;
+        for (int c = 0; c < wdt; ++c)
+          memcpy(M_loc + (size_t)(a + c) * ldm + a + c, tri.get() + (size_t)c * wdt + c, (size_t)(wdt - c) * 8);
+      }
+      return 0;
     };
     if (!rc2) rc2 = d2h_lower(uA, A_loc, desc_A[8]);
     if (!rc2 && problem == 1) rc2 = d2h_lower(uB, B_loc, desc_B[8]);

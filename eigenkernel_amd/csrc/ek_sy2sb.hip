@@ -1595,35 +1595,6 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
 }
 
 
-// EXPERIMENT (temporary): SYMM of order m on stream sa and a rank-256 lower update of order m on stream sb: alone, alone, together
-void sy2sb_corun_probe(hipStream_t sa, hipStream_t sb, int m, double *A, int lda, double *C2, int ldc, void *work, double *sec) {
-  const Layout L(m + 64);
-  char *w = (char *)work;
-  double *img = (double *)(w + L.off_opa[0]), *imgb = (double *)(w + L.off_opb[0]);
-  double *Ypart = (double *)(w + L.off_ypart);
-  const int ldi = L.mpad;
-  (void)hipMemsetAsync(img, 0, (size_t)ldi * 256 * 8, sa);
-  (void)hipMemsetAsync(imgb, 0, (size_t)ldi * 256 * 8, sa);
-  (void)hipStreamSynchronize(sa);
-  const int T = ceil_div(m, 128);
-  int nsplit, tps;
-  symm_split(T, L.maxsplit, &nsplit, &tps);
-  SymmArgs sy{m, A, lda, img, ldi, Ypart, L.mpad, (long long)L.mpad * SB, T, tps, 1, 0, 0};
-  const int R = 8;
-  auto run = [&](bool a, bool b) -> double {
-    (void)hipDeviceSynchronize();
-    auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < R; ++r) {
-      if (a) hipLaunchKernelGGL(symm_lower_kernel<false>, dim3(T, nsplit), dim3(256), 0, sa, sy);
-      if (b) gemm(sb, false, true, m, m, 256, -1.0, img, ldi, imgb, ldi, 1.0, C2, ldc, true);
-    }
-    (void)hipDeviceSynchronize();
-    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / R;
-  };
-  run(true, true);
-  sec[0] = run(true, false); sec[1] = run(false, true); sec[2] = run(true, true);
-}
-
 size_t sy2sb_dist_work_bytes(int n, int nranks) { return Layout(n, nranks > 0 ? nranks : 1).total; }
 
 // Team form of the dense -> band stage (the reference's PDSYTRD is distributed over its grid,

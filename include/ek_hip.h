@@ -80,7 +80,9 @@ const char *ek_hip_stage_name(int stage);       /* reference event name of a sta
  *             and B_loc are never referenced and, on a 1 x 1 grid, never written -- the caller
  *             finds there what it left there, as after PDPOTRF / PDSYTRD; from order 2048 on only
  *             the lower triangles cross PCIe.  On larger grids the local block-cyclic pieces are
- *             written whole.)
+ *             written whole: the entries of a piece that lie strictly above the GLOBAL diagonal
+ *             come back with UNSPECIFIED FINITE values (what the stages left in the library's
+ *             work array), never NaN or Inf -- tests/test_gpu_path.py holds the library to that.)
  *   w       : out: n doubles, ascending, first n_vec valid (eigenpairs%blacs%values)
  *   Z_loc   : out: eigenvectors (eigenpairs%blacs%Vectors), N x N descriptor, same NB as A;
  *             B-orthonormal (generalized) / orthonormal (standard)

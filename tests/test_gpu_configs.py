@@ -5,14 +5,14 @@
     C4  N=32768 generalized EVP: 1x1 grid and one rank of the 2x4 grid the reference lays 8 ranks out on
     C5  N=16384 generalized EVP, lowest 1024 pairs (`*_select` arm): 1x1 and one rank of the 2x4 grid
 
-Eigenvalues of C2, C3 and C5 are held to the reference's own library path (the six ScaLAPACK calls of
+Eigenvalues of C2, C3, C4 and C5 are held to the reference's own library path (the six ScaLAPACK calls of
 solver_scalapack_all.f90:59-115 / generalized_to_standard.f90:24-103, oracle/scalapack_path.c on
 oneMKL ScaLAPACK, 2x4 grid, NB=64; fixtures from tests/golden/make_scalapack_goldens.sh) within the
-SURVEY.md 8(c) bound  max|l - l_ref| <= N eps max|l|.  C4 has no eigenvalue fixture (an hour of the
-build container's 8 cores): it is held to the size-independent acceptance quantities of the
-reference's own verifier (verifier.f90:75-204, 233-330) evaluated on the GPU against fresh copies of
-the inputs -- N B-orthonormal vectors with residuals at rounding level ARE the full spectrum -- and
-to bit-identity between the grid piece and the 1x1 result.
+SURVEY.md 8(c) bound  max|l - l_ref| <= N eps max|l|.  Every configuration is also held to the
+size-independent acceptance quantities of the reference's own verifier (verifier.f90:75-204, 233-330)
+evaluated on the GPU against fresh copies of the inputs -- N B-orthonormal vectors with residuals at
+rounding level ARE the full spectrum -- and, for the 8-rank layouts C4 and C5, to bit-identity between
+one cell of the 2 x 4 grid and the 1x1 result.
 """
 import ctypes
 import os
