@@ -254,9 +254,28 @@ struct StedcSelect { int nsel, nb, npcol, mycol; };
 // d_flops (optional, device): receives the flops of the merge products this solve executed (after deflation)
 // wscratch (optional): an n x n array with leading dimension ldz for the permuted bases of the merges; without it Z
 // itself serves (and must then be n x n even where only sel->nsel columns are wanted)
+// Team form (the reference's PDSTEDC is distributed over its grid, solver_scalapack_all.f90:96): the
+// `levels` heights of the tree right below the top merge are sharded over a 1 x P team as well.  Everything that is
+// O(n^2) per height (rank sorts, deflation, secular equation, the permuted bases) stays replicated and bit-identical; the
+// products Q = W S -- all of the O(n^3) -- are cut into 128-wide strips of the compact basis array (n x (n - n/2), the
+// second half's blocks stored n/2 columns to the left), strip S on rank S mod P like every other strip of the library, so
+// that what deflation takes away is taken from every rank alike; a rank forms the S columns and the products of its own
+// strips only, then ONE in-place all-gather round per P strips completes the height's basis on every rank (whole
+// columns of the compact array: 8 n (n - n/2) bytes on the wire per sharded height).  Same GEMM per output element as on one
+// GPU (K walked in the same order), so the team's eigenvectors are the 1 x 1 result bit for bit.  Needs the compact
+// bases (a team member's share of the columns is at most half of them).
+//   rank >= 0: this process is that rank, x is its exchange;  rank == -1: rehearsal on one GPU -- the process plays every
+//   rank's strips in turn (no exchange; the per-rank sections are timed when stedc_team_profile is on).
+struct StedcTeam { int nranks; int rank; const SytrdExchange *x; int levels; };
+int stedc_team_levels(int n, int nranks);          // default number of sharded heights for that order and team (0: none)
+void stedc_team_set_levels(int levels);            // test / tool hook: force that many (-1: default)
+void stedc_team_profile(bool on);                  // HIP events around the call and around every rank's sections
+// after a stream sync: [0] the whole call, [1] all ranks' sections, [2] sum over the heights of the longest rank's section
+// (a rank of a real team spends [0] - [1] + [2] computing); resets
+void stedc_team_profile_collect(double *seconds);
 void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z,
            int ldz, void *work, int *d_info, const StedcSelect *sel = nullptr, double *d_flops = nullptr,
-           double *wscratch = nullptr);
+           double *wscratch = nullptr, const StedcTeam *team = nullptr);
 
 // ---------------------------------------------------------------- back-transformation (ek_ormtr.hip)
 size_t ormtr_work_bytes(int n, int ncols, int ncols_global = -1);   // ncols_global: columns of the whole Z (a grid cell holds ncols of them)

@@ -365,6 +365,8 @@ struct StageTimer {      // events are released when the timer goes out of scope
 // The copy of the reduced matrix for a fall-back to the one-stage reduction is gone: a bulge chasing that abandons a
 // bounded wait is repeated from the band it started from (a few MB) instead.
 int g_debug_fail_chase = 0;     // test aid (ek_hip_debug_fail_next_chase): pretend the next k bulge chasings abandoned a wait
+int g_debug_dc_team = 0;        // rehearsal aid (ek_hip_debug_stedc_team): a grid cell WITHOUT a communicator plays every rank of a
+                                // team of that many in the divide & conquer's sharded heights (one GPU: tests, tools/team_timing.py)
 
 struct PathPlan {
   int ld, nblk, zcols;
@@ -632,7 +634,13 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // forms only those (columns 0..nc_loc-1 of wZ) and the two remaining stages treat the
   // columns of Z independently
   const StedcSelect pick{nc_loc, cell ? cell->nb : (n > 0 ? n : 1), cell ? cell->npcol : 1, cell ? cell->mycol : 0};
-  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats);
+  // On a team the heights right below the top merge are sharded as well (strips of the compact bases, one all-gather
+  // round per P strips: ek_stedc.hip); the top merge forms this cell's columns only, as in the replicated-input mode.
+  SytrdExchange dcx{};
+  StedcTeam dct{0, 0, nullptr, 0};
+  if (dist && g_comm.nranks >= 2) { dcx = team_exchange(0); dct = StedcTeam{g_comm.nranks, g_comm.rank, &dcx, stedc_team_levels(n, g_comm.nranks)}; }
+  else if (cell && !dist && g_debug_dc_team >= 2) dct = StedcTeam{g_debug_dc_team, -1, nullptr, stedc_team_levels(n, g_debug_dc_team)};
+  stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats, nullptr, dct.levels > 0 ? &dct : nullptr);
   mark();                                                              // 5
   double *zc = wZ;
   // with a staging pipeline the LAST stage (the recovery; the back-transformation of a standard problem) runs in column
@@ -818,6 +826,28 @@ unsigned long long ek_hip_debug_workspace_bytes(int problem, int n, int n_vec, i
 int ek_hip_debug_last_pipe_stats(double *out, int count) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int i = 0; i < count && i < 12; ++i) out[i] = g_pipe_stats[i];
+  return 0;
+}
+
+// Rehearsal of the divide & conquer's team form on one GPU: while nranks >= 2, a grid cell solved WITHOUT a communicator
+// (ek_hip_solve_device_grid, replicated inputs) forms the sharded heights as a team of nranks would, rank after rank (no
+// exchange).  levels: heights below the top merge that are sharded (-1: the library's default for the order); profile != 0:
+// HIP events around the call and every rank's sections, read by ek_hip_debug_stedc_team_get ([0] the D&C, [1] all ranks'
+// sections, [2] the longest rank's per height: a rank of a real team computes for [0] - [1] + [2] seconds).
+int ek_hip_debug_stedc_team(int nranks, int levels, int profile) {
+  if (nranks < 0 || nranks > kMaxTeam) return -1;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_debug_dc_team = nranks;
+  stedc_team_set_levels(levels);
+  stedc_team_profile(profile != 0);
+  return 0;
+}
+int ek_hip_debug_stedc_team_get(double *seconds) {
+  if (!seconds) return -1;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  EK_HIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  stedc_team_profile_collect(seconds);
   return 0;
 }
 

@@ -51,7 +51,10 @@ struct DcBufs {
   int *k, *nrot;                 // per merge
   Merge *merges;
   double *orgnrm;                // 1
+  // team form of a height (StedcTeam): S is formed for the columns of rank tR's strips only (tP == 0: all columns)
+  int tP = 0, tR = 0;
 };
+constexpr int kStrip = 128;      // strip width of the team form (compact basis columns)
 
 __device__ __forceinline__ size_t cq(const DcBufs &b, int c) { return (size_t)(c >= b.hq ? c - b.hq : c); }
 __device__ __forceinline__ size_t cw(const DcBufs &b, int c) { return (size_t)(c >= b.hw ? c - b.hw : c); }
@@ -537,6 +540,7 @@ __global__ __launch_bounds__(256) void dc_vectors_kernel(int mbeg, DcBufs b, dou
   const int c = blockIdx.x, t = threadIdx.x;
   const int k = b.k[mi];
   if (c >= k) return;
+  if (b.tP > 0 && (int)(cq(b, mg.off + c) / kStrip) % b.tP != b.tR) return;   // (a column of another rank's strip)
   double *col = S + (size_t)mg.off + cs(b, mg.off + c) * lds;
   const double *dl = b.dl + mg.off, *zh = b.zhat + mg.off;
   const int *grp = b.grp + mg.off;
@@ -552,6 +556,23 @@ __global__ __launch_bounds__(256) void dc_vectors_kernel(int mbeg, DcBufs b, dou
   __syncthreads();
   const double inv = 1.0 / sqrt((red[0] + red[1]) + (red[2] + red[3]));
   for (int j = t; j < k; j += 256) col[grp[j]] = zh[j] / ((dl[j] - dK) - tau) * inv;
+}
+
+// Team form of a height: the two products of every merge cut into the pieces that fall into one rank's strips of the
+// compact basis array.  The table (which merge, which product, first column inside the merge, width) depends on the
+// order and the team only and is built on the host; the deflation's counts turn it into GEMM operands here.
+struct TeamEntry { int mi, prod, c0, wd; };
+__global__ void dc_team_entries_kernel(const TeamEntry *__restrict__ tab, int cnt, DcBufs b, long long *__restrict__ eoffs,
+                                       int *__restrict__ edims) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= cnt) return;
+  const TeamEntry te = tab[e];
+  const long long *go = b.goffs + 6 * (size_t)te.mi + 3 * te.prod;
+  const int *gd = b.gdims + 6 * (size_t)te.mi + 3 * te.prod;
+  int nn = gd[1] - te.c0;                      // columns of the product (roots) from c0 on
+  nn = nn < 0 ? 0 : (nn > te.wd ? te.wd : nn);
+  eoffs[3 * e] = go[0]; eoffs[3 * e + 1] = go[1] + (long long)te.c0 * b.lds; eoffs[3 * e + 2] = go[2] + (long long)te.c0 * b.ldq;
+  edims[3 * e] = gd[0]; edims[3 * e + 1] = nn; edims[3 * e + 2] = gd[2];
 }
 
 // Deflated eigenpairs: columns c >= k of W are final eigenvectors
@@ -667,8 +688,8 @@ struct Plan {
 // its S and result have nsel columns: 1.5 n^2 + n nsel doubles instead of the 3 n^2 of the full form with a separate
 // scratch for the permuted bases.
 struct WorkLayout {
-  size_t off_Q, off_S, off_Ssel, off_vec, off_int, off_merge, off_leaf, off_offs, off_dims, total;
-  int nmerge_cap, nleaf_cap;
+  size_t off_Q, off_S, off_Ssel, off_vec, off_int, off_merge, off_leaf, off_offs, off_dims, off_eoffs, off_edims, total;
+  int nmerge_cap, nleaf_cap, nentry_cap;
   bool compact;
   int h2;
   explicit WorkLayout(int n, int nsel = -1) {
@@ -685,6 +706,9 @@ struct WorkLayout {
     off_leaf = o; o += al256((size_t)nleaf_cap * sizeof(Leaf));
     off_offs = o; o += al256((size_t)nmerge_cap * 6 * 8);
     off_dims = o; o += al256((size_t)nmerge_cap * 6 * 4);
+    nentry_cap = 4 * (ceil_div(h2, kStrip) + 64);            // team form: pieces of one rank at one height (both products)
+    off_eoffs = o; o += al256((size_t)nentry_cap * 3 * 8);
+    off_edims = o; o += al256((size_t)nentry_cap * 3 * 4);
     total = o;
   }
 };
@@ -709,8 +733,53 @@ __global__ void dc_flops_kernel(int nmerge, const int *__restrict__ gdims, doubl
 }
 }  // namespace
 
+// ---- team form: which heights, and the rehearsal's clock
+namespace {
+int g_team_levels = -1;
+struct TeamProfile {
+  bool on = false;
+  hipEvent_t call[2] = {nullptr, nullptr};
+  bool have_call = false;
+  struct Sec { hipEvent_t e0, e1; int level, rank; };
+  std::vector<Sec> secs;
+  void clear() {
+    for (auto &q : secs) { (void)hipEventDestroy(q.e0); (void)hipEventDestroy(q.e1); }
+    secs.clear();
+    if (call[0]) (void)hipEventDestroy(call[0]);
+    if (call[1]) (void)hipEventDestroy(call[1]);
+    call[0] = call[1] = nullptr; have_call = false;
+  }
+} g_tprof;
+}  // namespace
+
+// Two heights below the top merge from order 8192 on.  The top merge is 3/4 of the D&C's products and already forms the
+// rank's own columns only; heights 2 and 3 are 3/16 and 3/64, everything below them 1/64 (1.6 % of 4/3 n^3: replicated,
+// it costs a rank of 8 less than the two exchanges of a further height would).  A sharded height moves 8 n (n - n/2)
+// bytes per rank whatever its merges' order (whole columns of the compact array), so going deeper buys less and less.
+int stedc_team_levels(int n, int nranks) {
+  if (g_team_levels >= 0) return nranks >= 2 ? g_team_levels : 0;
+  return (nranks >= 2 && n >= 8192) ? 2 : 0;
+}
+void stedc_team_set_levels(int levels) { g_team_levels = levels; }
+void stedc_team_profile(bool on) { g_tprof.clear(); g_tprof.on = on; }
+void stedc_team_profile_collect(double *seconds) {
+  seconds[0] = seconds[1] = seconds[2] = 0.0;
+  float ms = 0.f;
+  if (g_tprof.have_call && hipEventElapsedTime(&ms, g_tprof.call[0], g_tprof.call[1]) == hipSuccess) seconds[0] = ms * 1e-3;
+  std::vector<double> longest;
+  for (auto &q : g_tprof.secs) {
+    if (hipEventElapsedTime(&ms, q.e0, q.e1) != hipSuccess) continue;
+    seconds[1] += ms * 1e-3;
+    if ((int)longest.size() <= q.level) longest.resize(q.level + 1, 0.0);
+    if (ms * 1e-3 > longest[q.level]) longest[q.level] = ms * 1e-3;
+  }
+  for (double v : longest) seconds[2] += v;
+  const bool on = g_tprof.on;
+  g_tprof.clear(); g_tprof.on = on;
+}
+
 void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, double *Z, int ldz,
-           void *work, int *d_info, const StedcSelect *sel, double *d_flops, double *wscratch) {
+           void *work, int *d_info, const StedcSelect *sel, double *d_flops, double *wscratch, const StedcTeam *team) {
   if (n <= 0) return;
   const WorkLayout L(n, sel ? sel->nsel : -1);
   char *base = (char *)work;
@@ -781,6 +850,54 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
   d_leaves = cache.d_leaves;
   b.merges = cache.d_merges;
 
+  // Team form: the heights right below the top merge whose products are cut into strips (compact bases only), and the
+  // pieces of every rank at every such height (a function of the order and the team: built and uploaded once).
+  const int nlev = (int)plan.levels.size();
+  int tlevels = (team && compact && team->nranks >= 2) ? team->levels : 0;
+  if (tlevels > nlev - 1) tlevels = nlev - 1;
+  while (tlevels > 0 && (int)plan.levels[nlev - 1 - tlevels].size() > 32) --tlevels;
+  struct TeamPlan {
+    int n = -1, P = 0, levels = 0;
+    std::vector<int> beg;            // [(height index from the top - 1) * P + rank] -> first piece; one more at the end
+    TeamEntry *d_tab = nullptr;
+  };
+  static TeamPlan tplan;
+  const int tP = tlevels > 0 ? team->nranks : 0;
+  if (tlevels > 0 && (tplan.n != n || tplan.P != tP || tplan.levels != tlevels)) {
+    (void)hipStreamSynchronize(s);
+    if (tplan.d_tab) (void)hipFree(tplan.d_tab);
+    tplan = TeamPlan();
+    std::vector<TeamEntry> tab;
+    for (int t = 1; t <= tlevels; ++t) {
+      const int lv = nlev - 1 - t, mbeg = lvl_beg[lv];
+      std::vector<std::vector<TeamEntry>> per(tP);
+      for (size_t i = 0; i < plan.levels[lv].size(); ++i) {
+        const Merge &m = plan.levels[lv][i];
+        const int q0 = m.off >= half ? m.off - half : m.off;            // first column of the block as stored
+        for (int S = q0 / kStrip; S * kStrip < q0 + m.n; ++S) {
+          const int lo = std::max(q0, S * kStrip), hi = std::min(q0 + m.n, (S + 1) * kStrip);
+          for (int pr = 0; pr < 2; ++pr) per[S % tP].push_back({mbeg + (int)i, pr, lo - q0, hi - lo});
+        }
+      }
+      for (int r = 0; r < tP; ++r) {
+        tplan.beg.push_back((int)tab.size());
+        tab.insert(tab.end(), per[r].begin(), per[r].end());
+      }
+    }
+    tplan.beg.push_back((int)tab.size());
+    (void)hipMalloc((void **)&tplan.d_tab, tab.size() * sizeof(TeamEntry) + 64);
+    (void)hipMemcpy(tplan.d_tab, tab.data(), tab.size() * sizeof(TeamEntry), hipMemcpyHostToDevice);
+    tplan.n = n; tplan.P = tP; tplan.levels = tlevels;
+  }
+  long long *eoffs = (long long *)(base + L.off_eoffs);
+  int *edims = (int *)(base + L.off_edims);
+  const bool tprof = g_tprof.on && tlevels > 0;
+  if (tprof) {
+    g_tprof.clear(); g_tprof.on = true;
+    (void)hipEventCreate(&g_tprof.call[0]); (void)hipEventCreate(&g_tprof.call[1]);
+    (void)hipEventRecord(g_tprof.call[0], s);
+  }
+
   hipLaunchKernelGGL(dc_scale_kernel, dim3(1), dim3(256), 0, s, n, d, e, b);
   if (!all.empty())
     hipLaunchKernelGGL(dc_split_kernel, dim3(ceil_div((int)all.size(), 256)), dim3(256), 0, s,
@@ -837,6 +954,49 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
       copy_matrix(s, n, sel->nsel, Q, ldq, Z, ldz);
       break;
     }
+    const int tdepth = nlev - 1 - (int)lv;            // 1: right below the top merge
+    if (tlevels > 0 && tdepth >= 1 && tdepth <= tlevels) {
+      // team form of this height (StedcTeam): S and the products of a rank's own strips only, then the strips change hands
+      const int r0 = team->rank >= 0 ? team->rank : 0, r1 = team->rank >= 0 ? team->rank + 1 : tP;
+      for (int r = r0; r < r1; ++r) {
+        const int ib = tplan.beg[(size_t)(tdepth - 1) * tP + r], ie = tplan.beg[(size_t)(tdepth - 1) * tP + r + 1];
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (tprof && team->rank < 0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, s); }
+        b.tP = tP; b.tR = r;
+        hipLaunchKernelGGL(dc_vectors_kernel, dim3(maxn, cnt), dim3(256), 0, s, mbeg, b, S, lds);
+        b.tP = 0;
+        if (ie > ib) {
+          hipLaunchKernelGGL(dc_team_entries_kernel, dim3(ceil_div(ie - ib, 256)), dim3(256), 0, s, tplan.d_tab + ib, ie - ib,
+                             b, eoffs, edims);
+          GemmDesc g{};
+          g.M = (maxn + 1) / 2; g.N = kStrip; g.K = maxn; g.transA = false; g.transB = false;
+          g.alpha = 1.0; g.beta = 0.0;
+          g.A = W; g.lda = ldw; g.strideA = 0; g.B = S; g.ldb = lds; g.strideB = 0;
+          g.C = Q; g.ldc = ldq; g.strideC = 0; g.batch = ie - ib; g.lower_only = false;
+          g.d_offs = eoffs; g.d_dims = edims; g.even_offs = even;
+          gemm(s, g);
+        }
+        if (e0) { (void)hipEventRecord(e1, s); g_tprof.secs.push_back({e0, e1, tdepth, r}); }
+      }
+      // (the deflated columns are copies of the replicated W: every rank writes all of them)
+      hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldw, Q, ldq);
+      if (team->rank >= 0) {
+        // one in-place all-gather per round of P strips: whole columns of the compact array (ld = n, so a strip is one
+        // contiguous piece and a round's pieces lie in rank order: ncclAllGather's own layout)
+        const int NS = ceil_div(L.h2, kStrip);
+        double *bufs[1] = {Q};
+        for (int q = 0; q * tP < NS; ++q) {
+          size_t offs[kMaxTeam], counts[kMaxTeam];
+          for (int r = 0; r < tP; ++r) {
+            const int Sx = q * tP + r;
+            const int cols = Sx < NS ? std::min(kStrip, L.h2 - Sx * kStrip) : 0;
+            offs[r] = (size_t)std::min(Sx, NS) * kStrip * ldq; counts[r] = (size_t)cols * ldq;
+          }
+          team->x->allgatherv(s, 1, team->rank, bufs, offs, counts, tP, team->x->user);
+        }
+      }
+      continue;
+    }
     hipLaunchKernelGGL(dc_vectors_kernel, dim3(maxn, cnt), dim3(256), 0, s, mbeg, b, S, lds);
     // two GEMMs per merge (top rows x [top-only|dense] columns, bottom rows x [dense|bottom-only]
     // columns), all merges of this height in one launch; sizes and offsets come from the
@@ -851,6 +1011,7 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     hipLaunchKernelGGL(dc_copy_deflated_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, W, ldw, Q, ldq);
   }
   count_flops();
+  if (tprof) { (void)hipEventRecord(g_tprof.call[1], s); g_tprof.have_call = true; }   // (the final gather of a full spectrum is not a team's)
   if (sel_done) return;
   hipLaunchKernelGGL(dc_final_rank_kernel, dim3(ceil_div(n * RP, 256)), dim3(256), 0, s, n, b, w, fperm, d_info);
   if (selecting) {

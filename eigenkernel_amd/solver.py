@@ -119,6 +119,8 @@ def load_library(path=None):
         "ek_hip_debug_sy2sb_team_timing": (c_int, [c_int, c_int, c_int, _dp]),
         "ek_hip_debug_sy2sb_team_profile": (c_int, [c_int, c_int, c_int, c_int, _dp, _dp]),
         "ek_hip_debug_fail_next_chase": (c_int, [c_int]),
+        "ek_hip_debug_stedc_team": (c_int, [c_int, c_int, c_int]),
+        "ek_hip_debug_stedc_team_get": (c_int, [_dp]),
         "ek_hip_debug_last_pipe_stats": (c_int, [_dp, c_int]),
         "ek_hip_debug_workspace_bytes": (ctypes.c_ulonglong, [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
     }
@@ -151,6 +153,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_debug_sy2sb", "ek_hip_debug_sb2st", "ek_hip_debug_two_stage_timing", "ek_hip_debug_set_two_stage",
     "ek_hip_profile_kernels", "ek_hip_profile_kernels_get", "ek_hip_debug_last_solve_stats",
     "ek_hip_debug_sy2sb_team", "ek_hip_debug_sy2sb_team_timing", "ek_hip_debug_sy2sb_team_profile", "ek_hip_debug_workspace_bytes", "ek_hip_debug_fail_next_chase", "ek_hip_debug_last_pipe_stats",
+    "ek_hip_debug_stedc_team", "ek_hip_debug_stedc_team_get",
 )
 
 
@@ -449,6 +452,23 @@ BAND_W = 64   # half bandwidth of the two-stage tridiagonalisation (kBandW in cs
 def set_two_stage(min_order=-1):
     """Order from which the whole-path calls tridiagonalise in two stages (-1: default, 0: never)."""
     load_library().ek_hip_debug_set_two_stage(int(min_order))
+
+
+def stedc_team(nranks=0, levels=-1, profile=False):
+    """Team form of the divide & conquer's heights below the top merge (ek_stedc.hip StedcTeam).  levels: sharded heights
+    (-1: the library's default for the order and team) -- applies to real teams too; nranks >= 2: grid cells solved
+    WITHOUT a communicator rehearse a team of that many, rank after rank in this process.  stedc_team() restores the
+    defaults."""
+    rc = load_library().ek_hip_debug_stedc_team(int(nranks), int(levels), 1 if profile else 0)
+    assert rc == 0, rc
+
+
+def stedc_team_seconds():
+    """[the D&C, all ranks' sections, the longest rank's section per height summed] of the last profiled rehearsal."""
+    out = (ctypes.c_double * 3)()
+    rc = load_library().ek_hip_debug_stedc_team_get(out)
+    assert rc == 0, rc
+    return [float(x) for x in out]
 
 
 def last_solve_stats():

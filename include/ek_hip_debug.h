@@ -82,6 +82,16 @@ unsigned long long ek_hip_debug_workspace_bytes(int problem, int n, int n_vec, i
    saved band and the -992 exit of ek_solve.hip) */
 int ek_hip_debug_fail_next_chase(int times);
 
+/* Rehearsal of the divide & conquer's team form on one GPU (ek_stedc.hip, StedcTeam): while nranks >= 2, a grid cell solved
+   WITHOUT a communicator (ek_hip_solve_device_grid / ek_hip_solve_replicated) forms the heights below the top merge that a
+   team of nranks shards by strips rank after rank in this process (no exchange; same bits as any other form).  levels:
+   sharded heights (-1: the library's default for the order and team); profile != 0: HIP events around the call and every
+   rank's sections.  ek_hip_debug_stedc_team(0, -1, 0) switches it off.
+   _get: seconds[0] the D&C, [1] all ranks' sections, [2] the longest rank's section summed over the heights -- a rank of
+   a real team computes for [0] - [1] + [2] seconds (the all-gathers are not in it: one GPU). */
+int ek_hip_debug_stedc_team(int nranks, int levels, int profile);
+int ek_hip_debug_stedc_team_get(double *seconds);
+
 /* what the staging pipeline of the last ek_hip_solve on host arrays did: out[0] bytes in, [1] span of the input transfers
    (s), [2] busy seconds of the input workers, [3..5] the same on the way out, [6] seconds the main thread waited for
    inputs, [7] for the drain at the end, [8] 100 x workers on the way in + workers on the way out, [9] 0 (round 4: directions through a pinned ring, removed), [10] seconds from the start of the pipeline to its end, [11] seconds before the first input transfer */

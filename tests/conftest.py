@@ -44,3 +44,4 @@ def _default_tridiagonalisation_after_each_gpu_test(request):
         from eigenkernel_amd import solver
         if solver._lib is not None:
             solver._lib.ek_hip_debug_set_two_stage(-1)
+            solver._lib.ek_hip_debug_stedc_team(0, -1, 0)

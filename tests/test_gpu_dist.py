@@ -424,6 +424,19 @@ def _mp_worker(rank, world, port, q):
         os.environ.pop("EK_SY2SB_DIST_LOOKAHEAD_MIN", None)
         out["lookahead"] = la
         say("look-ahead on / off done")
+        # (3c) the divide & conquer's team form (heights below the top merge sharded by strips of the compact bases, one
+        # all-gather round per `world` strips: ek_stedc.hip) forced at this order, across real processes: same bits as
+        # with those heights replicated -- for the full spectrum and for a *_select arm
+        dc = {}
+        for key, lv in (("team", 3), ("replicated", 0)):
+            sv.stedc_team(0, lv)
+            ep, _ = sv.eigen_solver("hip", A2, None, proc=proc)
+            cols = d.local_indices(n2, int(ep.desc[d.BLOCK_ROW_]), rank, world)
+            eps_, _ = sv.eigen_solver("general_hip_select", A, B, n_vec=90, proc=proc)
+            dc[key] = (ep.values.copy(), ep.Vectors[:, :len(cols)].copy(), eps_.values.copy(), eps_.Vectors.copy())
+        sv.stedc_team()
+        out["dc_team"] = dc
+        say("D&C team form on / off done")
         # (4) an exchange that fails on ONE rank in the middle of a solve (here: rank 1's hook reports a failure of its
         # 12th exchange from now, inside the dense -> band stage at this order) ends the call on EVERY rank with -996: the sticky
         # record travels in the team's votes (ek_comm.hip comm_vote); the next call starts clean
@@ -523,6 +536,12 @@ def test_three_processes_share_the_gpu_and_exchange_through_the_host(hip, oracle
         assert np.array_equal(o["lookahead"]["on"][0], o["lookahead"]["off"][0])
         assert np.array_equal(o["lookahead"]["on"][1], o["lookahead"]["off"][1])
         assert np.array_equal(o["lookahead"]["on"][0], outs[0]["lookahead"]["on"][0])
+    # nor does the divide & conquer's team form, and rank 0's eigenvalues are everybody's
+    for o in outs:
+        for a, b in zip(o["dc_team"]["team"], o["dc_team"]["replicated"]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(o["dc_team"]["team"][0], outs[0]["lookahead"]["on"][0])
+        assert np.array_equal(o["dc_team"]["team"][1], o["lookahead"]["on"][1])
     w2 = np.linalg.eigvalsh(oracle.synth_matrix(1500, 1))
     assert np.abs(outs[0]["lookahead"]["on"][0] - w2).max() <= 4 * 1500 * EPS * np.abs(w2).max()
     # potrf: the complete factor on every process
@@ -733,3 +752,29 @@ def test_bench_self_launch_rehearsed_on_one_gpu(hip):
     assert line["parity"]["residual_norm_max"] <= line["parity"]["bounds"]["residual_norm_max"]
     probe = line.get("grid_probe")
     assert probe is not None and not probe.get("error"), probe
+
+
+@pytest.mark.parametrize("n,P,levels,n_vec,gen", [(1500, 3, 2, None, False), (2048, 8, 2, None, True), (1152, 2, 1, None, False),
+                                                   (1500, 4, 3, 200, True), (1301, 5, 9, None, False)])
+def test_stedc_team_rehearsal_changes_no_bit(hip, oracle, n, P, levels, n_vec, gen):
+    """The team form of the divide & conquer (heights below the top merge cut into 128-wide strips of the compact bases,
+    strip S on rank S mod P; ek_stedc.hip) rehearsed on one GPU: a grid cell plays every rank's strips in turn.  Each
+    product is the same GEMM per output element as on one GPU, so eigenvalues and the cell's eigenvectors must be the
+    replicated form's bit for bit -- on ragged orders (strips that straddle two merges), with more heights asked for
+    than the tree has, and for a *_select arm."""
+    A = oracle.synth_matrix(n, 1)
+    B = oracle.synth_matrix(n, 2) if gen else None
+    name = ("general_hip" if gen else "hip") + ("_select" if n_vec else "")
+    for rank in sorted({0, P - 1, P // 2}):
+        proc = hip.Process(rank, P, 0, 1, P, 0, rank)
+        hip.stedc_team()
+        ref, _ = hip.eigen_solver(name, A, B, n_vec=n_vec, proc=proc)
+        hip.stedc_team(P, levels, profile=True)
+        ep, _ = hip.eigen_solver(name, A, B, n_vec=n_vec, proc=proc)
+        sec = hip.stedc_team_seconds()
+        hip.stedc_team()
+        assert np.array_equal(ep.values, ref.values)
+        assert np.array_equal(ep.Vectors, ref.Vectors)
+        assert sec[0] > 0.0 and sec[1] > 0.0 and sec[2] <= sec[1] <= sec[0]      # (the team form did run)
+    w_or = oracle.solve(A, B)[0] if gen else np.linalg.eigvalsh(A)
+    assert np.abs(ref.values - w_or[:len(ref.values)]).max() <= 4 * n * EPS * np.abs(w_or).max()

@@ -66,13 +66,23 @@ for P in teams:
     assert lib.ek_hip_debug_reduce_team(n, P, 2, red) == 0
     ncl = (n + P - 1) // P
     dZ = dmalloc((ncl + 64) * n * 8)
+    # the D&C's team form (heights below the top merge sharded by strips) rehearsed inside the cell's solve: the cell plays
+    # every rank's sections in turn; a rank of a real team computes for (stage - all sections + the longest rank's) seconds
+    dc = (ctypes.c_double * 3)()
+    levels = int(os.environ.get("EK_TEAM_DC_LEVELS", "-1"))
     for rep in range(2):
         assert lib.ek_hip_synth_matrix_device(n, 1, dA, n) == 0
         assert lib.ek_hip_synth_matrix_device(n, 2, dB, n) == 0
+        assert lib.ek_hip_debug_stedc_team(P, levels, 1) == 0
         rc = lib.ek_hip_solve_device_grid(1, n, n, dA, n, dB, n, dw, dZ, n, 64, 1, P, 0, 0, stage, 8)
         assert rc == 0, rc
+        assert lib.ek_hip_debug_stedc_team_get(dc) == 0
+        assert lib.ek_hip_debug_stedc_team(0, -1, 0) == 0
+    stedc_rank = stage[4] - dc[1] + dc[2]
+    print("n=%d P=%d D&C: stage %.4f s with every rank's sections back to back (%.4f s of sections, the longest rank's %.4f) -> %.4f s per rank"
+          % (n, P, stage[4], dc[1], dc[2], stedc_rank), flush=True)
     parts = {"potrf (team)": red[0] / P, "sygst (team)": red[1] / P, "dense->band (team, look-ahead, chain in full)": d2b[P][1],
-             "band->tridiagonal (replicated)": ts[1], "stedc (top merge on own columns)": stage[4],
+             "band->tridiagonal (replicated)": ts[1], "stedc (team form below the top merge, top merge on own columns)": stedc_rank,
              "Q2 + Q1 (own columns)": stage[5], "recovery (own columns)": stage[6]}
     print("n=%d P=%d per-rank compute: %.3f s = %s   [dense->band without look-ahead: %.3f]" % (n, P, sum(parts.values()),
           ", ".join("%s %.3f" % kv for kv in parts.items()), d2b[P][0]), flush=True)
