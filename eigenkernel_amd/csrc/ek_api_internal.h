@@ -103,6 +103,12 @@ int two_stage_min();
 int dist_min_ranks();
 void comm_teardown();     // the communicator itself (ek_hip_finalize)
 SytrdExchange team_exchange(int nteam, int n = 0);
+// Pairwise exchange over the attached communicator (RCCL: grouped ncclSend / ncclRecv; host communicator: two rounds of
+// the allgatherv hook): this rank sends send[i] (send_counts[i] doubles, device) to world rank peers[i] and receives
+// recv_counts[i] doubles from it into recv[i]; stream-ordered, collective over the communicator (a rank with no peer
+// calls it with npeers = 0).  Failures are recorded in g_comm.err like those of every other exchange.
+void team_sendrecv(hipStream_t s, int npeers, const int *peers, double *const *send, const size_t *send_counts,
+                   double *const *recv, const size_t *recv_counts);
 int comm_any(int local);
 int comm_agree(int local_rc);
 const char *comm_error_string();

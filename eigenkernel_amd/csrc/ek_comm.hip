@@ -22,6 +22,9 @@ struct Rccl {
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;   // (optional)
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;              // (grids with nprow > 1)
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   int load() {
     if (h) return 0;
     const char *names[] = {getenv("EK_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -39,6 +42,9 @@ struct Rccl {
     Broadcast = (decltype(Broadcast))dlsym(h, "ncclBroadcast");
     GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+    AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+    Send = (decltype(Send))dlsym(h, "ncclSend");
+    Recv = (decltype(Recv))dlsym(h, "ncclRecv");
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString || !Broadcast ||
         !GroupStart || !GroupEnd) {
       fprintf(stderr, "[ek_hip] RCCL symbols missing\n");
@@ -60,6 +66,15 @@ void rccl_allreduce(hipStream_t s, int nmem, double *const *bufs, size_t count, 
 void rccl_allgatherv(hipStream_t s, int nmem, int, double *const *bufs, const size_t *offs,
                      const size_t *counts, int nranks, void *) {
   if (nmem != 1 || !g_comm.on || nranks != g_comm.nranks) { if (!g_comm.err) g_comm.err = (int)ncclInvalidUsage; return; }
+  // equal pieces that lie side by side in rank order (a round of P strips of the D&C's compact bases, a round of band
+  // strips): that is ncclAllGather's own in-place layout -- one ring collective instead of P broadcasts
+  bool side_by_side = g_rccl.AllGather != nullptr && counts[0] > 0;
+  for (int q = 1; q < nranks && side_by_side; ++q) side_by_side = counts[q] == counts[0] && offs[q] == offs[0] + (size_t)q * counts[0];
+  if (side_by_side) {
+    const ncclResult_t ra = g_rccl.AllGather(bufs[0] + offs[g_comm.rank], bufs[0] + offs[0], counts[0], ncclDouble, g_comm.comm, s);
+    if (ra != ncclSuccess && !g_comm.err) g_comm.err = (int)ra;
+    return;
+  }
   ncclResult_t r = g_rccl.GroupStart();
   for (int root = 0; root < nranks && r == ncclSuccess; ++root)
     if (counts[root] > 0)
@@ -137,6 +152,71 @@ void host_allgatherv(hipStream_t s, int nmem, int, double *const *bufs, const si
   for (int r = 0; ok && r < nranks; ++r)
     if (r != me && counts[r] > 0)
       ok = hipMemcpy(bufs[0] + offs[r], g_hx_recv.data() + displs[r], counts[r] * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok && !g_comm.err) g_comm.err = (int)ncclSystemError;
+}
+
+// Pairwise exchange (the eigenvector columns' way from the rank that formed them to the cells of its process column, on
+// grids with more than one process row: ek_solve.hip).  Where the reference's PDORMTR / PDTRTRS leave Z on the 2-D grid
+// by construction (solver_scalapack_all.f90:115, generalized_to_standard.f90:103).
+void team_sendrecv(hipStream_t s, int npeers, const int *peers, double *const *send, const size_t *send_counts,
+                   double *const *recv, const size_t *recv_counts) {
+  if (!g_comm.on) { if (!g_comm.err) g_comm.err = (int)ncclInvalidUsage; return; }
+  if (!g_comm.host) {
+    if (npeers == 0) return;
+    if (!g_rccl.Send || !g_rccl.Recv) { if (!g_comm.err) g_comm.err = (int)ncclInvalidUsage; return; }
+    ncclResult_t r = g_rccl.GroupStart();
+    for (int i = 0; i < npeers && r == ncclSuccess; ++i) {
+      if (send_counts[i] > 0) r = g_rccl.Send(send[i], send_counts[i], ncclDouble, peers[i], g_comm.comm, s);
+      if (r == ncclSuccess && recv_counts[i] > 0) r = g_rccl.Recv(recv[i], recv_counts[i], ncclDouble, peers[i], g_comm.comm, s);
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess && !g_comm.err) g_comm.err = (int)r;
+    return;
+  }
+  // host communicator: a header round (who sends how much to whom), then one all-gather of everybody's payloads, of which
+  // a rank keeps what is addressed to it -- a compatibility path like the other host exchanges
+  if (!g_allgatherv) { if (!g_comm.err) g_comm.err = (int)ncclInvalidUsage; return; }
+  const int P = g_comm.nranks, me = g_comm.rank, H = 2 * kMaxTeam + 1;
+  std::vector<double> hdr(H, 0.0), hall((size_t)H * P);
+  hdr[0] = npeers;
+  size_t mine = 0;
+  for (int i = 0; i < npeers && i < kMaxTeam; ++i) { hdr[1 + 2 * i] = peers[i]; hdr[2 + 2 * i] = (double)send_counts[i]; mine += send_counts[i]; }
+  std::vector<long long> cnt(P, H), dsp(P);
+  for (int r = 0; r < P; ++r) dsp[r] = (long long)r * H;
+  bool ok = npeers <= kMaxTeam && hipStreamSynchronize(s) == hipSuccess;
+  ok = g_allgatherv(hdr.data(), H, hall.data(), cnt.data(), dsp.data(), g_allgatherv_user) == 0 && ok;
+  long long tot = 0;
+  for (int r = 0; r < P; ++r) {
+    long long c = 0;
+    const int np_r = (int)hall[(size_t)r * H];
+    for (int i = 0; i < np_r && i < kMaxTeam; ++i) c += (long long)hall[(size_t)r * H + 2 + 2 * i];
+    cnt[r] = c; dsp[r] = tot; tot += c;
+  }
+  g_hx_send.resize(mine > 0 ? mine : 1); g_hx_recv.resize(tot > 0 ? (size_t)tot : 1);
+  size_t o = 0;
+  for (int i = 0; ok && i < npeers; ++i) {
+    if (send_counts[i] > 0) ok = hipMemcpy(g_hx_send.data() + o, send[i], send_counts[i] * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    o += send_counts[i];
+  }
+  // (every rank makes the second call even after a local failure: the exchange is collective)
+  ok = g_allgatherv(g_hx_send.data(), (long long)mine, g_hx_recv.data(), cnt.data(), dsp.data(), g_allgatherv_user) == 0 && ok;
+  for (int i = 0; ok && i < npeers; ++i) {
+    const int r = peers[i];
+    const int np_r = (int)hall[(size_t)r * H];
+    long long off = dsp[r];
+    bool found = false;
+    for (int j = 0; j < np_r && j < kMaxTeam; ++j) {
+      const long long c = (long long)hall[(size_t)r * H + 2 + 2 * j];
+      if ((int)hall[(size_t)r * H + 1 + 2 * j] == me) {
+        found = (size_t)c == recv_counts[i];
+        if (found && c > 0) ok = hipMemcpy(recv[i], g_hx_recv.data() + off, (size_t)c * 8, hipMemcpyHostToDevice) == hipSuccess;
+        break;
+      }
+      off += c;
+    }
+    ok = ok && (found || recv_counts[i] == 0);
+  }
   if (!ok && !g_comm.err) g_comm.err = (int)ncclSystemError;
 }
 

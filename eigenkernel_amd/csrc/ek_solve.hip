@@ -374,7 +374,8 @@ struct PathPlan {
   size_t mat, zmat, x0, x1, sygst_dbl, potrf_wb, wb_sytrd, wb_stedc, wb_ormtr, wb_sy2sb, wb_sb2st, wb_rec, wb_q1prep,
          trsm_work, inv256, total;
 };
-PathPlan plan_path(int problem, int n, int n_vec, int nc_loc, int nranks_dist /* 0: not distributed */) {
+PathPlan plan_path(int problem, int n, int n_vec, int nc_loc, int nranks_dist /* 0: not distributed */,
+                   size_t exch_bytes = 0 /* X1's last life: the eigenvector pieces on their way between the cells of a process column */) {
   PathPlan p{};
   const bool dist = nranks_dist > 0;
   p.ld = pad_ld(n); p.nblk = ceil_div(n, kDiagNB);
@@ -410,6 +411,7 @@ PathPlan plan_path(int problem, int n, int n_vec, int nc_loc, int nranks_dist /*
   if (al(p.wb_stedc) > p.x1) p.x1 = al(p.wb_stedc);
   if (p.wb_rec > p.x1) p.x1 = p.wb_rec;
   if (al(p.wb_ormtr) > p.x1) p.x1 = al(p.wb_ormtr);
+  if (al(exch_bytes) > p.x1) p.x1 = al(exch_bytes);
   p.total = 2 * p.mat + p.zmat + p.x0 + p.x1 + al((size_t)p.nblk * kDiagNB * kDiagNB * 8) + p.trsm_work +
             5 * al((size_t)p.ld * 8) + p.wb_sy2sb + p.wb_sb2st + p.wb_q1prep + p.inv256 + 4096;
   return p;
@@ -426,7 +428,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
                         double *dw, double *dZ, int ldz, double *stage_seconds, int n_stages,
                         const GridCell *cell = nullptr, HostPipe *pipe = nullptr) {
   hipStream_t s = g_ctx.stream;
-  const int nc_loc = cell ? numroc0(n_vec, cell->nb, cell->mycol, cell->npcol) : n_vec;
+  const int nc_out = cell ? numroc0(n_vec, cell->nb, cell->mycol, cell->npcol) : n_vec;    // columns of the piece of Z this call returns
   const int nr_loc = cell ? numroc0(n, cell->nb, cell->myrow, cell->nprow) : n;
   // A communicator attached by the host (ek_hip_comm_init) whose size is the grid's: the Cholesky factorisation, the
   // reduction and the dense -> band stage of the tridiagonalisation are distributed over the ranks (1 x P team, per panel
@@ -434,7 +436,17 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // other stages are as in the replicated-input mode.
   const bool dist = cell && g_comm.on && g_comm.nranks == cell->nprow * cell->npcol;
   if (dist && g_comm.rank != cell->myrow * cell->npcol + cell->mycol) return -994;
-  const PathPlan pl = plan_path(problem, n, n_vec, nc_loc, dist ? g_comm.nranks : 0);
+  // On a grid with more than one process ROW the cells of a process column would all form the same eigenvector columns
+  // (each keeping its rows): with a communicator they split them instead -- cell (i, j) forms the blocks l of its process
+  // column's share with l mod nprow = i, which is the block-cyclic share of world rank i * npcol + j among all P ranks
+  // -- and exchange row pieces pairwise at the end (team_sendrecv): 1 / P of the back-transformations and of the recovery
+  // on every rank whatever the grid's shape, as PDORMTR / PDTRTRS have it on the reference's 2 x 4 grid
+  // (solver_scalapack_all.f90:115, generalized_to_standard.f90:103, processes.f90:56-65).
+  const bool split_rows = dist && cell->nprow > 1;
+  const int nc_loc = split_rows ? numroc0(n_vec, cell->nb, g_comm.rank, g_comm.nranks) : nc_out;   // columns this call FORMS
+  size_t exch_bytes = 0;
+  if (split_rows) exch_bytes = ((size_t)n * (nc_loc > 0 ? nc_loc : 1) + (size_t)(nr_loc > 0 ? nr_loc : 1) * (nc_out > 0 ? nc_out : 1)) * 8 + 4096;
+  const PathPlan pl = plan_path(problem, n, n_vec, nc_loc, dist ? g_comm.nranks : 0, exch_bytes);
   const int ld = pl.ld, nblk = pl.nblk, zcols = pl.zcols;
   const bool two_stage = pl.two_stage, potrf_rl = pl.potrf_rl;
   const size_t wb_sytrd = pl.wb_sytrd;
@@ -633,7 +645,8 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // eigenvector columns wanted: the first n_vec, or this grid cell's share of them; the D&C
   // forms only those (columns 0..nc_loc-1 of wZ) and the two remaining stages treat the
   // columns of Z independently
-  const StedcSelect pick{nc_loc, cell ? cell->nb : (n > 0 ? n : 1), cell ? cell->npcol : 1, cell ? cell->mycol : 0};
+  const StedcSelect pick{nc_loc, cell ? cell->nb : (n > 0 ? n : 1), split_rows ? g_comm.nranks : (cell ? cell->npcol : 1),
+                         split_rows ? g_comm.rank : (cell ? cell->mycol : 0)};
   // On a team the heights right below the top merge are sharded as well (strips of the compact bases, one all-gather
   // round per P strips: ek_stedc.hip); the top merge forms this cell's columns only, as in the replicated-input mode.
   SytrdExchange dcx{};
@@ -698,7 +711,35 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   if (sigma != 1.0) scale_vector(s, n, 1.0 / sigma, dwv);
   EK_HIP_CHECK(hipMemcpyAsync(dw, dwv, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
   if (!pipe) {
-    if (cell) gather_block_cyclic(s, nr_loc, nc_loc, zc, ld, cell->nb, cell->nprow, cell->myrow, 1, 0, dZ, ldz);
+    if (split_rows) {
+      // every cell of this process column receives its rows of the columns the others formed: per peer one packed piece
+      // each way (X1, free by now), then the pieces' columns take their places in the cell's block-cyclic piece
+      const int nb = cell->nb, R = cell->nprow, C = cell->npcol, P = g_comm.nranks;
+      double *buf = (double *)x1;
+      int peers[kMaxTeam]; double *sp[kMaxTeam], *rp[kMaxTeam]; size_t sc[kMaxTeam], rcn[kMaxTeam];
+      int np = 0;
+      double *own = nullptr;
+      for (int i = 0; i < R; ++i) {               // what goes out (and this cell's own rows of its own columns)
+        const int nr_i = numroc0(n, nb, i, R);
+        const size_t cnt = (size_t)nr_i * nc_loc;
+        if (cnt > 0) gather_block_cyclic(s, nr_i, nc_loc, zc, ld, nb, R, i, 1, 0, buf, nr_i > 1 ? nr_i : 1);
+        if (i == cell->myrow) own = buf;
+        else { peers[np] = i * C + cell->mycol; sp[np] = buf; sc[np] = cnt; ++np; }
+        buf += cnt;
+      }
+      for (int i = 0, q = 0; i < R; ++i) {        // what comes in
+        if (i == cell->myrow) continue;
+        rcn[q] = (size_t)nr_loc * numroc0(n_vec, nb, i * C + cell->mycol, P);
+        rp[q] = buf; buf += rcn[q]; ++q;
+      }
+      team_sendrecv(s, np, peers, sp, sc, rp, rcn);
+      const int ldp = nr_loc > 1 ? nr_loc : 1;
+      for (int i = 0, q = 0; i < R; ++i) {
+        const int nc_i = numroc0(n_vec, nb, i * C + cell->mycol, P);
+        const double *src = (i == cell->myrow) ? own : rp[q++];
+        scatter_block_cyclic(s, nr_loc, nc_i, src, ldp, nb, 1, 0, R, i, dZ, ldz);
+      }
+    } else if (cell) gather_block_cyclic(s, nr_loc, nc_loc, zc, ld, cell->nb, cell->nprow, cell->myrow, 1, 0, dZ, ldz);
     else if (!aliasZ) copy_matrix(s, n, n_vec, wZ, ld, dZ, ldz);
     if (problem == 1 && !aliasB) copy_matrix(s, n, n, wB, ld, dB, ldb);
   }

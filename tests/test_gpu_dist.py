@@ -602,8 +602,12 @@ def _mp_grid_worker(rank, world, port, q, nprow, npcol, inputs, two_stage_min=No
         proc = sv.Process(rank, world, 0, nprow, npcol, myrow, mycol)
         ep, _ = sv.eigen_solver("general_hip", A, B, proc=proc, inputs=inputs)
         sys.stderr.write("[rank %d] (%d,%d) solved, stages %s\n" % (rank, myrow, mycol, sorted(ep.stage_seconds)[:1]))
+        # the same team laid out as 1 x world: the cells of a process column split its eigenvector columns among them and
+        # exchange row pieces at the end (ek_solve.hip, team_sendrecv), so both layouts must assemble to the same bits
+        proc1 = sv.Process(rank, world, 0, 1, world, 0, rank)
+        ep1, _ = sv.eigen_solver("general_hip", A, B, proc=proc1, inputs=inputs)
         out = (myrow, mycol, int(ep.desc[d.BLOCK_ROW_]), ep.values.copy(), ep.Vectors.copy(),
-               getattr(ep, "B_loc", None))
+               getattr(ep, "B_loc", None), ep1.values.copy(), ep1.Vectors.copy(), int(ep1.desc[d.BLOCK_ROW_]))
         sv.comm_destroy()
         q.put((rank, out, None))
         dist.barrier()
@@ -662,6 +666,9 @@ def test_four_processes_on_a_2x2_grid(hip, oracle, inputs, two_stage_min):
     Z = d.assemble_global({(o[0], o[1]): o[4] for o in outs}, n, n, nb, nprow, npcol)
     assert np.abs(A @ Z - (B @ Z) * w).max() <= 1e-12
     assert np.abs(Z.T @ B @ Z - np.eye(n)).max() <= 1e-11
+    # 2 x 2 against 1 x 4: the same team, the same bits
+    Z1 = d.assemble_global({(0, r): o[7] for r, o in enumerate(outs)}, n, n, outs[0][8], 1, world)
+    assert np.array_equal(outs[0][6], w) and np.array_equal(Z1, Z)
     if inputs == "distributed":      # B_loc came back as the pieces of L
         L = np.tril(d.assemble_global({(o[0], o[1]): o[5] for o in outs}, n, n, nb, nprow, npcol))
         assert np.abs(L @ L.T - B).max() <= 16 * n * EPS * np.abs(B).max()
