@@ -53,6 +53,9 @@ struct DcBufs {
   double *orgnrm;                // 1
   // team form of a height (StedcTeam): S is formed for the columns of rank tR's strips only (tP == 0: all columns)
   int tP = 0, tR = 0;
+  // ... and the secular equation / the Loewner weights for the roots (weights) tc * tR .. tc * (tR + 1) - 1 of every merge only
+  int tc = 0;
+  double *kd = nullptr;          // n: the origin pole of each root as a double (it travels with tauv in the team's all-gathers)
 };
 constexpr int kStrip = 128;      // strip width of the team form (compact basis columns)
 
@@ -501,13 +504,22 @@ __global__ void dc_secular_kernel(int mbeg, DcBufs b) {
   const int i = gid / SP, sub = gid % SP;
   const int k = b.k[mi];
   if (i >= k) return;
+  if (b.tP > 0 && i / b.tc != b.tR) return;      // (another rank's roots)
   int K; double tau;
   secular_root(k, i, sub, b.dl + mg.off, b.zl + mg.off, b.rho[mi], &K, &tau);
   if (sub == 0) {
     b.korig[mg.off + i] = K;
     b.tauv[mg.off + i] = tau;
     b.d[mg.off + i] = b.dl[mg.off + K] + tau;    // new eigenvalue, W column i
+    if (b.tP > 0) b.kd[mg.off + i] = (double)K;
   }
+}
+// after the team's all-gather of kd: the origins as the later kernels read them
+__global__ void dc_korig_kernel(int mbeg, DcBufs b) {
+  const int mi = mbeg + blockIdx.y;
+  const Merge mg = b.merges[mi];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b.k[mi]) b.korig[mg.off + i] = (int)b.kd[mg.off + i];
 }
 
 // Loewner / Gu-Eisenstat weights: zhat_j = sign(z_j) sqrt(| prod_i (d_j - lam_i) / prod_{i!=j} (d_j - d_i) |)
@@ -518,6 +530,7 @@ __global__ void dc_zhat_kernel(int mbeg, DcBufs b) {
   const int j = gid / SP, sub = gid % SP;          // SP lanes share one weight (they split the product)
   const int k = b.k[mi];
   if (j >= k) return;
+  if (b.tP > 0 && j / b.tc != b.tR) return;      // (another rank's weights)
   const double *dl = b.dl + mg.off, *tauv = b.tauv + mg.off;
   const int *korig = b.korig + mg.off;
   const double dj = dl[j];
@@ -797,7 +810,8 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     auto dv = [&](size_t cnt) { double *r = (double *)p; p += al256(cnt * 8); return r; };
     b.d = dv(n + 8); b.e = dv(n + 8); b.dsort = dv(n + 8); b.zsort = dv(n + 8); b.dl = dv(n + 8);
     b.zl = dv(n + 8); b.zhat = dv(n + 8); b.tauv = dv(n + 8); b.rotc = dv(n + 8); b.rots = dv(n + 8);
-    double *spare1 = dv(n + 8), *spare2 = dv(n + 8); (void)spare1; (void)spare2;
+    b.kd = dv(n + 8);
+    double *spare2 = dv(n + 8); (void)spare2;
     b.rho = dv(L.nmerge_cap); b.orgnrm = (double *)p;
     char *q = base + L.off_int;
     auto iv = [&](size_t cnt) { int *r = (int *)q; q += al256(cnt * 4); return r; };
@@ -928,8 +942,47 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
     const int gy = std::min(maxn, std::max(1, 4096 / std::max(1, gx * cnt)));
     hipLaunchKernelGGL(dc_permute_kernel, dim3(gx, gy, cnt), dim3(256), 0, s, mbeg, b, Q, ldq, W, ldw);
     hipLaunchKernelGGL(dc_rotate_kernel, dim3(gx, cnt), dim3(256), 0, s, mbeg, b, W, ldw);
-    hipLaunchKernelGGL(dc_secular_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
-    hipLaunchKernelGGL(dc_zhat_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
+    const int tdepth = nlev - 1 - (int)lv;            // 0: the top merge, 1: right below it
+    const bool tshard = tlevels > 0 && tdepth <= tlevels;
+    if (tshard) {
+      // Team form: the roots (then the Loewner weights) of every merge of this height in P equal runs, a run per rank; the
+      // three vectors (shift, origin, new eigenvalue -- then the weights) change hands in all-gathers of n_m doubles per
+      // merge.  Same arithmetic per root: same bits.
+      const int tc = round_up(ceil_div(maxn, tP), 2);
+      const int r0 = team->rank >= 0 ? team->rank : 0, r1 = team->rank >= 0 ? team->rank + 1 : tP;
+      auto exchange = [&](double *vec) {
+        if (team->rank < 0) return;
+        for (auto &m : plan.levels[lv]) {
+          size_t offs[kMaxTeam], counts[kMaxTeam];
+          for (int r = 0; r < tP; ++r) {
+            const int a = std::min(r * tc, m.n), e2 = std::min((r + 1) * tc, m.n);
+            offs[r] = (size_t)m.off + a; counts[r] = (size_t)(e2 - a);
+          }
+          double *bufs[1] = {vec};
+          team->x->allgatherv(s, 1, team->rank, bufs, offs, counts, tP, team->x->user);
+        }
+      };
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int r = r0; r < r1; ++r) {
+          hipEvent_t e0 = nullptr, e1 = nullptr;
+          if (tprof && team->rank < 0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, s); }
+          b.tP = tP; b.tR = r; b.tc = tc;
+          if (pass == 0) hipLaunchKernelGGL(dc_secular_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
+          else hipLaunchKernelGGL(dc_zhat_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
+          b.tP = 0;
+          if (e0) { (void)hipEventRecord(e1, s); g_tprof.secs.push_back({e0, e1, 64 + 2 * tdepth + pass, r}); }
+        }
+        if (pass == 0) {
+          exchange(b.tauv); exchange(b.kd); exchange(b.d);
+          if (team->rank >= 0) hipLaunchKernelGGL(dc_korig_kernel, dim3(ceil_div(maxn, 256), cnt), dim3(256), 0, s, mbeg, b);
+        } else {
+          exchange(b.zhat);
+        }
+      }
+    } else {
+      hipLaunchKernelGGL(dc_secular_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
+      hipLaunchKernelGGL(dc_zhat_kernel, dim3(ceil_div(maxn * SP, 256), cnt), dim3(256), 0, s, mbeg, b);
+    }
     if (selecting && lv + 1 == plan.levels.size()) {
       // Top merge (off = 0, order n): every eigenvalue is known now, so the final order can be
       // fixed before the eigenvector product and only the selected columns are multiplied,
@@ -954,7 +1007,6 @@ void stedc(hipStream_t s, int n, const double *d, const double *e, double *w, do
       copy_matrix(s, n, sel->nsel, Q, ldq, Z, ldz);
       break;
     }
-    const int tdepth = nlev - 1 - (int)lv;            // 1: right below the top merge
     if (tlevels > 0 && tdepth >= 1 && tdepth <= tlevels) {
       // team form of this height (StedcTeam): S and the products of a rank's own strips only, then the strips change hands
       const int r0 = team->rank >= 0 ? team->rank : 0, r1 = team->rank >= 0 ? team->rank + 1 : tP;
