@@ -69,6 +69,16 @@ __global__ void build_v_kernel(int n, const double *__restrict__ A, int lda, dou
 
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// Gram matrices of the blocks: reflector j is zero above row j + 1, so block b's product starts at row b * KB (a multiple of
+// the GEMM's K step: the steps that remain are the same instructions on the same operands -- same bits, half the flops)
+__global__ void gram_table_kernel(int nblk, int n, int ldv, long long *offs, int *dims) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  const long long c0 = (long long)b * KB;
+  offs[3 * b] = c0 + c0 * ldv; offs[3 * b + 1] = offs[3 * b]; offs[3 * b + 2] = (long long)b * KB * KB;
+  dims[3 * b] = KB; dims[3 * b + 1] = KB; dims[3 * b + 2] = n - (int)c0;
+}
+
 }  // namespace
 
 void build_explicit_v(hipStream_t s, int n, const double *A, int lda, double *V, int ldv) {
@@ -137,17 +147,22 @@ void ormtr_prepare(hipStream_t s, int n, const double *V, int ldv, const double 
   (void)hipMemsetAsync(T, 0, (size_t)nblk * KB * KB * 8, s);
   const int full = nrefl / KB;            // blocks with all KB reflectors
   if (full > 0) {
+    // (the table of per-block offsets and inner dimensions lives where the couplings' scratch will be: spent by then)
+    long long *offs = (long long *)Tmp;
+    int *dims = (int *)(offs + 3 * (size_t)full);
+    hipLaunchKernelGGL(gram_table_kernel, dim3(ceil_div(full, 256)), dim3(256), 0, s, full, n, ldv, offs, dims);
     GemmDesc g{};
     g.M = KB; g.N = KB; g.K = n; g.transA = true; g.transB = false; g.alpha = 1.0; g.beta = 0.0;
-    g.A = V; g.lda = ldv; g.strideA = (long long)KB * ldv;
-    g.B = V; g.ldb = ldv; g.strideB = (long long)KB * ldv;
-    g.C = G; g.ldc = KB; g.strideC = (long long)KB * KB;
+    g.A = V; g.lda = ldv; g.strideA = 0;
+    g.B = V; g.ldb = ldv; g.strideB = 0;
+    g.C = G; g.ldc = KB; g.strideC = 0;
     g.batch = full; g.lower_only = false;
+    g.d_offs = offs; g.d_dims = dims; g.even_offs = (ldv & 1) == 0;
     gemm(s, g);
   }
   if (full < nblk) {
     const int c0 = full * KB, kb = nrefl - c0;
-    gemm(s, true, false, kb, kb, n, 1.0, V + (size_t)c0 * ldv, ldv, V + (size_t)c0 * ldv, ldv, 0.0,
+    gemm(s, true, false, kb, kb, n - c0, 1.0, V + (size_t)c0 + (size_t)c0 * ldv, ldv, V + (size_t)c0 + (size_t)c0 * ldv, ldv, 0.0,
          G + (size_t)full * KB * KB, KB);
   }
   // T_b: the 128x128 diagonal parts by one batched LDS kernel, then pairs are coupled bottom-up,
