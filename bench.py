@@ -359,19 +359,23 @@ def q2_traffic_record(n, ncols):
     """HBM bytes per q2_apply_nb_kernel launch from the committed PMC measurement -- only while the kernel's source is
     the file the measurement was taken from (the record carries its sha256); a stale record is not reported."""
     import hashlib
-    tpath = os.path.join(ROOT, "profiles", "r05_q2_apply_traffic.json")
     src = os.path.join(ROOT, "eigenkernel_amd", "csrc", "ek_sb2st.hip")
-    try:
-        tj = json.load(open(tpath))
-        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
-        if tj.get("n") != n or tj.get("ncols") != int(ncols):
-            return None, "profiles/r05_q2_apply_traffic.json is for another shape"
-        if tj.get("source_sha256") != sha:
-            return None, "profiles/r05_q2_apply_traffic.json is stale: ek_sb2st.hip has changed since it was measured"
-        return tj.get("hbm_bytes_per_launch"), ("profiles/r05_q2_apply_traffic.json (rocprofv3 --pmc at git %s, not live)"
-                                                % tj.get("git", "?"))
-    except Exception as exc:
-        return None, "no PMC record (%r)" % (exc,)
+    why = "no PMC record"
+    for name in ("r06_q2_apply_traffic.json", "r05_q2_apply_traffic.json"):      # the newest record that is still valid
+        tpath = os.path.join(ROOT, "profiles", name)
+        try:
+            tj = json.load(open(tpath))
+            sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+            if tj.get("n") != n or tj.get("ncols") != int(ncols):
+                why = "profiles/%s is for another shape" % name
+                continue
+            if tj.get("source_sha256") != sha:
+                why = "profiles/%s is stale: ek_sb2st.hip has changed since it was measured" % name
+                continue
+            return tj.get("hbm_bytes_per_launch"), ("profiles/%s (rocprofv3 --pmc at git %s, not live)" % (name, tj.get("git", "?")))
+        except Exception as exc:
+            why = "no PMC record (%r)" % (exc,)
+    return None, why
 
 
 _cpu_child = None    # the CPU baseline's mpiexec (leader of its own session) while it runs
@@ -1045,7 +1049,8 @@ def main():
                 try:
                     if (n, problem, n_vec) == (16384, 1, 16384):
                         anchors = {}
-                        for tag, fn in (("gpu_box_64_cores_round5", "r05_cpu_anchor_n16384_np64.json"),
+                        for tag, fn in (("gpu_box_64_cores_round6", "r06_cpu_anchor_n16384_np64.json"),
+                                        ("gpu_box_64_cores_round5", "r05_cpu_anchor_n16384_np64.json"),
                                         ("build_container_8_cores_round4", "r04_cpu_anchor_n16384_np8.json")):
                             fp = os.path.join(ROOT, "profiles", fn)
                             if os.path.exists(fp):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r05_q2_apply_traffic.json from the PMC summaries tools/r05_profile.sh left under gpurun_out/r05prof_<tag>/:
+"""profiles/r06_q2_apply_traffic.json from the PMC summaries tools/r06_profile.sh left under gpurun_out/r06prof_<tag>/:
 HBM bytes per q2_apply_nb_kernel launch = FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64 bytes,
 MI355X_MICROARCH.md) + WRITE_SIZE (16-byte stores: exact), both in KiB in the counter files; with the sha256 of the
 kernel's source file and the git commit, so that bench.py can tell a stale record.  usage: make_traffic_record.py <tag> [n]"""
@@ -34,7 +34,7 @@ NOTE = ("four blocks of sweeps per pass: WRITE_SIZE is Z stored once per bundle 
 def main():
     tag = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
-    d = os.path.join(ROOT, "gpurun_out", "r05prof_" + tag)
+    d = os.path.join(ROOT, "gpurun_out", "r06prof_" + tag)
     nf, fetch = counter(os.path.join(d, "pmc_fetch_c3.txt"), "q2_apply", "FETCH_SIZE")
     nw, write = counter(os.path.join(d, "pmc_write_c3.txt"), "q2_apply", "WRITE_SIZE")
     sha_box = open(os.path.join(d, "source_sha256.txt")).read().split()[0]
@@ -45,7 +45,7 @@ def main():
     git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     rec = {"n": n, "ncols": n, "kernel": "q2_apply_nb_kernel<4>", "git": git, "source_sha256": sha,
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex) on "
-                     "`python3 bench.py --steps 1 --warmup 0 ...` (tools/r05_profile.sh); counters are KiB; FETCH_SIZE doubled as "
+                     "`python3 bench.py --steps 1 --warmup 0 ...` (tools/r06_profile.sh); counters are KiB; FETCH_SIZE doubled as "
                      "MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE taken as is (16-byte stores)",
            "fetch_size_kib": fetch / nf, "write_size_kib": write / nw,
            "hbm_bytes_per_launch": (2.0 * fetch / nf + write / nw) * 1024.0,
@@ -53,7 +53,7 @@ def main():
            # and every group record (2 x 96 x 32 doubles, n^2 / 4096 of them) comes from memory once
            "algorithmic_bytes_per_launch": 2.0 * (n / 128.0) * (8.0 * n * n / 2.0) + (n * n / 4096.0) * 6144 * 8.0,
            "note": NOTE}
-    out = os.path.join(ROOT, "profiles", "r05_q2_apply_traffic.json")
+    out = os.path.join(ROOT, "profiles", "r06_q2_apply_traffic.json")
     json.dump(rec, open(out, "w"), indent=1)
     print(out, rec["hbm_bytes_per_launch"] / 1e12, "TB per launch")
 

@@ -1,12 +1,12 @@
 #!/bin/bash
-# round-5 profile artefacts: the default bench line (headline + other_configs + cpu baseline), rocprofv3 kernel
+# round-6 profile artefacts: the default bench line (headline + other_configs + cpu baseline), rocprofv3 kernel
 # summary of the headline command, PMC passes (MFMA instruction / busy counters; HBM traffic of q2_apply_nb_kernel).
-# usage (on the GPU box): bash tools/r05_profile.sh <tag> ; then locally: python tools/make_traffic_record.py <tag>
+# usage (on the GPU box): bash tools/r06_profile.sh <tag> ; then locally: python tools/make_traffic_record.py <tag>
 export TMPDIR=/tmp
 TAG=${1:-v1}
-O=gpurun_out/r05prof_$TAG; mkdir -p $O
+O=gpurun_out/r06prof_$TAG; mkdir -p $O
 B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-path --no-other-configs --no-symv-events --no-parity-check"
-python bench.py --steps 10 --warmup 3 > $O/bench_c3.json 2> $O/bench.err; echo "bench rc=$?"
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench.err; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-path --no-other-configs --no-symv-events --no-parity-check > $O/kt.log 2>&1; echo "kt rc=$?"
 find /tmp/kt -name "*.db" | head -1 | xargs -r -I{} python tools/rocpd_summary.py {} > $O/kernel_stats_c3.txt 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 -d /tmp/pmc1 -o pmc -- $B > $O/pmc1.log 2>&1; echo "pmc1 rc=$?"
