@@ -17,6 +17,7 @@
 #include "ek_block64.h"
 
 #include <cstdlib>
+#include <vector>
 
 namespace ek {
 namespace {
@@ -506,11 +507,12 @@ namespace {
 inline size_t al256c(size_t b) { return (b + 255) & ~(size_t)255; }
 struct PotrfDistLayout {
   int NRB, maxb;
-  size_t off_pbuf, off_infos, off_infod, off_offs, off_dims, total;
+  size_t off_pbuf, off_pbuf2, off_infos, off_infod, off_offs, off_dims, total;
   PotrfDistLayout(int n, int ld, int P) {
     NRB = ceil_div(n > 0 ? n : 1, NB); maxb = ceil_div(NRB, P) + 1;
     size_t o = 0;
     off_pbuf = o; o += al256c((size_t)(2 * NB * NB + (size_t)ld * NB) * 8);
+    off_pbuf2 = o; o += al256c((size_t)(2 * NB * NB + (size_t)ld * NB) * 8);     // (look-ahead of the team form: the next strip's message)
     off_infos = o; o += al256c((size_t)NRB * sizeof(int));
     off_infod = o; o += al256c((size_t)NRB * 8);
     off_offs = o; o += al256c((size_t)NRB * maxb * 3 * sizeof(long long));
@@ -546,24 +548,90 @@ __global__ void first_info_kernel(int nrb, const double *v, int *d_info) {
 
 size_t potrf_dist_work_bytes(int n, int ld, int nranks) { return PotrfDistLayout(n, ld, nranks > 0 ? nranks : 1).total; }
 
-void potrf_lower_dist(hipStream_t s, int n, int nmem, const PotrfMember *mem, const SytrdExchange &x) {
+// optional timing of the team form (tools/team_timing.py): HIP events around every owner's chain (factor + invert the
+// diagonal block, solve the panel) and around every "rest of the update" section, on the streams they run on
+namespace {
+struct PotrfProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;      // pairs (begin, end)
+  std::vector<int> kind;           // per pair: 0 = chain, 1 = rest of the update
+  hipEvent_t mark(hipStream_t st) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    (void)hipEventRecord(e, st);
+    ev.push_back(e);
+    return e;
+  }
+};
+PotrfProf g_pprof;
+int g_potrf_la = -1;               // look-ahead of the team form: 0 off, 1 on, -1 default (on)
+}  // namespace
+void potrf_dist_set_lookahead(int on) { g_potrf_la = on; }
+void potrf_dist_profile(bool on) {
+  for (auto &e : g_pprof.ev) (void)hipEventDestroy(e);
+  g_pprof.ev.clear(); g_pprof.kind.clear();
+  g_pprof.on = on;
+}
+// after the streams have been synchronised (a rehearsal WITHOUT look-ahead: the sections do not overlap): seconds[0] = all
+// chains, [1] = all rest-of-update sections, [2] = the first chain + sum over the strips of max(chain of strip k + 1,
+// (update of strip k) / P): what the two cost a rank of a real team of P when the chain (one rank, the others wait for
+// its broadcast) runs beside the update (every rank its 1 / P)
+void potrf_dist_profile_collect(double *seconds, int P) {
+  seconds[0] = seconds[1] = seconds[2] = 0.0;
+  double last_update = -1.0;
+  for (size_t q = 0; q < g_pprof.kind.size(); ++q) {
+    float ms = 0.f;
+    if (!(g_pprof.ev[2 * q] && g_pprof.ev[2 * q + 1] && hipEventElapsedTime(&ms, g_pprof.ev[2 * q], g_pprof.ev[2 * q + 1]) == hipSuccess)) continue;
+    const double t = ms * 1e-3;
+    seconds[g_pprof.kind[q]] += t;
+    if (g_pprof.kind[q] == 1) {
+      if (last_update >= 0.0) seconds[2] += last_update / (P > 0 ? P : 1);
+      last_update = t;
+    } else {
+      const double u = last_update >= 0.0 ? last_update / (P > 0 ? P : 1) : 0.0;
+      seconds[2] += (t > u) ? t : u;
+      last_update = -1.0;
+    }
+  }
+  if (last_update >= 0.0) seconds[2] += last_update / (P > 0 ? P : 1);
+  potrf_dist_profile(g_pprof.on);
+}
+
+// Look-ahead (round 6; the single-GPU form and the team's dense -> band stage have had it): once strip k is in place
+// everywhere, the owner of strip k + 1 updates THAT strip first; its chain (factor + invert the diagonal block, solve the
+// panel), the broadcast of [inverse | block | panel] and the unpacking on every member then run on the second stream s2
+// while all members apply strip k to the rest of their strips on s.  The message buffer is double-buffered for that.
+// Until round 5 the owner's chain (0.1 - 0.15 ms, 256 of them at N = 32768) stood between every two updates while P - 1
+// ranks waited.  Same arithmetic on every element as without (s2 == nullptr or potrf_dist_set_lookahead(0)): same bits.
+void potrf_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const PotrfMember *mem, const SytrdExchange &x) {
   set_attrs();
   if (n <= 0 || nmem <= 0 || nmem > kMaxTeam) return;
   const int P = x.nranks;
   const PotrfDistLayout Ly(n, mem[0].ldb, P);
   const int NRB = Ly.NRB;
-  double *pbuf[kMaxTeam], *infod[kMaxTeam];
+  static bool evs = false;
+  static hipEvent_t evA[2], evB[2];
+  if (!evs) {
+    for (int q = 0; q < 2; ++q) {
+      (void)hipEventCreateWithFlags(&evA[q], hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&evB[q], hipEventDisableTiming);
+    }
+    evs = true;
+  }
+  const bool la_on = s2 != nullptr && g_potrf_la != 0 && NRB > 1;
+  double *pbuf[2][kMaxTeam], *infod[kMaxTeam];
   int *infos[kMaxTeam]; long long *offs[kMaxTeam]; int *dims[kMaxTeam];
   for (int m = 0; m < nmem; ++m) {
     char *w = (char *)mem[m].work;
-    pbuf[m] = (double *)(w + Ly.off_pbuf); infos[m] = (int *)(w + Ly.off_infos);
+    pbuf[0][m] = (double *)(w + Ly.off_pbuf); pbuf[1][m] = (double *)(w + Ly.off_pbuf2); infos[m] = (int *)(w + Ly.off_infos);
     infod[m] = (double *)(w + Ly.off_infod); offs[m] = (long long *)(w + Ly.off_offs); dims[m] = (int *)(w + Ly.off_dims);
     (void)hipMemsetAsync(infos[m], 0, (size_t)NRB * sizeof(int), s);
     hipLaunchKernelGGL(potrf_table_kernel, dim3(NRB), dim3(round_up(Ly.maxb, 64)), 0, s, n, mem[m].ldb, P,
                        mem[m].rank, NRB, Ly.maxb, offs[m], dims[m]);
   }
-  size_t zoffs[kMaxTeam], cnts[kMaxTeam];
-  for (int k = 0; k < NRB; ++k) {
+  // strip k on stream sp through message buffer `buf`: the owner factors it and solves the panel; one broadcast; every
+  // member stores the inverse, the block and the panel (L and the block inverses end up complete on all ranks)
+  auto issue_strip = [&](hipStream_t sp, int k, int buf) {
     const int off = k * NB, nbk = (n - off < NB) ? n - off : NB, mrows = n - off - nbk;
     const int owner = k % P;
     const size_t count = (size_t)2 * NB * NB + (size_t)mrows * nbk;
@@ -571,34 +639,77 @@ void potrf_lower_dist(hipStream_t s, int n, int nmem, const PotrfMember *mem, co
       if (mem[m].rank != owner) continue;
       const PotrfMember &M = mem[m];
       double *Bd = M.B + (size_t)off + (size_t)off * M.ldb;
-      double *pinv = pbuf[m], *pdiag = pbuf[m] + NB * NB, *ppan = pbuf[m] + 2 * NB * NB;
-      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), kDiagLds, s, nbk,
+      double *pinv = pbuf[buf][m], *pdiag = pbuf[buf][m] + NB * NB, *ppan = pbuf[buf][m] + 2 * NB * NB;
+      hipEvent_t e0 = g_pprof.on ? g_pprof.mark(sp) : nullptr;
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), kDiagLds, sp, nbk,
                          Bd, M.ldb, pinv, infos[m] + k, off);
-      copy_matrix(s, nbk, nbk, Bd, M.ldb, pdiag, NB);
-      if (mrows > 0) gemm(s, false, true, mrows, nbk, nbk, 1.0, Bd + nbk, M.ldb, pinv, NB, 0.0, ppan, mrows);
+      copy_matrix(sp, nbk, nbk, Bd, M.ldb, pdiag, NB);
+      if (mrows > 0) gemm(sp, false, true, mrows, nbk, nbk, 1.0, Bd + nbk, M.ldb, pinv, NB, 0.0, ppan, mrows);
+      if (e0) { g_pprof.mark(sp); g_pprof.kind.push_back(0); }
     }
+    size_t zoffs[kMaxTeam], cnts[kMaxTeam];
     for (int r = 0; r < P; ++r) { zoffs[r] = 0; cnts[r] = (r == owner) ? count : 0; }
-    x.allgatherv(s, nmem, mem[0].rank, pbuf, zoffs, cnts, P, x.user);
+    x.allgatherv(sp, nmem, mem[0].rank, pbuf[buf], zoffs, cnts, P, x.user);
     for (int m = 0; m < nmem; ++m) {
       const PotrfMember &M = mem[m];
       double *Bd = M.B + (size_t)off + (size_t)off * M.ldb;
-      const double *pinv = pbuf[m], *pdiag = pbuf[m] + NB * NB, *ppan = pbuf[m] + 2 * NB * NB;
-      copy_matrix(s, NB, NB, pinv, NB, M.invdiag + (size_t)k * NB * NB, NB);
-      if (M.rank != owner) copy_matrix(s, nbk, nbk, pdiag, NB, Bd, M.ldb);
-      if (mrows > 0) {
-        copy_matrix(s, mrows, nbk, ppan, mrows, Bd + nbk, M.ldb);
-        const int jf = k + 1 + ((M.rank - (k + 1)) % P + P) % P;
-        if (jf < NRB && jf * NB < n) {
-          GemmDesc g{};
-          g.M = n - jf * NB; g.N = NB; g.K = nbk; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
-          g.A = M.B; g.lda = M.ldb; g.B = M.B; g.ldb = M.ldb; g.C = M.B; g.ldc = M.ldb;
-          g.batch = ceil_div(NRB - jf, P); g.lower_only = true;
-          g.d_offs = offs[m] + (size_t)k * Ly.maxb * 3; g.d_dims = dims[m] + (size_t)k * Ly.maxb * 3;
-          gemm(s, g);
-        }
+      const double *pinv = pbuf[buf][m], *pdiag = pbuf[buf][m] + NB * NB, *ppan = pbuf[buf][m] + 2 * NB * NB;
+      copy_matrix(sp, NB, NB, pinv, NB, M.invdiag + (size_t)k * NB * NB, NB);
+      if (M.rank != owner) copy_matrix(sp, nbk, nbk, pdiag, NB, Bd, M.ldb);
+      if (mrows > 0) copy_matrix(sp, mrows, nbk, ppan, mrows, Bd + nbk, M.ldb);
+    }
+  };
+  // member m applies strip k to its own strips: entries first .. of its table for step k (entry 0 = its first owned strip
+  // beyond k)
+  auto update_strips = [&](int m, int k, int first, int count) {
+    const PotrfMember &M = mem[m];
+    const int nbk = (n - k * NB < NB) ? n - k * NB : NB;
+    const int jf = k + 1 + ((M.rank - (k + 1)) % P + P) % P;
+    if (count <= 0 || jf + first * P >= NRB || (jf + first * P) * NB >= n) return;
+    GemmDesc g{};
+    g.M = n - (jf + first * P) * NB; g.N = NB; g.K = nbk; g.transA = false; g.transB = true; g.alpha = -1.0; g.beta = 1.0;
+    g.A = M.B; g.lda = M.ldb; g.B = M.B; g.ldb = M.ldb; g.C = M.B; g.ldc = M.ldb;
+    g.batch = count; g.lower_only = true;
+    g.d_offs = offs[m] + ((size_t)k * Ly.maxb + first) * 3; g.d_dims = dims[m] + ((size_t)k * Ly.maxb + first) * 3;
+    gemm(s, g);
+  };
+  auto owned_after = [&](int m, int k) {                 // strips member m owns beyond strip k
+    const int jf = k + 1 + ((mem[m].rank - (k + 1)) % P + P) % P;
+    return (jf < NRB && jf * NB < n) ? ceil_div(NRB - jf, P) : 0;
+  };
+
+  issue_strip(s, 0, 0);
+  bool waited = true;
+  for (int k = 0; k < NRB; ++k) {
+    const int cur = k & 1;
+    if (!waited) (void)hipStreamWaitEvent(s, evB[cur], 0);
+    const int mrows = n - k * NB - ((n - k * NB < NB) ? n - k * NB : NB);
+    if (mrows <= 0) break;
+    const bool has_next = k + 1 < NRB && (k + 1) * NB < n;
+    if (la_on && has_next) {
+      const int owner_next = (k + 1) % P;
+      for (int m = 0; m < nmem; ++m)                      // the next strip first, on its owner
+        if (mem[m].rank == owner_next) update_strips(m, k, 0, 1);
+      (void)hipEventRecord(evA[cur], s);
+      hipEvent_t e0 = g_pprof.on ? g_pprof.mark(s) : nullptr;
+      for (int m = 0; m < nmem; ++m) {
+        const bool own = mem[m].rank == owner_next;
+        update_strips(m, k, own ? 1 : 0, owned_after(m, k) - (own ? 1 : 0));
       }
+      if (e0) { g_pprof.mark(s); g_pprof.kind.push_back(1); }
+      (void)hipStreamWaitEvent(s2, evA[cur], 0);
+      issue_strip(s2, k + 1, cur ^ 1);
+      (void)hipEventRecord(evB[cur ^ 1], s2);
+      waited = false;
+    } else {
+      hipEvent_t e0 = g_pprof.on ? g_pprof.mark(s) : nullptr;
+      for (int m = 0; m < nmem; ++m) update_strips(m, k, 0, owned_after(m, k));
+      if (e0) { g_pprof.mark(s); g_pprof.kind.push_back(1); }
+      if (has_next) issue_strip(s, k + 1, cur ^ 1);
+      waited = true;
     }
   }
+  // (the loop leaves at the last strip, whose chain stream s has waited for at the top of that iteration)
   // first failing pivot, known to every rank
   for (int m = 0; m < nmem; ++m)
     hipLaunchKernelGGL(info_to_double_kernel, dim3(ceil_div(NRB, 256)), dim3(256), 0, s, NRB, infos[m], infod[m]);

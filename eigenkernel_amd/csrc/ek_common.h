@@ -141,7 +141,11 @@ struct SytrdExchange;
 // *d_info receives the first failing pivot on every rank (one small all-reduce at the end).
 struct PotrfMember { double *B; int ldb; double *invdiag; int *d_info; void *work; int rank; };
 size_t potrf_dist_work_bytes(int n, int ld, int nranks);
-void potrf_lower_dist(hipStream_t s, int n, int nmem, const PotrfMember *mem, const SytrdExchange &x);
+// s2: second stream (look-ahead: the next strip's chain and broadcast beside the rest of the update; nullptr: none)
+void potrf_lower_dist(hipStream_t s, hipStream_t s2, int n, int nmem, const PotrfMember *mem, const SytrdExchange &x);
+void potrf_dist_set_lookahead(int on);               // 0 off, 1 on, -1 default (on)
+void potrf_dist_profile(bool on);                    // per-strip HIP events (tools/team_timing.py)
+void potrf_dist_profile_collect(double *seconds, int P);   // [0] chains, [1] rest-of-update sections, [2] their cost to a rank of P with look-ahead; after a sync
 size_t sygst_dist_scratch_doubles(int n, int ld, int nranks);
 void sygst_lower_dist(hipStream_t s, int n, int nmem, const SygstMember *mem, const SytrdExchange &x);
 

@@ -43,7 +43,7 @@ int ek_hip_potrf_team(int n, double *B_loc, const int desc_B[9], int nteam, long
     mem[m] = PotrfMember{dB, ld, dInv, dinfo, work, nteam > 0 ? m : g_comm.rank};
   }
   g_comm.err = 0;
-  potrf_lower_dist(s, n, nmem, mem, team_exchange(nteam));
+  potrf_lower_dist(s, g_ctx.stream2, n, nmem, mem, team_exchange(nteam));
   EK_HIP_CHECK(hipGetLastError());
   for (int m = 1; m < nmem; ++m) {
     count_mismatch(s, n, n, mem[0].B, ld, mem[m].B, ld, 1, d_cnt);
@@ -625,7 +625,7 @@ int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds) {
       synth_matrix(s, n, 2, pm[m].B, ld);
     }
     EK_HIP_CHECK(hipEventRecord(e0, s));
-    potrf_lower_dist(s, n, nmem, pm, x);
+    potrf_lower_dist(s, g_ctx.stream2, n, nmem, pm, x);
     EK_HIP_CHECK(hipEventRecord(e1, s));
     sygst_lower_dist(s, n, nmem, sm, x);
     EK_HIP_CHECK(hipEventRecord(e2, s));
@@ -637,6 +637,24 @@ int ek_hip_debug_reduce_team(int n, int nteam, int reps, double *seconds) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
   if (seconds) { seconds[0] = t1 / (reps > 0 ? reps : 1); seconds[1] = t2 / (reps > 0 ? reps : 1); }
   return g_comm.err ? -996 : 0;
+}
+
+// Team Cholesky: look-ahead on / off (-1: default) and, with profile != 0, HIP events around every owner's chain and every
+// rest-of-update section of the NEXT ek_hip_debug_reduce_team rehearsal (run it with the look-ahead OFF: the sections must
+// not overlap); _get: parts[0] chains, [1] update sections, [2] first chain + sum over strips of max(next chain, update / P).
+int ek_hip_debug_potrf_team_profile(int lookahead, int profile) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  potrf_dist_set_lookahead(lookahead);
+  potrf_dist_profile(profile != 0);
+  return 0;
+}
+int ek_hip_debug_potrf_team_profile_get(int nteam, double *parts) {
+  if (!parts) return -1;
+  int rc = ensure_init(); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  EK_HIP_CHECK(hipDeviceSynchronize());
+  potrf_dist_profile_collect(parts, nteam);
+  return 0;
 }
 
 // Tuning hook: the first max_cols columns of the tridiagonalisation of the synthetic matrix with the

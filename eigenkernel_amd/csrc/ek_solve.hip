@@ -549,7 +549,7 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
     // right-looking sweep with one panel broadcast per strip: pays from three ranks on
     if (dist && g_comm.nranks >= dist_min_ranks()) {
       const PotrfMember me{wB, ld, dInv, g_ctx.d_info, pwork, g_comm.rank};
-      potrf_lower_dist(s, n, 1, &me, team_exchange(0));
+      potrf_lower_dist(s, g_ctx.stream2, n, 1, &me, team_exchange(0));
     } else if (potrf_rl) {
       potrf_lower_rl(s, g_ctx.stream2, n, wB, ld, dInv, g_ctx.d_info, pwork);
     } else {

@@ -120,6 +120,8 @@ def load_library(path=None):
         "ek_hip_debug_sy2sb_team_profile": (c_int, [c_int, c_int, c_int, c_int, _dp, _dp]),
         "ek_hip_debug_fail_next_chase": (c_int, [c_int]),
         "ek_hip_debug_stedc_team": (c_int, [c_int, c_int, c_int]),
+        "ek_hip_debug_potrf_team_profile": (c_int, [c_int, c_int]),
+        "ek_hip_debug_potrf_team_profile_get": (c_int, [c_int, _dp]),
         "ek_hip_debug_stedc_team_get": (c_int, [_dp]),
         "ek_hip_debug_last_pipe_stats": (c_int, [_dp, c_int]),
         "ek_hip_debug_workspace_bytes": (ctypes.c_ulonglong, [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
@@ -154,6 +156,7 @@ EXPORTED_SYMBOLS = (
     "ek_hip_profile_kernels", "ek_hip_profile_kernels_get", "ek_hip_debug_last_solve_stats",
     "ek_hip_debug_sy2sb_team", "ek_hip_debug_sy2sb_team_timing", "ek_hip_debug_sy2sb_team_profile", "ek_hip_debug_workspace_bytes", "ek_hip_debug_fail_next_chase", "ek_hip_debug_last_pipe_stats",
     "ek_hip_debug_stedc_team", "ek_hip_debug_stedc_team_get",
+    "ek_hip_debug_potrf_team_profile", "ek_hip_debug_potrf_team_profile_get",
 )
 
 

@@ -92,6 +92,13 @@ int ek_hip_debug_fail_next_chase(int times);
 int ek_hip_debug_stedc_team(int nranks, int levels, int profile);
 int ek_hip_debug_stedc_team_get(double *seconds);
 
+/* Team Cholesky (ek_chol.hip potrf_lower_dist): look-ahead 0 off / 1 on / -1 default; profile != 0: HIP events around every
+   owner's chain and every rest-of-update section of the next rehearsals (meaningful with the look-ahead OFF).  _get (after the
+   rehearsal): parts[0] all chains, [1] all update sections, [2] first chain + sum over the strips of max(next chain, update / nteam):
+   what the two cost a rank of a real team with the look-ahead. */
+int ek_hip_debug_potrf_team_profile(int lookahead, int profile);
+int ek_hip_debug_potrf_team_profile_get(int nteam, double *parts);
+
 /* what the staging pipeline of the last ek_hip_solve on host arrays did: out[0] bytes in, [1] span of the input transfers
    (s), [2] busy seconds of the input workers, [3..5] the same on the way out, [6] seconds the main thread waited for
    inputs, [7] for the drain at the end, [8] 100 x workers on the way in + workers on the way out, [9] 0 (round 4: directions through a pinned ring, removed), [10] seconds from the start of the pipeline to its end, [11] seconds before the first input transfer */

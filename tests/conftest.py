@@ -45,3 +45,4 @@ def _default_tridiagonalisation_after_each_gpu_test(request):
         if solver._lib is not None:
             solver._lib.ek_hip_debug_set_two_stage(-1)
             solver._lib.ek_hip_debug_stedc_team(0, -1, 0)
+            solver._lib.ek_hip_debug_potrf_team_profile(-1, 0)

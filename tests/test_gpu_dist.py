@@ -198,6 +198,14 @@ def test_potrf_team_rehearsal(hip, oracle, n, P):
     assert np.abs(got[il] - L_or[il]).max() <= 16 * n * EPS * np.abs(L_or[il]).max()
     Lg = np.tril(got)
     assert np.abs(Lg @ Lg.T - B).max() <= 16 * n * EPS * np.abs(B).max()
+    # the look-ahead (next strip's chain and broadcast on a second stream beside the rest of the update) changes no bit
+    lib = hip.load_library()
+    assert lib.ek_hip_debug_potrf_team_profile(0, 0) == 0
+    try:
+        off, info_off, mismatch_off = hip.potrf_team(B, P)
+    finally:
+        assert lib.ek_hip_debug_potrf_team_profile(-1, 0) == 0
+    assert info_off == 0 and mismatch_off == 0 and np.array_equal(np.tril(off), np.tril(got))
 
 
 def test_potrf_team_reports_the_failing_pivot_on_every_rank(hip, oracle):
@@ -390,6 +398,10 @@ def _mp_worker(rank, world, port, q):
         Lg, info, _ = sv.potrf_team(B, 0)
         assert info == 0
         out["potrf"] = np.tril(Lg)
+        assert lib.ek_hip_debug_potrf_team_profile(0, 0) == 0      # the same without the look-ahead: same bits
+        Lg0, info0, _ = sv.potrf_team(B, 0)
+        assert lib.ek_hip_debug_potrf_team_profile(-1, 0) == 0
+        assert info0 == 0 and np.array_equal(np.tril(Lg0), out["potrf"])
         C, info = sv.sygst_team(A, np.tril(Lg), 0)
         assert info == 0
         own = [c for c in range(n) if (c // 128) % world == rank]

@@ -62,8 +62,22 @@ stage = (ctypes.c_double * 8)()
 for P in teams:
     if P < 2:
         continue
+    # the team's Cholesky factorisation like its dense -> band stage: the owner's chain of a strip (factor + invert the
+    # diagonal block, solve the panel) runs on ONE rank while the others wait for its broadcast, so it counts in full --
+    # measured with the look-ahead off (events around chains and rest-of-update sections), then priced with it
+    pp = (ctypes.c_double * 4)()
+    assert lib.ek_hip_debug_potrf_team_profile(0, 0) == 0
     assert lib.ek_hip_debug_reduce_team(n, P, 1, red) == 0
+    assert lib.ek_hip_debug_potrf_team_profile(0, 1) == 0
+    assert lib.ek_hip_debug_reduce_team(n, P, 1, red) == 0
+    assert lib.ek_hip_debug_potrf_team_profile_get(P, pp) == 0
+    T, C, U, M = red[0], pp[0], pp[1], pp[2]
+    potrf_serial, potrf_la = C + (T - C) / P, M + (T - C - U) / P
+    assert lib.ek_hip_debug_potrf_team_profile(-1, 0) == 0
     assert lib.ek_hip_debug_reduce_team(n, P, 2, red) == 0
+    print("n=%d team of %d rehearsed: potrf %.4f s back to back without look-ahead (chains %.4f, rest-of-update sections %.4f); per rank: "
+          "%.4f s without look-ahead, %.4f s with (model); the rehearsal with look-ahead on takes %.4f s; sygst %.4f s (%.4f per rank)"
+          % (n, P, T, C, U, potrf_serial, potrf_la, red[0], red[1], red[1] / P), flush=True)
     ncl = (n + P - 1) // P
     dZ = dmalloc((ncl + 64) * n * 8)
     # the D&C's team form (heights below the top merge sharded by strips) rehearsed inside the cell's solve: the cell plays
@@ -81,7 +95,7 @@ for P in teams:
     stedc_rank = stage[4] - dc[1] + dc[2]
     print("n=%d P=%d D&C: stage %.4f s with every rank's sections back to back (%.4f s of sections, the longest rank's %.4f) -> %.4f s per rank"
           % (n, P, stage[4], dc[1], dc[2], stedc_rank), flush=True)
-    parts = {"potrf (team)": red[0] / P, "sygst (team)": red[1] / P, "dense->band (team, look-ahead, chain in full)": d2b[P][1],
+    parts = {"potrf (team, look-ahead, chain in full)": potrf_la, "sygst (team)": red[1] / P, "dense->band (team, look-ahead, chain in full)": d2b[P][1],
              "band->tridiagonal (replicated)": ts[1], "stedc (team form below the top merge, top merge on own columns)": stedc_rank,
              "Q2 + Q1 (own columns)": stage[5], "recovery (own columns)": stage[6]}
     print("n=%d P=%d per-rank compute: %.3f s = %s   [dense->band without look-ahead: %.3f]" % (n, P, sum(parts.values()),
