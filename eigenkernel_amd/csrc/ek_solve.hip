@@ -651,7 +651,15 @@ int solve_device_locked(int problem, int n, int n_vec, double *dA, int lda, doub
   // round per P strips: ek_stedc.hip); the top merge forms this cell's columns only, as in the replicated-input mode.
   SytrdExchange dcx{};
   StedcTeam dct{0, 0, nullptr, 0};
-  if (dist && g_comm.nranks >= 2) { dcx = team_exchange(0); dct = StedcTeam{g_comm.nranks, g_comm.rank, &dcx, stedc_team_levels(n, g_comm.nranks)}; }
+  if (dist && g_comm.nranks >= 2) {
+    // (the team form needs the compact bases, and EVERY rank must take the same decision or the all-gathers never meet:
+    // a team of two on a ragged order can leave one rank with more than half of the columns -- then nobody shards)
+    const int P = g_comm.nranks, nbz = cell->nb, Pc = split_rows ? P : cell->npcol;
+    bool all_compact = true;
+    for (int r = 0; r < Pc; ++r) all_compact = all_compact && stedc_compact(n, numroc0(n_vec, nbz, r, Pc));
+    dcx = team_exchange(0);
+    dct = StedcTeam{P, g_comm.rank, &dcx, all_compact ? stedc_team_levels(n, P) : 0};
+  }
   else if (cell && !dist && g_debug_dc_team >= 2) dct = StedcTeam{g_debug_dc_team, -1, nullptr, stedc_team_levels(n, g_debug_dc_team)};
   stedc(s, n, dd, de, dwv, wZ, ld, work, g_ctx.d_info + 1, &pick, g_ctx.d_stats, nullptr, dct.levels > 0 ? &dct : nullptr);
   mark();                                                              // 5

@@ -797,3 +797,80 @@ def test_stedc_team_rehearsal_changes_no_bit(hip, oracle, n, P, levels, n_vec, g
         assert sec[0] > 0.0 and sec[1] > 0.0 and sec[2] <= sec[1] <= sec[0]      # (the team form did run)
     w_or = oracle.solve(A, B)[0] if gen else np.linalg.eigvalsh(A)
     assert np.abs(ref.values - w_or[:len(ref.values)]).max() <= 4 * n * EPS * np.abs(w_or).max()
+
+
+def _mp_ragged_pair_worker(rank, world, port, q):
+    """Two ranks, a ragged order: rank 0's share of the eigenvector columns is more than half of them (no compact D&C bases
+    there), rank 1's is not."""
+    import faulthandler
+    import sys
+    import traceback
+    try:
+        import torch.distributed as dist
+        faulthandler.dump_traceback_later(150, exit=True)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from eigenkernel_amd import solver as sv, descriptor as d
+        from oracle import ek_oracle
+        lib = sv.load_library()
+        assert lib.ek_hip_init(0) == 0
+        sv.set_allgatherv(sv.torch_allgatherv(dist))
+        sv.comm_attach_host(world, rank)
+        n = 1111
+        A = ek_oracle.synth_matrix(n, 1)
+        proc = sv.Process(rank, world, 0, 1, world, 0, rank)
+        sv.stedc_team(0, 2)                      # the team form asked for at this order
+        ep, _ = sv.eigen_solver("hip", A, None, proc=proc)
+        sv.stedc_team()
+        cols = d.local_indices(n, int(ep.desc[d.BLOCK_ROW_]), rank, world)
+        out = (ep.values.copy(), cols, ep.Vectors[:, :len(cols)].copy())
+        sv.comm_destroy()
+        q.put((rank, out, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, None, traceback.format_exc()))
+    faulthandler.cancel_dump_traceback_later()
+    q.close(); q.join_thread()
+    sys.stderr.flush()
+    os._exit(0)
+
+
+def test_two_ranks_on_a_ragged_order_take_the_same_decision_about_the_team_form(hip, oracle):
+    """The D&C's team form needs the compact bases (a rank's columns at most half of them).  With two ranks and 64-wide blocks
+    dealt round robin, order 1111 gives rank 0 576 columns (> 556) and rank 1 535: the decision has to be the team's, not the
+    rank's, or rank 1 waits in an all-gather that rank 0 never enters (ek_solve.hip: all_compact)."""
+    import multiprocessing as mp
+    import queue as _queue
+    world, n = 2, 1111
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mp_ragged_pair_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in procs:
+            got.append(q.get(timeout=300 if not got else 120))
+    except _queue.Empty:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        pytest.fail("only %d of %d ranks reported: the ranks did not agree about the team form" % (len(got), world))
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.terminate()
+    for rank, out, err in got:
+        assert err is None, "rank %d:\n%s" % (rank, err)
+    outs = [g[1] for g in sorted(got, key=lambda t: t[0])]
+    A = oracle.synth_matrix(n, 1)
+    w = np.linalg.eigvalsh(A)
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.abs(outs[0][0] - w).max() <= 4 * n * EPS * np.abs(w).max()
+    Z = np.zeros((n, n))
+    for _, cols, Zl in outs:
+        Z[:, cols] = Zl[:n, :]
+    assert np.abs(A @ Z - Z * outs[0][0]).max() <= 1e-12
+    assert np.abs(Z.T @ Z - np.eye(n)).max() <= 1e-11
