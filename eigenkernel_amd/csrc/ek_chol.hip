@@ -443,11 +443,7 @@ static void trsm_rlt_lower(hipStream_t s, int n, const double *L, int ldl, const
 // and largest GEMMs); above it the blocked recursion (n^3).  Measured on MI355X at N = 16384
 // (sygst stage), round 1: no recursion 0.133 s, threshold 2048 -> 0.115 s, 1024 -> 0.120 s, 512 -> 0.126 s;
 // with the 16-byte-load GEMM of round 2: 1024 -> 0.110, 2048 -> 0.103, 4096 -> 0.099, 8192 -> 0.099, none 0.115.
-static int sygst_direct() {      // (EK_SYGST_DIRECT: tuning)
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("EK_SYGST_DIRECT"); v = e ? atoi(e) : 4096; if (v < 256) v = 256; }
-  return v;
-}
+static int sygst_direct() { return 4096; }      // (the scan above; the tuning switch went in round 6)
 
 // Recursive blocked DSYGST(itype = 1, 'L'):  with A = [A11 .; A21 A22], L = [L11 0; L21 L22]
 //   C11 = sygst(A11, L11)

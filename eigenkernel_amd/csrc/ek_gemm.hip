@@ -673,11 +673,8 @@ void gemm(hipStream_t s, const GemmDesc &g) {
   // lower_only is defined on the 128x128 tiling (callers rely on whole diagonal tiles being
   // written), so the small-grid variant is used for plain products only
   const long long big_tiles = (long long)ceil_div(g.M, BM) * ceil_div(g.N, BN) * g.batch;
-  // lower-only products of one batch entry: a grid of the tiles on and below the diagonal only (EK_GEMM_LOWER_COMPACT=0:
-  // the full grid, whose upper workgroups leave at once)
-  static int compact_env = -1;
-  if (compact_env < 0) { const char *e = getenv("EK_GEMM_LOWER_COMPACT"); compact_env = e ? atoi(e) : 1; }
-  const bool compact = compact_env && g.lower_only && g.batch == 1 && !g.d_dims && !g.d_offs;
+  // lower-only products of one batch entry: a grid of the tiles on and below the diagonal only
+  const bool compact = g.lower_only && g.batch == 1 && !g.d_dims && !g.d_offs;
   // 16-byte operand fetch: every slab start must be 16-byte aligned -- even leading dimensions, aligned bases,
   // even batch strides, no per-batch offsets from device memory (EK_GEMM_VEC=0 turns the variants off)
   static int vec_env = -1;
@@ -691,9 +688,7 @@ void gemm(hipStream_t s, const GemmDesc &g) {
       p.lower_only = 2;
       sgrid.x = (unsigned)((long long)p.tiles_n * p.tiles_m - (long long)p.tiles_n * (p.tiles_n - 1) / 2);
     }
-    static int svec = -1;
-    if (svec < 0) { const char *e = getenv("EK_GEMM_SMALL_VEC"); svec = e ? atoi(e) : 1; }
-    if (vec && svec) {
+    if (vec) {
       if (!g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, false, true>), sgrid, sblock, 0, s, p);
       else if (!g.transA && g.transB) hipLaunchKernelGGL((gemm_small_kernel<false, true, true>), sgrid, sblock, 0, s, p);
       else if (g.transA && !g.transB) hipLaunchKernelGGL((gemm_small_kernel<true, false, true>), sgrid, sblock, 0, s, p);

@@ -1485,8 +1485,7 @@ void sy2sb_lower(hipStream_t s, hipStream_t s2, int n, double *A, int lda, doubl
   if (staged_max < 0) { const char *e = getenv("EK_SY2SB_STAGED_MAX"); staged_max = e ? atoi(e) : 8192; }
   static int la_min = -1;
   if (la_min < 0) { const char *e = getenv("EK_SY2SB_LOOKAHEAD_MIN"); la_min = e ? atoi(e) : 5120; }
-  static int small_max = -1;
-  if (small_max < 0) { const char *e = getenv("EK_SY2SB_SMALL_MAX"); small_max = e ? atoi(e) : 4096; }   // N = 4096: stage 14.6 -> 13.9 ms
+  constexpr int small_max = 4096;  // (N = 4096: stage 14.6 -> 13.9 ms)
   int pair_min = 5120;             // rows of the first panel's trailing matrix from which panels go in pairs (0: never)
   { const char *e = getenv("EK_SY2SB_PAIR_MIN"); if (e) pair_min = atoi(e); }      // (read per call: the tests force pairs at small orders)
 
