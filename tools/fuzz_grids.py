@@ -16,7 +16,7 @@ ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 lib = solver.load_library(); lib.ek_hip_init(0)
 bad = 0
 for case in range(ncase):
-    n = int(rng.integers(1, 700))
+    n = int(rng.integers(1, 700)) if rng.integers(0, 4) else int(rng.integers(700, 2400))
     kind = ["synth", "synth", "diag", "identity", "clustered", "block"][int(rng.integers(0, 6))]
     if kind == "synth": A = ok.synth_matrix(n, 1 + case % 7)
     elif kind == "diag": A = np.diag(rng.standard_normal(n))
@@ -41,6 +41,10 @@ for case in range(ncase):
     solver.set_allgatherv(hook if inputs == "distributed" else None)
     pieces = {}
     okv = True
+    # half of the cases with the D&C's team form rehearsed by every cell (a team of the grid's columns, 1 - 3 heights
+    # forced: small orders, heavy deflation, ragged strips): must change no bit
+    team = npcol >= 2 and bool(rng.integers(0, 2))
+    solver.stedc_team(npcol, int(rng.integers(1, 4))) if team else solver.stedc_team()
     for rank in range(nprow * npcol):
         hook.state["rank"] = rank
         myrow, mycol = rank // npcol, rank % npcol
@@ -49,11 +53,12 @@ for case in range(ncase):
         okv = okv and np.array_equal(ep.values, ref.values)
         pieces[(myrow, mycol)] = ep.Vectors
     solver.set_allgatherv(None)
+    solver.stedc_team()
     Zg = d.assemble_global(pieces, n, n, nbu, nprow, npcol)
     dz = float(np.abs(Zg[:, :nv] - ref.Vectors[:, :nv]).max()) if nv else 0.0
     flag = "" if (okv and dz <= 1e-13) else "  <-- BAD"
     bad += bool(flag)
-    print("n=%4d %-9s %s grid %dx%d nb=%3d(%3d) nv=%4d %-11s values_equal=%s max|dZ|=%.1e%s"
-          % (n, kind, "GEP" if gep else "SEP", nprow, npcol, nb, nbu, nv, inputs, okv, dz, flag), flush=True)
+    print("n=%4d %-9s %s grid %dx%d nb=%3d(%3d) nv=%4d %-11s dc_team=%d values_equal=%s max|dZ|=%.1e%s"
+          % (n, kind, "GEP" if gep else "SEP", nprow, npcol, nb, nbu, nv, inputs, team, okv, dz, flag), flush=True)
 print("BAD:", bad)
 sys.exit(1 if bad else 0)
