@@ -178,7 +178,12 @@ int ek_hip_solve_device_grid(int problem, int n, int n_vec,
  * column sharding of the eigenvector stages: from order 512 on the dense -> band stage with one broadcast of
  * a panel's reflectors and one ncclAllReduce of A22 V per panel of 64 columns (the band -> tridiagonal stage
  * then runs replicated after one all-gather of the band); below, the one-stage form with one ncclAllReduce of
- * <= 2n+1 doubles per Householder column.  All exchanges are issued on the library's stream.
+ * <= 2n+1 doubles per Householder column.  Since round 6 the divide & conquer is distributed below its top merge too (from
+ * order 8192 on: the two heights under the top merge in 128-wide strips of the basis array, one ncclAllGather per round of
+ * P strips; the secular equation in P runs of roots -- bit for bit the one-GPU result), and on a grid with more than one
+ * process ROW the cells of a process column split its eigenvector columns among them and exchange row pieces pairwise
+ * at the end (grouped ncclSend / ncclRecv), so every rank back-transforms n_vec / P columns whatever the grid's shape.
+ * All exchanges are issued on the library's streams.
  * With a communicator attached ek_hip_solve also takes the reference's own data contract (block-
  * cyclic pieces of A and B in; pieces of Z, of the reflectors and of L out) on that grid WITHOUT the
  * host hook: only the local pieces cross PCIe, the full matrices are assembled in HBM by one
