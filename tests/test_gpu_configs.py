@@ -83,11 +83,14 @@ def _solve_1x1(lib, dev, gep, n, n_vec):
     return dict(dA=dA, dB=dB, dA0=dA0, dB0=dB0, dZ=dZ, dw=dw, w=w, stages=st)
 
 
-def _grid_piece_is_bit_identical(lib, dev, r, gep, n, n_vec, grid, cell, nb=64):
+def _grid_piece_is_bit_identical(lib, dev, r, gep, n, n_vec, grid, cell, nb=64, dc_team=False):
     """One rank of an nprow x npcol grid (replicated-input mode, no collective: a rank's work does not
-    depend on the others, so the one GPU can play it): its block-cyclic piece of Z equals the 1x1 result."""
+    depend on the others, so the one GPU can play it): its block-cyclic piece of Z equals the 1x1 result.
+    dc_team: with the divide & conquer's team form rehearsed by the cell (a team of npcol ranks, the library's own number
+    of sharded heights for the order: ek_stedc.hip StedcTeam) -- still the 1x1 result bit for bit."""
     nprow, npcol = grid
     myrow, mycol = cell
+    assert lib.ek_hip_debug_stedc_team(npcol if dc_team else 0, -1, 0) == 0
     assert lib.ek_hip_synth_matrix_device(n, 1, r["dA"], n) == 0     # the solve destroyed A and B
     if gep:
         assert lib.ek_hip_synth_matrix_device(n, 2, r["dB"], n) == 0
@@ -110,6 +113,7 @@ def _grid_piece_is_bit_identical(lib, dev, r, gep, n, n_vec, grid, cell, nb=64):
             assert lib.ek_hip_memcpy_d2h(blk[:, k:k + 1].ctypes.data, ctypes.c_void_p(r["dZ"].value + int(c) * n * 8),
                                          n * 8) == 0
         assert np.array_equal(Zl[:, c0:c0 + len(cols)], blk[ri, :])
+    assert lib.ek_hip_debug_stedc_team(0, -1, 0) == 0
 
 
 def test_c2_n4096_standard_full_spectrum(hip, golden_dir):
@@ -146,6 +150,7 @@ def test_c5_n16384_generalized_lowest_1024(hip, golden_dir):
         _acceptance(lib, True, n, n_vec, r["dA0"], r["dB0"], r["dw"], r["dZ"])
         # rank (0, 2) of the 2 x 4 grid layout_procs gives 8 ranks (processes.f90:56-65)
         _grid_piece_is_bit_identical(lib, dev, r, True, n, n_vec, (2, 4), (0, 2))
+        _grid_piece_is_bit_identical(lib, dev, r, True, n, n_vec, (2, 4), (1, 1), dc_team=True)
 
 
 def test_c4_n32768_generalized_full_spectrum(hip, golden_dir):
@@ -162,6 +167,7 @@ def test_c4_n32768_generalized_full_spectrum(hip, golden_dir):
         # the generator's spectrum: GEP eigenvalues inside [0.38, 2.63]
         assert 0.3 < w[0] < 0.5 and 2.4 < w[-1] < 2.8
         _grid_piece_is_bit_identical(lib, dev, r, True, n, n, (2, 4), (1, 3))
+        _grid_piece_is_bit_identical(lib, dev, r, True, n, n, (1, 8), (0, 5), dc_team=True)
 
 
 @pytest.mark.parametrize("gep,n,n_vec", [(True, 1024, 1024), (False, 1280, 1280), (True, 1024, 200)])
